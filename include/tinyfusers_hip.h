@@ -1,0 +1,179 @@
+/*
+ * tinyfusers_hip.h -- C ABI of libtinyfusers_hip.so, the MI355X (gfx950) native backend that takes the
+ * place of the reference's `tinyfusers/native` ctypes layer (libcuda / libcudart / libnvrtc / libcublas
+ * bindings, native/cuda/ops.py, native/cublas/ops.py, native/nvrtc/ops.py) and of the cuDNN / CuPy
+ * calls the reference's per-op Python surface makes.
+ *
+ * Conventions (same as the reference's FFI):
+ *   - every function returns int, 0 = success, otherwise a hipError_t value or a TF_E_* code; callers
+ *     raise RuntimeError("<fn> failed with status N") exactly as storage/device.py:33-37 does.
+ *     tf_last_error() additionally returns a thread-local human-readable string.
+ *   - plain pointers and sizes only; device memory is caller-owned raw `void*`; opaque handles are
+ *     created through an out-pointer and destroyed by the caller; no callbacks; nothing aborts.
+ *   - all kernels are asynchronous on the given stream (NULL = the default stream, which is what the
+ *     reference always uses: `stream := cuda.CUstream()`), safe to capture into a HIP graph.
+ *   - activations are fp16 ("f16"), images in NHWC, tokens in (rows, C) row-major; accumulation fp32.
+ *     NCHW fp32 (the reference's layout/dtype) only appears in the layout converters.
+ * Each entry cites the reference interface (file:line under /root/reference) it replaces.
+ */
+#ifndef TINYFUSERS_HIP_H
+#define TINYFUSERS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tfStream_st* tfStream_t;
+typedef struct tfEvent_st* tfEvent_t;
+typedef struct tfGraph_st* tfGraph_t;
+
+#define TF_OK 0
+#define TF_E_ARG 10001
+#define TF_E_UNSUPPORTED 10002
+#define TF_E_WORKSPACE 10003
+#define TF_E_STATE 10004
+
+/* cudaMemcpy kinds kept numerically identical to native/cuda/ops.py:95-96 */
+#define TF_MEMCPY_H2D 1
+#define TF_MEMCPY_D2H 2
+#define TF_MEMCPY_D2D 3
+
+/* ---- context / device ------------------------------------------------------------------------ */
+/* cuInit + cuCtxCreate_v2 (native/cuda/ops.py:7-18; call site storage/device.py:32-37) */
+int tf_init(int device);
+int tf_device_count(int* count);
+/* cudaDeviceGetAttribute (native/cuda/ops.py:62-66). attr: 0 = CU count, 1 = max clock kHz,
+ * 2 = wavefront size, 3 = LDS bytes per workgroup, 4 = L2 bytes, 5 = total memory MiB. */
+int tf_device_attr(int* value, int attr, int device);
+/* gcn arch name ("gfx950:...") copied into buf */
+int tf_device_arch(char* buf, int buflen, int device);
+const char* tf_last_error(void);
+int tf_version(void);
+
+/* ---- memory: cudaMalloc / cudaMemcpy / cudaFree (native/cuda/ops.py:45-60; storage/tensor.py:20-46) */
+int tf_malloc(void** out, size_t nbytes);
+int tf_free(void* ptr);
+int tf_memcpy(void* dst, const void* src, size_t nbytes, int kind);
+int tf_memcpy_async(void* dst, const void* src, size_t nbytes, int kind, tfStream_t stream);
+int tf_memset_async(void* dst, int value, size_t nbytes, tfStream_t stream);
+/* strided device-to-device row copy (weight re-packing at install time: GEGLU block interleave, K padding) */
+int tf_memcpy_2d_async(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t height,
+                       tfStream_t stream);
+int tf_host_alloc(void** out, size_t nbytes);   /* pinned host memory for async H2D of step parameters */
+int tf_host_free(void* ptr);
+
+/* ---- streams / events / graphs.  The reference has only the NULL stream and device-wide syncs
+ * (attention/sdpa.py:70-71, variants/sd.py:40-41, ff/group_norm.py:6); timing is host-side
+ * (example/sd1.py:71).  Here: explicit streams, HIP-event timing and whole-step HIP graphs. */
+int tf_stream_create(tfStream_t* out);
+int tf_stream_destroy(tfStream_t s);
+int tf_stream_sync(tfStream_t s);
+int tf_device_sync(void);
+int tf_event_create(tfEvent_t* out);
+int tf_event_destroy(tfEvent_t e);
+int tf_event_record(tfEvent_t e, tfStream_t s);
+int tf_event_sync(tfEvent_t e);
+int tf_event_elapsed_ms(float* ms, tfEvent_t start, tfEvent_t stop);
+int tf_graph_begin_capture(tfStream_t s);
+int tf_graph_end_capture(tfStream_t s, tfGraph_t* out);
+int tf_graph_launch(tfGraph_t g, tfStream_t s);
+int tf_graph_destroy(tfGraph_t g);
+/* per-launch profiling of the GEMM/conv kernel family with HIP events on the launch stream
+ * (bench.py roofline leg): enable, run eagerly, then read back accumulated ms / flops / launches. */
+int tf_prof_enable(int on);
+int tf_prof_read(double* gemm_ms, double* gemm_flops, long long* gemm_launches);
+/* test / tuning hook: force the GEMM tile (bm x bn in {128,64} x {160,128,64}) and split-K; 0,0,0 = heuristic */
+int tf_gemm_force_config(int bm, int bn, int splitk);
+
+/* ---- layout / dtype converters (the API edge: the reference's arrays are fp32 NCHW) ----------- */
+int tf_nchw_f32_to_nhwc_f16(void* dst, const void* src, int N, int C, int H, int W, tfStream_t s);
+int tf_nhwc_f16_to_nchw_f32(void* dst, const void* src, int N, int C, int H, int W, tfStream_t s);
+int tf_cast_f32_to_f16(void* dst, const void* src, long long n, tfStream_t s);
+int tf_cast_f16_to_f32(void* dst, const void* src, long long n, tfStream_t s);
+
+/* ---- conv2d / linear: one implicit-GEMM MFMA kernel family ------------------------------------
+ * tf_conv2d_f16 replaces conv_2d + Conv2d.__call__ (vision/conv2d.py:9-28, :48-58: cuDNN conv_fprop graph
+ * rebuilt per call + NHWC->NCHW re-view + separate bias kernel), and folds in what surrounds it in the
+ * UNet: the channel concat of vision/unet.py:72 (x2/C2), the nearest-2x upsample of unet.py:81-83
+ * (upsample=1), the time-embedding broadcast add of vision/resnet.py:28 (bias_nc, one row per image) and
+ * the residual add of resnet.py:30 / attention.py:75 (residual).
+ *   x  : (N, H, W, C1) f16;  x2 : (N, H, W, C2) f16 or NULL (C2 = 0)
+ *   w  : (Cout, R, S, C1+C2) f16 ("KRSC": the reference's (K,C,R,S) weight, vision/conv2d.py:52, with C innermost)
+ *   bias : (Cout) f16 or NULL; residual : (N, Ho, Wo, Cout) f16 or NULL
+ *   bias_nc : per-image bias rows f16 or NULL, image i reads bias_nc + i*bias_nc_stride (stride 0 = one row
+ *             broadcast to every image, which is what resnet.py:28 does with its (1, C) embedding)
+ *   y  : (N, Ho, Wo, Cout) f16, Ho = (H*(1+upsample) + 2*pad - R)/stride + 1
+ *   workspace: fp32 scratch for split-K (may be NULL if tf_conv2d_workspace() returned 0).
+ * Requirements: (C1+C2) % 8 == 0; R,S in {1,3} (any odd), dilation 1, groups 1 (all the UNet uses). */
+int tf_conv2d_f16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc,
+                  long long bias_nc_stride, const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R,
+                  int S, int stride, int pad, int upsample, void* workspace, size_t workspace_bytes, tfStream_t s);
+size_t tf_conv2d_workspace(int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample);
+/* tf_linear_f16 replaces Linear.__call__ (ff/linear.py:112-121; live branch cp.dot(x, W^T)+b) and the
+ * test-only cuBLAS/cuDNN paths linear_cublas / linear / gemm_batch (ff/linear.py:8-110):
+ *   y(M,N) = act(x(M,K) . w(N,K)^T + bias(N)) + residual(M,N)
+ * act: 0 none; 1 GEGLU (ff/nn.py:10-12): w holds 2*N rows packed by tf_pack_geglu order
+ *      (16-row blocks alternating value / gate), bias likewise, y(M,N) = a * gelu_tanh(gate). */
+int tf_linear_f16(void* y, const void* x, const void* w, const void* bias, const void* residual, int M, int N, int K,
+                  int act, void* workspace, size_t workspace_bytes, tfStream_t s);
+size_t tf_linear_workspace(int M, int N, int K, int act);
+/* M == 1..8 weight-streaming GEMV with optional SiLU on the input (the time-embedding MLP and the 22
+ * ResBlock emb_layers, vision/unet.py:53-54, vision/resnet.py:27): y(M,N) = silu?(x)(M,K) . w(N,K)^T + b */
+int tf_gemv_f16(void* y, const void* x, const void* w, const void* bias, int M, int N, int K, int silu_input, tfStream_t s);
+
+/* ---- attention: fused flash-style SDPA, replaces scaled_dot_product_attention (attention/sdpa.py:53-77:
+ * cp.matmul + softmax_kernel (native/cuda/softmax.cu:24-112) + cp.matmul with the score matrix in HBM).
+ * o = softmax(q k^T / sqrt(HS)) v; element strides (batch, head, token) per tensor, innermost dim HS is
+ * contiguous.  Output strides select the head-merge layout: (NH*T*HS, T*HS, HS) reproduces the reference's
+ * CrossAttention (attention/attention.py:38-39, no transpose back: SURVEY D11); (T*NH*HS, HS, NH*HS) is the
+ * LDM-intended merge.  causal != 0 applies the CLIP causal mask (attention.py:94).  HS % 8 == 0, HS <= 160. */
+int tf_sdpa_f16(void* o, const void* q, const void* k, const void* v, int B, int NH, int Tq, int Tk, int HS,
+                long long q_sb, long long q_sh, long long q_st, long long k_sb, long long k_sh, long long k_st,
+                long long v_sb, long long v_sh, long long v_st, long long o_sb, long long o_sh, long long o_st,
+                int causal, tfStream_t s);
+/* row softmax over (N, C) fp32 -- Device.softmax (storage/device.py:129-157; softmax_func.cu:22-113) */
+int tf_softmax_rows_f32(void* out, const void* inp, int N, int C, tfStream_t s);
+
+/* ---- normalisation ---------------------------------------------------------------------------
+ * group_norm + GroupNorm affine (+ the SiLU that always follows it in ResBlock / UNet.out)
+ * (ff/group_norm.py:3-11, :13-21; storage/tensor.py:68-70): x,y (N, HW, C) f16 NHWC, G groups, biased var.
+ * x2/C2: optional second source for the channel concat (vision/unet.py:72): channels [C1, C1+C2) come from x2.
+ * gamma/beta f16 (C) or NULL (plain group_norm).  workspace: tf_group_norm_workspace bytes. */
+int tf_group_norm_f16(void* y, const void* x, const void* x2, const void* gamma, const void* beta, int N, int HW,
+                      int C1, int C2, int G, float eps, int silu, void* workspace, size_t workspace_bytes, tfStream_t s);
+size_t tf_group_norm_workspace(int N, int HW, int C, int G);
+/* LayerNorm over the last dim (ff/layer_norm.py:8-32, :34-49; semantics = F.layer_norm, tests/layer_norm.py:38) */
+int tf_layer_norm_f16(void* y, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s);
+
+/* ---- elementwise (storage/tensor.py:64-86; ff/nn.py:10-12; vision/unet.py:72, :81-83) ---------- */
+int tf_silu_f16(void* y, const void* x, long long n, tfStream_t s);
+int tf_sigmoid_f16(void* y, const void* x, long long n, tfStream_t s);
+int tf_gelu_f16(void* y, const void* x, long long n, tfStream_t s);
+int tf_quick_gelu_f16(void* y, const void* x, long long n, tfStream_t s);
+int tf_geglu_f16(void* y, const void* x, int rows, int C, tfStream_t s);          /* x (rows,2C) -> y (rows,C) */
+int tf_add_f16(void* y, const void* a, const void* b, long long n, tfStream_t s);
+int tf_add_bias_nc_f16(void* y, const void* x, const void* bias_nc, int N, int HW, int C, tfStream_t s);
+int tf_upsample2x_nhwc_f16(void* y, const void* x, int N, int H, int W, int C, tfStream_t s);
+int tf_concat_channels_f16(void* y, const void* a, const void* b, long long rows, int Ca, int Cb, tfStream_t s);
+/* im2col for the 4-channel conv_in (K = R*S*C padded to Kpad): y (N*Ho*Wo, Kpad) */
+int tf_im2col_nhwc_f16(void* y, const void* x, int N, int H, int W, int C, int R, int S, int stride, int pad, int Kpad, tfStream_t s);
+/* own-runtime kernels of the reference (native/cuda kernels via storage/device.py:79-233), fp32 */
+int tf_scale_f32(void* x, float scale, long long n, tfStream_t s);                        /* scale_tensor_func.cu:5-10 */
+int tf_add_bias_colmajor_f32(void* out, const void* bias, int BT, int OC, tfStream_t s);  /* add_bias_func.cu:1-9 */
+int tf_transpose_f32(void* out, const void* inp, int ndim, const int* shape, const int* axes, tfStream_t s); /* transpose.cu, transpose4d.cu */
+
+/* ---- sampler pieces (vision/unet.py:92-97; variants/sd.py:14-25, :27-46) ------------------------
+ * step_params (device, fp32): [0] timestep, [1] a_t, [2] a_prev, [3] guidance -- written by the host once per
+ * step with tf_memcpy_async so that the whole step can live in one HIP graph. */
+int tf_timestep_embedding_f16(void* out, const void* step_params, int dim, float max_period, tfStream_t s);
+/* latent (B,C,H,W) f32 NCHW  ->  unet input (2B,H,W,C) f16 NHWC = [latent ; latent]  (variants/sd.py:31) */
+int tf_cfg_duplicate_f16(void* x2b_nhwc, const void* latent_nchw_f32, int B, int C, int H, int W, tfStream_t s);
+/* e = e_u + g (e_c - e_u); DDIM sigma=0 update, latent updated in place (variants/sd.py:44-45, :14-25) */
+int tf_cfg_ddim_step_f32(void* latent_nchw_f32, const void* unet_out_2b_nhwc_f16, const void* step_params, int B, int C,
+                         int H, int W, tfStream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

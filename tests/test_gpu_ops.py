@@ -1,0 +1,243 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu): every HIP op, called through the C-ABI, against
+the CPU oracle on the same seeded inputs; per-op tolerance atol = rtol = 1e-2, the reference's own
+(tests/conv2d.py:33, tests/group_norm.py:25-28, tests/layer_norm.py:25-28, tests/sdpa.py:100)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(rtol=1e-2, atol=1e-2)
+
+
+@pytest.fixture(scope="module")
+def tf():
+    import tinyfusers_amd.storage.tensor as T
+    T.ensure_init(0)
+    return T
+
+
+def rnd(name, shape, std=1.0, seed=11):
+    from tinyfusers_amd.storage.synth import synth_normal
+    return synth_normal(seed, name, shape, std).astype(np.float16).astype(np.float32)
+
+
+def close(got, want, **kw):
+    t = dict(TOL); t.update(kw)
+    got = np.asarray(got, dtype=np.float32); want = np.asarray(want, dtype=np.float32)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.isfinite(got).all(), "non-finite output"
+    np.testing.assert_allclose(got, want, **t)
+
+
+def dev(tf, x, layout=None, dtype=np.float16):
+    return tf.DeviceArray.from_numpy(x, dtype, layout)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_device_attributes(tf):
+    import ctypes
+    from tinyfusers_amd.native import hip
+    v = ctypes.c_int()
+    hip.tf_device_attr(ctypes.byref(v), 0, 0); assert v.value == 256
+    hip.tf_device_attr(ctypes.byref(v), 2, 0); assert v.value == 64
+    buf = ctypes.create_string_buffer(64)
+    hip.tf_device_arch(buf, 64, 0); assert buf.value.decode().startswith("gfx950")
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 1000, 2 * 320 * 64 * 64 + 3])
+def test_activations(tf, n):
+    from oracle import ops as O
+    x = rnd("act", (n,), 3.0)
+    d = dev(tf, x)
+    for name in ("silu", "sigmoid", "gelu", "quick_gelu", "swish"):
+        got = getattr(tf.Tensor, name)(d).numpy()
+        want = getattr(O, "silu" if name == "swish" else name)(x).numpy()
+        close(got, want, atol=4e-3)
+
+
+def test_add_cast_layout(tf):
+    a, b = rnd("a", (3, 1003)), rnd("b", (3, 1003))
+    close((dev(tf, a) + dev(tf, b)).numpy(), a + b)
+    x = rnd("img", (2, 37, 9, 11))
+    d = dev(tf, x)                       # host-side NHWC packing
+    close(d.numpy(), x, atol=0, rtol=0)
+    # device-side converters
+    from tinyfusers_amd.native import hip
+    src = tf.DeviceArray.from_numpy(x, np.float32, "row")
+    dst = tf.DeviceArray.empty(x.shape, np.float16, "nhwc")
+    hip.tf_nchw_f32_to_nhwc_f16(dst.ptr, src.ptr, 2, 37, 9, 11, None)
+    close(dst.numpy(), x, atol=0, rtol=0)
+    back = tf.DeviceArray.empty(x.shape, np.float32, "row")
+    hip.tf_nhwc_f16_to_nchw_f32(back.ptr, dst.ptr, 2, 37, 9, 11, None)
+    close(back.numpy(), x, atol=0, rtol=0)
+    close(src.astype(np.float16).astype(np.float32).numpy(), x, atol=0, rtol=0)
+
+
+@pytest.mark.parametrize("rows,c", [(1, 8), (5, 64), (154, 768), (2 * 4096, 320), (2 * 256, 1280), (3, 2560)])
+def test_layer_norm(tf, rows, c):
+    from oracle import ops as O
+    from tinyfusers_amd.ff.layer_norm import LayerNorm
+    x = rnd("ln.x", (rows, c), 1.5) + 0.25
+    m = LayerNorm(c); m.weight = dev(tf, 1 + rnd("ln.w", (c,), 0.1)); m.bias = dev(tf, rnd("ln.b", (c,), 0.1))
+    close(m(dev(tf, x)).numpy(), O.layer_norm(x, m.weight.numpy(), m.bias.numpy()).numpy())
+
+
+@pytest.mark.parametrize("n,c,h,w,g", [(2, 64, 5, 3, 32), (2, 320, 64, 64, 32), (2, 1280, 8, 8, 32), (2, 2560, 16, 16, 32),
+                                       (2, 1920, 16, 16, 32), (2, 960, 32, 32, 32), (64, 768, 2, 2, 2), (3, 32, 1, 1, 32)])
+def test_group_norm(tf, n, c, h, w, g):
+    from oracle import ops as O
+    from tinyfusers_amd.ff.group_norm import GroupNorm, group_norm
+    x = rnd("gn.x", (n, c, h, w), 2.0) + 0.5
+    close(group_norm(dev(tf, x), g, 1e-5).numpy(), O.group_norm(x, g, 1e-5).numpy())
+    m = GroupNorm(g, c); m.weight = dev(tf, 1 + rnd("gn.w", (c,), 0.1)); m.bias = dev(tf, rnd("gn.b", (c,), 0.1))
+    want = O.group_norm_affine(x, g, m.weight.numpy(), m.bias.numpy())
+    close(m(dev(tf, x)).numpy(), want.numpy())
+    close(m(dev(tf, x), silu=True).numpy(), O.silu(want).numpy())
+
+
+@pytest.mark.parametrize("c1,c2", [(1280, 1280), (1280, 640), (640, 320), (64, 8)])
+def test_group_norm_concat(tf, c1, c2):
+    from oracle import ops as O
+    from tinyfusers_amd.ff.group_norm import GroupNorm
+    a, b = rnd("gnc.a", (2, c1, 8, 8), 2.0), rnd("gnc.b", (2, c2, 8, 8), 0.5) - 1
+    g = 32 if (c1 + c2) % 32 == 0 else 8
+    m = GroupNorm(g, c1 + c2); m.weight = dev(tf, 1 + rnd("gn.w", (c1 + c2,), 0.1)); m.bias = dev(tf, rnd("gn.b", (c1 + c2,), 0.1))
+    want = O.silu(O.group_norm_affine(np.concatenate((a, b), 1), g, m.weight.numpy(), m.bias.numpy()))
+    close(m((dev(tf, a), dev(tf, b)), silu=True).numpy(), want.numpy())
+
+
+LIN_SHAPES = [(1, 1280, 320), (2, 320, 1280), (8, 640, 1280), (154, 320, 768), (154, 1280, 768), (128, 1280, 1280),
+              (512, 1280, 1280), (2048, 640, 640), (8192, 320, 320), (8192, 320, 1280), (100, 48, 64), (77, 6, 8), (300, 200, 72)]
+
+
+@pytest.mark.parametrize("m,n,k", LIN_SHAPES)
+def test_linear(tf, m, n, k):
+    from oracle import ops as O
+    from tinyfusers_amd.ff.linear import Linear
+    x = rnd("lin.x", (m, k)); w = rnd("lin.w", (n, k), k ** -0.5); b = rnd("lin.b", (n,), 0.1); r = rnd("lin.r", (m, n))
+    lin = Linear(k, n, init=False); lin.weight = dev(tf, w); lin.bias = dev(tf, b)
+    close(lin(dev(tf, x)).numpy(), O.linear(x, w, b).numpy())
+    if m > 8:
+        close(lin(dev(tf, x), residual=dev(tf, r)).numpy(), (O.linear(x, w, b) + torch.from_numpy(r)).numpy())
+    lin.bias = None
+    close(lin(dev(tf, x)).numpy(), O.linear(x, w).numpy())
+
+
+@pytest.mark.parametrize("bm,bn,sk", [(128, 160, 1), (64, 160, 1), (128, 128, 1), (64, 128, 1), (128, 64, 1), (64, 64, 1),
+                                      (128, 160, 3), (64, 64, 4), (64, 160, 2)])
+def test_linear_every_tile_config(tf, bm, bn, sk):
+    """Each template instantiation + split-K, on exact small-integer data (any lane-map slip is an O(1) error)
+    with ragged M / N / K edges."""
+    from tinyfusers_amd.native import hip, lib
+    m, n, k = 333, 276, 200
+    rs = np.random.RandomState(5)
+    x = rs.randint(-3, 4, (m, k)).astype(np.float32); w = rs.randint(-2, 3, (n, k)).astype(np.float32)
+    b = rs.randint(-4, 5, (n,)).astype(np.float32)
+    want = x @ w.T + b
+    y = tf.DeviceArray.empty((m, n))
+    ws = tf.DeviceArray.empty((sk * m * n * 4 + 16,), np.uint8, "row")
+    lib.tf_gemm_force_config(bm, bn, sk)
+    try:
+        hip.tf_linear_f16(y.ptr, dev(tf, x).ptr, dev(tf, w).ptr, dev(tf, b).ptr, None, m, n, k, 0, ws.ptr, ws.nbytes, None)
+    finally:
+        lib.tf_gemm_force_config(0, 0, 0)
+    close(y.numpy(), want, atol=0.5, rtol=1e-3)   # |values| up to ~100: fp16 output rounding only
+
+
+@pytest.mark.parametrize("m,c", [(8192, 320), (77, 64), (128, 1280)])
+def test_geglu_fused(tf, m, c):
+    from oracle import ops as O
+    from tinyfusers_amd.ff.nn import GEGLU, FeedForward
+    x = rnd("gg.x", (m, c)); w = rnd("gg.w", (8 * c, c), c ** -0.5); b = rnd("gg.b", (8 * c,), 0.1)
+    g = GEGLU(c, 4 * c, init=False); g.proj.weight = dev(tf, w); g.proj.bias = dev(tf, b)
+    close(g(dev(tf, x)).numpy(), O.geglu(x, w, b).numpy())
+
+
+CONV_CASES = [  # n, cin, h, w, cout, k, stride, pad
+    (2, 8, 9, 7, 6, 3, 1, 1), (2, 8, 9, 7, 6, 3, 2, 1), (2, 8, 9, 7, 6, 1, 1, 0), (1, 16, 50, 40, 8, 2, 1, 0),
+    (2, 320, 64, 64, 320, 3, 1, 1), (2, 320, 64, 64, 320, 3, 2, 1), (2, 640, 32, 32, 640, 1, 1, 0),
+    (2, 1280, 8, 8, 1280, 3, 1, 1), (2, 320, 64, 64, 4, 3, 1, 1), (2, 4, 64, 64, 320, 3, 1, 1), (1, 4, 9, 7, 16, 3, 2, 1),
+    (2, 1280, 16, 16, 640, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("n,cin,h,w,cout,k,stride,pad", CONV_CASES)
+def test_conv2d(tf, n, cin, h, w, cout, k, stride, pad):
+    from oracle import ops as O
+    from tinyfusers_amd.vision.conv2d import Conv2d, conv_2d
+    x = rnd("conv.x", (n, cin, h, w)); wt = rnd("conv.w", (cout, cin, k, k), (cin * k * k) ** -0.5); b = rnd("conv.b", (cout,), 0.1)
+    close(conv_2d(dev(tf, x), dev(tf, wt), [pad, pad], [stride, stride], [1, 1]).numpy(), O.conv_2d(x, wt, (pad, pad), (stride, stride), (1, 1)).numpy())
+    m = Conv2d(cin, cout, [k, k], stride=[stride, stride], padding=[pad, pad], init=False); m.weight = dev(tf, wt); m.bias = dev(tf, b)
+    want = O.conv2d_bias(x, wt, b, (pad, pad), (stride, stride))
+    close(m(dev(tf, x)).numpy(), want.numpy())
+    if cin % 8 == 0:
+        r = rnd("conv.r", tuple(want.shape)); e = rnd("conv.e", (n, cout))
+        got = m(dev(tf, x), bias_nc=dev(tf, e), residual=dev(tf, r)).numpy()
+        close(got, (want + torch.from_numpy(e)[:, :, None, None] + torch.from_numpy(r)).numpy())
+        e1 = rnd("conv.e1", (1, cout))
+        close(m(dev(tf, x), bias_nc=dev(tf, e1)).numpy(), (want + torch.from_numpy(e1)[:, :, None, None]).numpy())
+
+
+@pytest.mark.parametrize("c1,c2,cout,hw,k", [(1280, 1280, 1280, 8, 3), (1280, 640, 1280, 16, 1), (640, 320, 320, 32, 3), (64, 8, 24, 5, 3)])
+def test_conv2d_concat_and_upsample(tf, c1, c2, cout, hw, k):
+    from oracle import ops as O
+    from tinyfusers_amd.vision.conv2d import Conv2d
+    from tinyfusers_amd.vision.unet import Upsample
+    a, b = rnd("cc.a", (2, c1, hw, hw)), rnd("cc.b", (2, c2, hw, hw))
+    wt = rnd("cc.w", (cout, c1 + c2, k, k), ((c1 + c2) * k * k) ** -0.5); bs = rnd("cc.bias", (cout,), 0.1)
+    m = Conv2d(c1 + c2, cout, [k, k], padding=[k // 2, k // 2], init=False); m.weight = dev(tf, wt); m.bias = dev(tf, bs)
+    close(m((dev(tf, a), dev(tf, b))).numpy(), O.conv2d_bias(np.concatenate((a, b), 1), wt, bs, (k // 2, k // 2)).numpy())
+    up = Upsample(c1, init=False); wu = rnd("up.w", (c1, c1, 3, 3), (c1 * 9) ** -0.5)
+    up.conv.weight = dev(tf, wu); up.conv.bias = dev(tf, rnd("up.b", (c1,), 0.1))
+    close(up(dev(tf, a)).numpy(), O.conv2d_bias(O.upsample_nearest2x(a), wu, up.conv.bias.numpy(), (1, 1)).numpy())
+
+
+SDPA_CASES = [  # b, nh, tq, tk, hs
+    (2, 2, 16, 16, 8), (2, 2, 16, 5, 8), (1, 3, 100, 77, 40), (2, 8, 256, 256, 160), (2, 8, 64, 77, 160), (2, 8, 1024, 1024, 80),
+    (2, 8, 4096, 77, 40), (1, 2, 4096, 4096, 40), (2, 2, 130, 130, 32), (1, 12, 77, 77, 64), (1, 1, 200, 333, 128), (1, 2, 70, 70, 96),
+]
+
+
+@pytest.mark.parametrize("b,nh,tq,tk,hs", SDPA_CASES)
+def test_sdpa(tf, b, nh, tq, tk, hs):
+    from oracle import ops as O
+    from tinyfusers_amd.attention.sdpa import scaled_dot_product_attention
+    q, k, v = rnd("sd.q", (b, nh, tq, hs)), rnd("sd.k", (b, nh, tk, hs)), rnd("sd.v", (b, nh, tk, hs))
+    got = scaled_dot_product_attention(dev(tf, q, "row"), dev(tf, k, "row"), dev(tf, v, "row")).numpy()
+    close(got, O.scaled_dot_product_attention(q, k, v).numpy())
+    if tq == tk and tq <= 256:
+        mask = np.tril(np.ones((tq, tk), dtype=bool))
+        got = scaled_dot_product_attention(dev(tf, q, "row"), dev(tf, k, "row"), dev(tf, v, "row"), attn_mask=mask).numpy()
+        close(got, O.scaled_dot_product_attention(q, k, v, mask).numpy())
+
+
+def test_sdpa_online_softmax_rescale(tf):
+    """Force the running-max rescale branch: one huge score late in the key sequence (guide rule 26)."""
+    from oracle import ops as O
+    from tinyfusers_amd.attention.sdpa import scaled_dot_product_attention
+    b, nh, t, hs = 1, 1, 256, 64
+    q, k, v = rnd("rs.q", (b, nh, t, hs), 0.5), rnd("rs.k", (b, nh, t, hs), 0.5), rnd("rs.v", (b, nh, t, hs))
+    k[0, 0, 200] = q[0, 0, 17] * 6.0           # query 17 . key 200 spikes in the 4th tile
+    k[0, 0, 70] = q[0, 0, 33] * 4.0
+    got = scaled_dot_product_attention(dev(tf, q, "row"), dev(tf, k, "row"), dev(tf, v, "row")).numpy()
+    close(got, O.scaled_dot_product_attention(q, k, v).numpy())
+
+
+def test_softmax_rows_and_own_runtime_kernels(tf):
+    from oracle import ops as O
+    from tinyfusers_amd.storage.device import Device
+    d = Device("hip")
+    x = rnd("sm", (13, 87), 2.0)
+    t_in = tf.Tensor.from_np(x).eval(); t_out = tf.Tensor.zeros(x.shape, np.float32).eval()
+    d.softmax(t_out, t_in)
+    close(t_out.to("cpu").data, O.softmax_rows(x).numpy(), atol=1e-5)
+    t2 = tf.Tensor.from_np(x.copy()).eval()
+    d.scale_tensor(t2.dt_ptr, 2.5, 1, 13, 1, 87)
+    close(t2.to("cpu").data, 2.5 * x, atol=1e-6)
+    for shape, axes in (((13, 87), (1, 0)), ((30, 7, 30), (1, 2, 0)), ((7, 13, 13, 5), (1, 2, 0, 3))):
+        a = rnd("tr", shape)
+        src = tf.Tensor.from_np(a).eval(); dst = tf.Tensor.zeros(shape, np.float32).eval()
+        (d.transpose4d if len(shape) == 4 else d.transpose)(dst, src, axes)
+        out = dst.to("cpu").data.reshape([shape[i] for i in axes])
+        close(out, np.transpose(a, axes), atol=0, rtol=0)

@@ -1,0 +1,118 @@
+"""Pin the CPU oracle: every restated function must reproduce the reference's own outputs
+(tests/golden/*.npz, produced by tests/golden/make_golden.py from the reference's Python)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import ops as O
+from oracle.unet import (SD15, basic_transformer_block, cross_attention, feed_forward, resblock,
+                         spatial_transformer, unet_param_shapes)
+from tinyfusers_amd.storage.synth import synth_normal, synth_state_dict
+
+TOL = dict(rtol=1e-5, atol=2e-5)
+
+
+def close(a, b, **kw):
+    t = dict(TOL); t.update(kw)
+    np.testing.assert_allclose(np.asarray(a, dtype=np.float32), np.asarray(b, dtype=np.float32), **t)
+
+
+def test_conv(golden):
+    g = golden["ops"]
+    close(O.conv_2d(g["conv_x"], g["conv_w3"], (1, 1), (1, 1), (1, 1)), g["conv_y_3x3_s1"])
+    close(O.conv_2d(g["conv_x"], g["conv_w3"], (1, 1), (2, 2), (1, 1)), g["conv_y_3x3_s2"])
+    close(O.conv_2d(g["conv_x"], g["conv_w1"], (0, 0), (1, 1), (1, 1)), g["conv_y_1x1"])
+    close(O.conv2d_bias(g["conv_x"], g["conv_w3"], g["conv_b"], (1, 1)), g["conv_y_module"])
+    close(O.conv_2d(g["convt_x"], g["convt_w"], (0, 0), (1, 1), (1, 1)), g["convt_y"])
+
+
+def test_norms(golden):
+    g = golden["ops"]
+    close(O.group_norm(g["gn_x"], 32, 1e-5), g["gn_y_plain"])
+    close(O.group_norm_affine(g["gn_x"], 32, g["gn_w"], g["gn_b"]), g["gn_y_affine"])
+    close(O.group_norm(g["gn2_x"], 2, 1e-5), g["gn2_y"])
+    close(O.layer_norm(g["ln_x"], g["ln_w"], g["ln_b"]), g["ln_y"])
+    # the reference's GroupNorm == torch's (tests/group_norm.py:38-40)
+    ref = torch.nn.functional.group_norm(torch.from_numpy(g["gn_x"]), 32, torch.from_numpy(g["gn_w"]), torch.from_numpy(g["gn_b"]), 1e-5)
+    close(ref, g["gn_y_affine"])
+
+
+def test_linear_geglu(golden):
+    g = golden["ops"]
+    close(O.linear(g["lin_x"], g["lin_w"], g["lin_b"]), g["lin_y"])
+    close(O.linear(g["lin_x"], g["lin_w"]), g["lin_y_nobias"])
+    close(O.geglu(g["lin_x"], g["geglu_w"], g["geglu_b"]), g["geglu_y"])
+
+
+def test_sdpa(golden):
+    g = golden["ops"]
+    close(O.scaled_dot_product_attention(g["sdpa_q"], g["sdpa_k"], g["sdpa_v"]), g["sdpa_y_self"])
+    close(O.scaled_dot_product_attention(g["sdpa_q"], g["sdpa_kc"], g["sdpa_vc"]), g["sdpa_y_cross"])
+    mask = np.tril(np.ones((16, 16), dtype=bool))
+    close(O.scaled_dot_product_attention(g["sdpa_q"], g["sdpa_k"], g["sdpa_v"], mask), g["sdpa_y_causal"])
+
+
+def test_activations_embedding_schedule(golden):
+    g = golden["ops"]
+    for n in ("sigmoid", "silu", "gelu", "quick_gelu"):
+        close(getattr(O, n)(g["act_x"]), g["act_" + n])
+    close(O.silu(g["act_x"]), g["act_swish"])
+    close(O.timestep_embedding(np.array([981]), 320), g["temb_981"], atol=1e-4)
+    close(O.timestep_embedding(np.array([1]), 320), g["temb_1"], atol=1e-4)
+    close(O.get_alphas_cumprod(), g["alphas_cumprod"], rtol=1e-6, atol=0)
+    xp, p0 = O.get_x_prev_and_pred_x0(g["ddim_x"], g["ddim_e"], g["ddim_a_t"], g["ddim_a_prev"])
+    close(xp, g["ddim_x_prev"]); close(p0, g["ddim_pred_x0"])
+
+
+def test_up_down(golden):
+    g = golden["ops"]
+    close(O.conv2d_bias(O.upsample_nearest2x(g["ud_x"]), g["up_w"], g["up_b"], (1, 1)), g["up_y"])
+    close(O.conv2d_bias(g["ud_x"], g["dn_w"], g["dn_b"], (1, 1), (2, 2)), g["dn_y"])
+
+
+def _block_weights():
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from block_shapes import BLOCK_SHAPES
+    return {k: v.astype(np.float32) for k, v in synth_state_dict(BLOCK_SHAPES, 3).items()}
+
+
+def test_blocks(golden):
+    g = golden["blocks"]
+    W = _block_weights()
+    cfg = oracle.UNetConfig(num_groups=32)
+    close(resblock(g["res_x"], torch.from_numpy(g["res_emb"]), {k: O.as_t(v) for k, v in W.items()}, "res", cfg), g["res_y"], atol=5e-5)
+    Wt = {k: O.as_t(v) for k, v in W.items()}
+    ctx = O.as_t(g["st_ctx"])
+    t = "st.transformer_blocks.0"
+    close(cross_attention(O.as_t(g["blk_x"]), None, Wt, t + ".attn1", 2), g["attn1_y"], atol=5e-5)
+    close(cross_attention(O.as_t(g["blk_x"]), ctx, Wt, t + ".attn2", 2), g["attn2_y"], atol=5e-5)
+    close(feed_forward(O.as_t(g["blk_x"]), Wt, t + ".ff"), g["ff_y"], atol=5e-5)
+    close(basic_transformer_block(O.as_t(g["blk_x"]), ctx, Wt, t, 2), g["blk_y"], atol=1e-4)
+    close(spatial_transformer(O.as_t(g["st_x"]), ctx, Wt, "st", 2, cfg), g["st_y"], atol=1e-4)
+    # D11: the reference's head merge differs from the LDM-intended one
+    y_int = cross_attention(O.as_t(g["blk_x"]), None, Wt, t + ".attn1", 2, head_merge="intended")
+    assert float((y_int - torch.from_numpy(g["attn1_y"])).abs().max()) > 1e-2
+
+
+def test_param_census():
+    P = unet_param_shapes(SD15)
+    assert len(P) == 686
+    assert sum(int(np.prod(s)) for s in P.values()) == 859520964
+
+
+@pytest.mark.slow
+def test_unet_full_sd15(golden):
+    """Whole UNet + CFG + DDIM against the reference's trajectory (2 steps, ~1 min on 8 cores)."""
+    if "unet_sd15" not in golden:
+        pytest.skip("unet_sd15.npz not generated")
+    g = golden["unet_sd15"]
+    W = {k: v.astype(np.float32) for k, v in synth_state_dict(unet_param_shapes(SD15), 0).items()}
+    latent = synth_normal(1234, "sd.latent", (1, 4, 64, 64))
+    ctx = synth_normal(1234, "sd.context", (1, 77, 768)); unc = synth_normal(1234, "sd.uncond", (1, 77, 768))
+    ts, al, ap = g["timesteps"], g["alphas"], g["alphas_prev"]
+    Wt = {k: O.as_t(v) for k, v in W.items()}
+    x = oracle.sd_step(unc, ctx, latent, np.array([ts[49]]), al[49:50], ap[49:50], np.array([7.5]), Wt)
+    err = float((x - torch.from_numpy(g["x_after_step0"])).abs().max())
+    assert err < 2e-4, err

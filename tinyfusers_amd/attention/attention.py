@@ -1,0 +1,117 @@
+"""CrossAttention / BasicTransformerBlock / SpatialTransformer -- mirrors tinyfusers/attention/attention.py:26-76.
+
+MI355X-first differences (results identical to the reference within fp16 tolerance):
+  * to_q/to_k/to_v of self-attention run as ONE GEMM over a device-side concatenated (3C, C) weight, to_k/to_v
+    of cross-attention as one (2C, ctx) GEMM; the SDPA kernel reads heads through strides, so the
+    reshape+transpose(0,2,1,3) of attention.py:38 never materialises;
+  * the head merge after SDPA is an output-stride choice (config.head_merge);
+  * every residual add is fused into the producing GEMM's epilogue.
+"""
+import numpy as np
+
+from .. import config
+from ..ff.group_norm import GroupNorm
+from ..ff.layer_norm import LayerNorm
+from ..ff.linear import Linear, linear_f16
+from ..ff.nn import FeedForward
+from ..native import hip
+from ..storage.tensor import DeviceArray, _sh
+from ..vision.conv2d import Conv2d
+from .sdpa import sdpa_strided
+
+
+def _concat_rows(ws):
+    k = ws[0].shape[1]
+    n = sum(w.shape[0] for w in ws)
+    out = DeviceArray.empty((n, k), np.float16, "row")
+    off = 0
+    for w in ws:
+        hip.tf_memcpy_async(out.ptr + off, w.ptr, w.nbytes, 3, _sh())
+        off += w.nbytes
+    return out
+
+
+class CrossAttention:
+    def __init__(self, query_dim, context_dim, n_heads, d_head, init=True):
+        self.to_q = Linear(query_dim, n_heads * d_head, bias=False, init=init)
+        self.to_k = Linear(context_dim, n_heads * d_head, bias=False, init=init)
+        self.to_v = Linear(context_dim, n_heads * d_head, bias=False, init=init)
+        self.num_heads = n_heads
+        self.head_size = d_head
+        self.to_out = [Linear(n_heads * d_head, query_dim, init=init)]
+        self._fused = None
+
+    def _fused_weights(self, self_attn):
+        key = (self.to_q.weight.ptr, self.to_k.weight.ptr, self.to_v.weight.ptr, self_attn)
+        if self._fused is None or self._fused[0] != key:
+            ws = [self.to_q.weight, self.to_k.weight, self.to_v.weight] if self_attn else [self.to_k.weight, self.to_v.weight]
+            self._fused = (key, _concat_rows(ws))
+        return self._fused[1]
+
+    def project_kv(self, context):
+        """(b, tk, 2C) fused K|V projection of the context (computed once per UNet call by the model)."""
+        return linear_f16(context, self._fused_weights(False))
+
+    def __call__(self, x, context=None, residual=None, kv=None):
+        b, t, _ = x.shape
+        nh, hs = self.num_heads, self.head_size
+        c = nh * hs
+        if context is None and kv is None:
+            qkv = linear_f16(x, self._fused_weights(True))            # (b, t, 3C): q | k | v
+            q, k, v = qkv, qkv.view((b, t, 3 * c), "row", c), qkv.view((b, t, 3 * c), "row", 2 * c)
+            tk, qs, ks = t, (t * 3 * c, hs, 3 * c), (t * 3 * c, hs, 3 * c)
+        else:
+            q = linear_f16(x, self.to_q.weight)
+            if kv is None:
+                kv = self.project_kv(context)
+            if hasattr(kv, "ld"):                          # column slice of the UNet's step-level K|V GEMM
+                tk, ld = kv.arr.shape[1], kv.ld
+                k = kv.arr.view(kv.arr.shape, "row", kv.off)
+                v = kv.arr.view(kv.arr.shape, "row", kv.off + c)
+            else:
+                tk, ld = kv.shape[1], 2 * c
+                k, v = kv, kv.view(kv.shape, "row", c)
+            qs, ks = (t * c, hs, c), (tk * ld, hs, ld)
+        o = DeviceArray.empty((b, t, c), np.float16, "row")
+        if config.head_merge == "reference_exact":
+            os_ = (nh * t * hs, t * hs, hs)      # (b,h,t,d) contiguous, then read as (b, t, h*d): attention.py:38-39
+        else:
+            os_ = (t * c, hs, c)                 # LDM-intended merge
+        sdpa_strided(o, q, k, v, b, nh, t, tk, hs, qs, ks, ks, os_)
+        return self.to_out[0](o, residual=residual)
+
+
+class BasicTransformerBlock:
+    def __init__(self, dim, context_dim, n_heads, d_head, init=True):
+        self.attn1 = CrossAttention(dim, dim, n_heads, d_head, init=init)
+        self.ff = FeedForward(dim, init=init)
+        self.attn2 = CrossAttention(dim, context_dim, n_heads, d_head, init=init)
+        self.norm1 = LayerNorm(dim, init=init)
+        self.norm2 = LayerNorm(dim, init=init)
+        self.norm3 = LayerNorm(dim, init=init)
+
+    def __call__(self, x, context=None, kv=None):
+        x = self.attn1(self.norm1(x), residual=x)
+        x = self.attn2(self.norm2(x), context=context, residual=x, kv=kv)
+        x = self.ff(self.norm3(x), residual=x)
+        return x
+
+
+class SpatialTransformer:
+    def __init__(self, channels, context_dim, n_heads, d_head, init=True):
+        self.norm = GroupNorm(32, channels, init=init)
+        assert channels == n_heads * d_head
+        self.proj_in = Conv2d(channels, n_heads * d_head, kernel_size=[1, 1], init=init)
+        self.transformer_blocks = [BasicTransformerBlock(channels, context_dim, n_heads, d_head, init=init)]
+        self.proj_out = Conv2d(n_heads * d_head, channels, kernel_size=[1, 1], init=init)
+
+    def __call__(self, x, context=None, kv=None):
+        b, c, h, w = x.shape
+        x_in = x
+        x = self.norm(x)
+        x = self.proj_in(x)
+        x = x.tokens()                                   # (b, hw, c): free re-view of NHWC (attention.py:71)
+        for block in self.transformer_blocks:
+            x = block(x, context=context, kv=kv)
+        x = x.image(b, c, h, w)                          # attention.py:74
+        return self.proj_out(x, residual=x_in)           # + x_in fused (attention.py:75)

@@ -1,0 +1,62 @@
+// Shared helpers for the gfx950 kernels behind libtinyfusers_hip.so (C-ABI in include/tinyfusers_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef _Float16 half_t;
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32;
+
+// ---- error plumbing: every exported function returns int (0 = ok, else hipError_t or TF_E_*),
+// mirroring the reference's "C status -> RuntimeError" convention (storage/device.py:33-37).
+enum { TF_OK = 0, TF_E_ARG = 10001, TF_E_UNSUPPORTED = 10002, TF_E_WORKSPACE = 10003, TF_E_STATE = 10004 };
+void tf_set_error(const char* fmt, ...);
+#define TF_HIP(expr)                                                                  \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      tf_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return (int)_e;                                                                 \
+    }                                                                                 \
+  } while (0)
+#define TF_REQUIRE(cond, ...)                  \
+  do {                                         \
+    if (!(cond)) {                             \
+      tf_set_error(__VA_ARGS__);               \
+      return TF_E_ARG;                         \
+    }                                          \
+  } while (0)
+#define TF_LAUNCH_CHECK() TF_HIP(hipGetLastError())
+
+struct tfStream_st { hipStream_t s; };
+struct tfEvent_st { hipEvent_t e; };
+struct tfGraph_st { hipGraph_t g; hipGraphExec_t x; };
+static inline hipStream_t tf_hs(struct tfStream_st* s) { return s ? s->s : (hipStream_t)0; }
+
+// device-side helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// tanh-GELU of storage/tensor.py:80-82: 0.5 x (1 + tanh(0.7978845608 x (1 + 0.044715 x^2)))
+__device__ __forceinline__ float gelu_f(float x) {
+  float u = 0.7978845608f * x * (1.0f + 0.044715f * x * x);
+  // tanh(u) = 1 - 2/(exp(2u)+1)
+  float t = 1.0f - 2.0f / (__expf(2.0f * u) + 1.0f);
+  return 0.5f * x * (1.0f + t);
+}
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }

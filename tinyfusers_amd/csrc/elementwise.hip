@@ -1,0 +1,420 @@
+// HBM-bound elementwise / layout / sampler kernels (fp16 storage, fp32 math), 16 B per lane.
+// Reference semantics: storage/tensor.py:64-86, ff/nn.py:10-12, vision/unet.py:72,81-83,92-97,
+// variants/sd.py:14-46, native/cuda/{scale_tensor_func,add_bias_func,transpose,transpose4d,softmax_func}.cu.
+#include "common.h"
+#include "../../include/tinyfusers_hip.h"
+
+#define EW_BLOCK 256
+static inline int ew_grid(long long nvec) {
+  long long g = ceil_div_ll(nvec, EW_BLOCK);
+  if (g > 256 * 8) g = 256 * 8;  // 8 blocks/CU, grid-stride the rest
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+enum { OP_SILU = 0, OP_SIGMOID = 1, OP_GELU = 2, OP_QGELU = 3 };
+
+template <int OP>
+__device__ __forceinline__ float act(float x) {
+  if (OP == OP_SILU) return silu_f(x);
+  if (OP == OP_SIGMOID) return 1.0f / (1.0f + __expf(-x));
+  if (OP == OP_GELU) return gelu_f(x);
+  return x / (1.0f + __expf(-1.702f * x));
+}
+
+template <int OP>
+__global__ void __launch_bounds__(EW_BLOCK) k_unary(half_t* __restrict__ y, const half_t* __restrict__ x, long long n) {
+  long long nvec = n >> 3;
+  long long stride = (long long)gridDim.x * EW_BLOCK;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < nvec; i += stride) {
+    h8 v = *reinterpret_cast<const h8*>(x + i * 8), o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)act<OP>((float)v[j]);
+    *reinterpret_cast<h8*>(y + i * 8) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    long long i = (nvec << 3) + threadIdx.x;
+    y[i] = (half_t)act<OP>((float)x[i]);
+  }
+}
+
+__global__ void __launch_bounds__(EW_BLOCK) k_add(half_t* __restrict__ y, const half_t* __restrict__ a, const half_t* __restrict__ b, long long n) {
+  long long nvec = n >> 3;
+  long long stride = (long long)gridDim.x * EW_BLOCK;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < nvec; i += stride) {
+    h8 u = *reinterpret_cast<const h8*>(a + i * 8), v = *reinterpret_cast<const h8*>(b + i * 8), o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)u[j] + (float)v[j]);
+    *reinterpret_cast<h8*>(y + i * 8) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    long long i = (nvec << 3) + threadIdx.x;
+    y[i] = (half_t)((float)a[i] + (float)b[i]);
+  }
+}
+
+// x (rows, 2C) -> y (rows, C): a * gelu(gate)   (ff/nn.py:10-12)
+__global__ void __launch_bounds__(EW_BLOCK) k_geglu(half_t* __restrict__ y, const half_t* __restrict__ x, long long rows, int C) {
+  int cv = C >> 3;
+  long long nvec = rows * cv;
+  long long stride = (long long)gridDim.x * EW_BLOCK;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < nvec; i += stride) {
+    long long r = i / cv;
+    int c = (int)(i - r * cv) * 8;
+    h8 a = *reinterpret_cast<const h8*>(x + r * 2 * C + c), g = *reinterpret_cast<const h8*>(x + r * 2 * C + C + c), o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)a[j] * gelu_f((float)g[j]));
+    *reinterpret_cast<h8*>(y + r * C + c) = o;
+  }
+}
+
+// y[n,hw,c] = x[n,hw,c] + b[n,c]   (vision/resnet.py:28)
+__global__ void __launch_bounds__(EW_BLOCK) k_add_bias_nc(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ b, int N, long long HW, int C) {
+  int cv = C >> 3;
+  long long nvec = (long long)N * HW * cv;
+  long long stride = (long long)gridDim.x * EW_BLOCK;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < nvec; i += stride) {
+    long long p = i / cv;
+    int c = (int)(i - p * cv) * 8;
+    int n = (int)(p / HW);
+    h8 u = *reinterpret_cast<const h8*>(x + p * C + c), v = *reinterpret_cast<const h8*>(b + (long long)n * C + c), o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)u[j] + (float)v[j]);
+    *reinterpret_cast<h8*>(y + p * C + c) = o;
+  }
+}
+
+// nearest 2x (vision/unet.py:81-83), NHWC
+__global__ void __launch_bounds__(EW_BLOCK) k_upsample2x(half_t* __restrict__ y, const half_t* __restrict__ x, int N, int H, int W, int C) {
+  int cv = C >> 3;
+  long long nvec = (long long)N * (2 * H) * (2 * W) * cv;
+  long long stride = (long long)gridDim.x * EW_BLOCK;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < nvec; i += stride) {
+    long long p = i / cv;
+    int c = (int)(i - p * cv) * 8;
+    int wo = (int)(p % (2 * W));
+    long long q = p / (2 * W);
+    int ho = (int)(q % (2 * H));
+    int n = (int)(q / (2 * H));
+    const half_t* src = x + (((long long)n * H + (ho >> 1)) * W + (wo >> 1)) * C + c;
+    *reinterpret_cast<h8*>(y + p * C + c) = *reinterpret_cast<const h8*>(src);
+  }
+}
+
+// channel concat (vision/unet.py:72): y (rows, Ca+Cb) = [a (rows,Ca) | b (rows,Cb)]
+__global__ void __launch_bounds__(EW_BLOCK) k_concat(half_t* __restrict__ y, const half_t* __restrict__ a, const half_t* __restrict__ b, long long rows, int Ca, int Cb) {
+  int C = Ca + Cb, cv = C >> 3;
+  long long nvec = rows * cv;
+  long long stride = (long long)gridDim.x * EW_BLOCK;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < nvec; i += stride) {
+    long long r = i / cv;
+    int c = (int)(i - r * cv) * 8;
+    const half_t* src = c < Ca ? a + r * Ca + c : b + r * Cb + (c - Ca);
+    *reinterpret_cast<h8*>(y + r * C + c) = *reinterpret_cast<const h8*>(src);
+  }
+}
+
+// im2col for tiny channel counts (conv_in, C = 4): y (N*Ho*Wo, Kpad), k = (r*S + s)*C + c, zero padded
+__global__ void __launch_bounds__(EW_BLOCK) k_im2col(half_t* __restrict__ y, const half_t* __restrict__ x, int N, int H, int W, int C, int R, int S,
+                                                     int stride, int pad, int Ho, int Wo, int Kpad) {
+  long long total = (long long)N * Ho * Wo * Kpad;
+  long long gs = (long long)gridDim.x * EW_BLOCK;
+  int K = R * S * C;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += gs) {
+    int k = (int)(i % Kpad);
+    long long m = i / Kpad;
+    half_t v = (half_t)0.0f;
+    if (k < K) {
+      int c = k % C, t = k / C, s = t % S, r = t / S;
+      int wo = (int)(m % Wo);
+      long long q = m / Wo;
+      int ho = (int)(q % Ho), n = (int)(q / Ho);
+      int hi = ho * stride - pad + r, wi = wo * stride - pad + s;
+      if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = x[(((long long)n * H + hi) * W + wi) * C + c];
+    }
+    y[i] = v;
+  }
+}
+
+__global__ void __launch_bounds__(EW_BLOCK) k_cast_f32_f16(half_t* __restrict__ y, const float* __restrict__ x, long long n) {
+  long long gs = (long long)gridDim.x * EW_BLOCK;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += gs) y[i] = (half_t)x[i];
+}
+__global__ void __launch_bounds__(EW_BLOCK) k_cast_f16_f32(float* __restrict__ y, const half_t* __restrict__ x, long long n) {
+  long long gs = (long long)gridDim.x * EW_BLOCK;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += gs) y[i] = (float)x[i];
+}
+
+// (N,C,HW) f32 -> (N,HW,C) f16 through a 32x32 LDS tile (both sides coalesced)
+__global__ void __launch_bounds__(256) k_nchw_to_nhwc(half_t* __restrict__ dst, const float* __restrict__ src, int C, int HW) {
+  __shared__ float tile[32][33];
+  int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    int c = c0 + j, p = p0 + tx;
+    tile[j][tx] = (c < C && p < HW) ? src[((long long)n * C + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int p = p0 + j, c = c0 + tx;
+    if (c < C && p < HW) dst[((long long)n * HW + p) * C + c] = (half_t)tile[tx][j];
+  }
+}
+__global__ void __launch_bounds__(256) k_nhwc_to_nchw(float* __restrict__ dst, const half_t* __restrict__ src, int C, int HW) {
+  __shared__ float tile[32][33];
+  int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    int p = p0 + j, c = c0 + tx;
+    tile[j][tx] = (c < C && p < HW) ? (float)src[((long long)n * HW + p) * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int c = c0 + j, p = p0 + tx;
+    if (c < C && p < HW) dst[((long long)n * C + c) * HW + p] = tile[tx][j];
+  }
+}
+
+// ---- reference own-runtime kernels (fp32) ------------------------------------------------------
+__global__ void __launch_bounds__(EW_BLOCK) k_scale_f32(float* x, float s, long long n) {
+  long long gs = (long long)gridDim.x * EW_BLOCK;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += gs) x[i] *= s;
+}
+// out is a column-major (BT x OC) cuBLAS result: out[(idx%OC)*BT + idx/OC] += bias[idx%OC]  (add_bias_func.cu:1-9)
+__global__ void __launch_bounds__(EW_BLOCK) k_add_bias_cm(float* out, const float* bias, int BT, int OC) {
+  long long n = (long long)BT * OC, gs = (long long)gridDim.x * EW_BLOCK;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += gs) {
+    int oc = (int)(i % OC);
+    long long bt = i / OC;
+    out[(long long)oc * BT + bt] += bias[oc];
+  }
+}
+struct PermArgs { int ndim; int oshape[4]; long long istride_of_o[4]; };
+__global__ void __launch_bounds__(EW_BLOCK) k_permute_f32(float* __restrict__ out, const float* __restrict__ inp, PermArgs a, long long n) {
+  long long gs = (long long)gridDim.x * EW_BLOCK;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += gs) {
+    long long rem = i, off = 0;
+#pragma unroll
+    for (int d = 3; d >= 0; --d) {
+      if (d < a.ndim) { int idx = (int)(rem % a.oshape[d]); rem /= a.oshape[d]; off += idx * a.istride_of_o[d]; }
+    }
+    out[i] = inp[off];
+  }
+}
+
+// numerically stable row softmax (N, C) fp32: one 256-thread block per row, row cached in registers when
+// C <= 256*16, single pass over HBM (the reference's softmax.cu:24-112 makes three passes).
+__global__ void __launch_bounds__(256) k_softmax_rows(float* __restrict__ out, const float* __restrict__ inp, int C) {
+  __shared__ float red[8];
+  const float* x = inp + (long long)blockIdx.x * C;
+  float* y = out + (long long)blockIdx.x * C;
+  int t = threadIdx.x, w = t >> 6, l = t & 63;
+  float m = -INFINITY;
+  for (int i = t; i < C; i += 256) m = fmaxf(m, x[i]);
+  m = wave_max(m);
+  if (l == 0) red[w] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+  for (int i = t; i < C; i += 256) s += __expf(x[i] - m);
+  s = wave_sum(s);
+  if (l == 0) red[4 + w] = s;
+  __syncthreads();
+  s = red[4] + red[5] + red[6] + red[7];
+  float inv = 1.0f / s;
+  for (int i = t; i < C; i += 256) y[i] = __expf(x[i] - m) * inv;
+}
+
+// ---- sampler pieces ----------------------------------------------------------------------------
+// out (1, dim) f16 = [cos(t f_i), sin(t f_i)], f_i = exp(-ln(max_period) i / half)   (vision/unet.py:92-97)
+__global__ void k_timestep_embedding(half_t* out, const float* params, int dim, float max_period) {
+  int half_dim = dim / 2;
+  float t = params[0];
+  for (int i = threadIdx.x; i < half_dim; i += blockDim.x) {
+    float f = expf(-logf(max_period) * (float)i / (float)half_dim);
+    float a = t * f;
+    out[i] = (half_t)cosf(a);
+    out[half_dim + i] = (half_t)sinf(a);
+  }
+}
+// latent (B,C,H,W) f32 -> x (2B,H,W,C) f16, both CFG halves the same latent (variants/sd.py:31)
+__global__ void __launch_bounds__(EW_BLOCK) k_cfg_duplicate(half_t* __restrict__ x, const float* __restrict__ lat, int B, int C, int HW) {
+  long long n = (long long)B * C * HW, gs = (long long)gridDim.x * EW_BLOCK;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += gs) {
+    int c = (int)(i % C);
+    long long p = i / C;
+    int hw = (int)(p % HW), b = (int)(p / HW);
+    half_t v = (half_t)lat[((long long)b * C + c) * HW + hw];
+    x[i] = v;
+    x[n + i] = v;
+  }
+}
+// e = e_u + g (e_c - e_u); pred_x0 = (x - sqrt(1-a_t) e)/sqrt(a_t); x' = sqrt(a_prev) pred_x0 + sqrt(1-a_prev) e
+__global__ void __launch_bounds__(EW_BLOCK) k_cfg_ddim(float* __restrict__ lat, const half_t* __restrict__ eps2, const float* __restrict__ params, int B, int C, int HW) {
+  float a_t = params[1], a_prev = params[2], g = params[3];
+  float s1 = sqrtf(1.0f - a_t), r = sqrtf(a_t), sp = sqrtf(a_prev), dp = sqrtf(1.0f - a_prev);
+  long long n = (long long)B * C * HW, gs = (long long)gridDim.x * EW_BLOCK;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += gs) {
+    int hw = (int)(i % HW);
+    long long q = i / HW;
+    int c = (int)(q % C), b = (int)(q / C);
+    long long j = ((long long)b * HW + hw) * C + c;
+    float eu = (float)eps2[j], ec = (float)eps2[n + j];
+    float e = eu + g * (ec - eu);
+    float x = lat[i];
+    float px0 = (x - s1 * e) / r;
+    lat[i] = sp * px0 + dp * e;
+  }
+}
+
+extern "C" {
+
+#define EW_UNARY(NAME, OP)                                                                 \
+  int NAME(void* y, const void* x, long long n, tfStream_t s) {                            \
+    TF_REQUIRE(y && x && n >= 0, #NAME ": bad arguments");                                 \
+    if (n == 0) return TF_OK;                                                              \
+    hipLaunchKernelGGL(k_unary<OP>, dim3(ew_grid(n >> 3)), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)y, (const half_t*)x, n); \
+    TF_LAUNCH_CHECK();                                                                     \
+    return TF_OK;                                                                          \
+  }
+EW_UNARY(tf_silu_f16, OP_SILU)
+EW_UNARY(tf_sigmoid_f16, OP_SIGMOID)
+EW_UNARY(tf_gelu_f16, OP_GELU)
+EW_UNARY(tf_quick_gelu_f16, OP_QGELU)
+
+int tf_add_f16(void* y, const void* a, const void* b, long long n, tfStream_t s) {
+  TF_REQUIRE(y && a && b && n >= 0, "tf_add_f16: bad arguments");
+  if (n == 0) return TF_OK;
+  hipLaunchKernelGGL(k_add, dim3(ew_grid(n >> 3)), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)y, (const half_t*)a, (const half_t*)b, n);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_geglu_f16(void* y, const void* x, int rows, int C, tfStream_t s) {
+  TF_REQUIRE(y && x && rows >= 0 && C > 0 && C % 8 == 0, "tf_geglu_f16: C=%d must be a positive multiple of 8", C);
+  if (rows == 0) return TF_OK;
+  hipLaunchKernelGGL(k_geglu, dim3(ew_grid((long long)rows * (C >> 3))), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)y, (const half_t*)x, (long long)rows, C);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_add_bias_nc_f16(void* y, const void* x, const void* b, int N, int HW, int C, tfStream_t s) {
+  TF_REQUIRE(y && x && b && C % 8 == 0, "tf_add_bias_nc_f16: C=%d must be a multiple of 8", C);
+  if ((long long)N * HW == 0) return TF_OK;
+  hipLaunchKernelGGL(k_add_bias_nc, dim3(ew_grid((long long)N * HW * (C >> 3))), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)b, N, (long long)HW, C);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_upsample2x_nhwc_f16(void* y, const void* x, int N, int H, int W, int C, tfStream_t s) {
+  TF_REQUIRE(y && x && C % 8 == 0, "tf_upsample2x_nhwc_f16: C=%d must be a multiple of 8", C);
+  if ((long long)N * H * W == 0) return TF_OK;
+  hipLaunchKernelGGL(k_upsample2x, dim3(ew_grid((long long)N * 4 * H * W * (C >> 3))), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)y, (const half_t*)x, N, H, W, C);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_concat_channels_f16(void* y, const void* a, const void* b, long long rows, int Ca, int Cb, tfStream_t s) {
+  TF_REQUIRE(y && a && b && Ca % 8 == 0 && Cb % 8 == 0, "tf_concat_channels_f16: Ca=%d Cb=%d must be multiples of 8", Ca, Cb);
+  if (rows == 0) return TF_OK;
+  hipLaunchKernelGGL(k_concat, dim3(ew_grid(rows * ((Ca + Cb) >> 3))), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)y, (const half_t*)a, (const half_t*)b, rows, Ca, Cb);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_im2col_nhwc_f16(void* y, const void* x, int N, int H, int W, int C, int R, int S, int stride, int pad, int Kpad, tfStream_t s) {
+  TF_REQUIRE(y && x && Kpad >= R * S * C && stride >= 1, "tf_im2col_nhwc_f16: Kpad=%d < R*S*C=%d", Kpad, R * S * C);
+  int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+  long long total = (long long)N * Ho * Wo * Kpad;
+  if (total == 0) return TF_OK;
+  hipLaunchKernelGGL(k_im2col, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)y, (const half_t*)x, N, H, W, C, R, S, stride, pad, Ho, Wo, Kpad);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_cast_f32_to_f16(void* dst, const void* src, long long n, tfStream_t s) {
+  TF_REQUIRE(dst && src && n >= 0, "tf_cast_f32_to_f16: bad arguments");
+  if (n == 0) return TF_OK;
+  hipLaunchKernelGGL(k_cast_f32_f16, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)dst, (const float*)src, n);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_cast_f16_to_f32(void* dst, const void* src, long long n, tfStream_t s) {
+  TF_REQUIRE(dst && src && n >= 0, "tf_cast_f16_to_f32: bad arguments");
+  if (n == 0) return TF_OK;
+  hipLaunchKernelGGL(k_cast_f16_f32, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (float*)dst, (const half_t*)src, n);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_nchw_f32_to_nhwc_f16(void* dst, const void* src, int N, int C, int H, int W, tfStream_t s) {
+  TF_REQUIRE(dst && src && N >= 0 && C > 0 && N <= 65535, "tf_nchw_f32_to_nhwc_f16: bad arguments");
+  int HW = H * W;
+  if ((long long)N * HW == 0) return TF_OK;
+  hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(ceil_div(HW, 32), ceil_div(C, 32), N), dim3(256), 0, tf_hs(s), (half_t*)dst, (const float*)src, C, HW);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_nhwc_f16_to_nchw_f32(void* dst, const void* src, int N, int C, int H, int W, tfStream_t s) {
+  TF_REQUIRE(dst && src && N >= 0 && C > 0 && N <= 65535, "tf_nhwc_f16_to_nchw_f32: bad arguments");
+  int HW = H * W;
+  if ((long long)N * HW == 0) return TF_OK;
+  hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(ceil_div(HW, 32), ceil_div(C, 32), N), dim3(256), 0, tf_hs(s), (float*)dst, (const half_t*)src, C, HW);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_scale_f32(void* x, float scale, long long n, tfStream_t s) {
+  TF_REQUIRE(x && n >= 0, "tf_scale_f32: bad arguments");
+  if (n == 0) return TF_OK;
+  hipLaunchKernelGGL(k_scale_f32, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (float*)x, scale, n);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_add_bias_colmajor_f32(void* out, const void* bias, int BT, int OC, tfStream_t s) {
+  TF_REQUIRE(out && bias && BT >= 0 && OC >= 0, "tf_add_bias_colmajor_f32: bad arguments");
+  if ((long long)BT * OC == 0) return TF_OK;
+  hipLaunchKernelGGL(k_add_bias_cm, dim3(ew_grid((long long)BT * OC)), dim3(EW_BLOCK), 0, tf_hs(s), (float*)out, (const float*)bias, BT, OC);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_transpose_f32(void* out, const void* inp, int ndim, const int* shape, const int* axes, tfStream_t s) {
+  TF_REQUIRE(out && inp && shape && axes && ndim >= 1 && ndim <= 4, "tf_transpose_f32: ndim=%d must be 1..4", ndim);
+  long long istride[4], n = 1;
+  bool seen[4] = {false, false, false, false};
+  for (int d = ndim - 1, st = 1; d >= 0; --d) { istride[d] = n; n *= shape[d]; (void)st; }
+  PermArgs a;
+  a.ndim = ndim;
+  for (int d = 0; d < 4; ++d) { a.oshape[d] = 1; a.istride_of_o[d] = 0; }
+  for (int d = 0; d < ndim; ++d) {
+    TF_REQUIRE(axes[d] >= 0 && axes[d] < ndim && !seen[axes[d]], "tf_transpose_f32: axes is not a permutation");
+    seen[axes[d]] = true;
+    a.oshape[d] = shape[axes[d]];
+    a.istride_of_o[d] = istride[axes[d]];
+  }
+  if (n == 0) return TF_OK;
+  hipLaunchKernelGGL(k_permute_f32, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (float*)out, (const float*)inp, a, n);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_softmax_rows_f32(void* out, const void* inp, int N, int C, tfStream_t s) {
+  TF_REQUIRE(out && inp && N >= 0 && C >= 1, "tf_softmax_rows_f32: bad arguments");
+  if (N == 0) return TF_OK;
+  hipLaunchKernelGGL(k_softmax_rows, dim3(N), dim3(256), 0, tf_hs(s), (float*)out, (const float*)inp, C);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_timestep_embedding_f16(void* out, const void* step_params, int dim, float max_period, tfStream_t s) {
+  TF_REQUIRE(out && step_params && dim > 0 && dim % 2 == 0, "tf_timestep_embedding_f16: dim=%d must be even", dim);
+  hipLaunchKernelGGL(k_timestep_embedding, dim3(1), dim3(256), 0, tf_hs(s), (half_t*)out, (const float*)step_params, dim, max_period);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_cfg_duplicate_f16(void* x2b, const void* latent, int B, int C, int H, int W, tfStream_t s) {
+  TF_REQUIRE(x2b && latent && B > 0 && C > 0, "tf_cfg_duplicate_f16: bad arguments");
+  long long n = (long long)B * C * H * W;
+  hipLaunchKernelGGL(k_cfg_duplicate, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)x2b, (const float*)latent, B, C, H * W);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_cfg_ddim_step_f32(void* latent, const void* eps2, const void* params, int B, int C, int H, int W, tfStream_t s) {
+  TF_REQUIRE(latent && eps2 && params && B > 0 && C > 0, "tf_cfg_ddim_step_f32: bad arguments");
+  long long n = (long long)B * C * H * W;
+  hipLaunchKernelGGL(k_cfg_ddim, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (float*)latent, (const half_t*)eps2, (const float*)params, B, C, H * W);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+
+}  // extern "C"

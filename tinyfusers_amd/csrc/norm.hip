@@ -1,0 +1,215 @@
+// GroupNorm(+affine,+SiLU) on NHWC f16 and LayerNorm over the last dim.  HBM-bound: 16-B loads, wave64
+// shuffles, fp32 statistics.  Reference: ff/group_norm.py:3-21, ff/layer_norm.py:8-49.
+#include "common.h"
+#include "../../include/tinyfusers_hip.h"
+
+#define GN_MAX_CHUNKS 64
+
+// ---- GroupNorm pass 1: per-(image, pixel-chunk) partial sums per group ---------------------------
+// block = CV * RPB threads (CV = C/8 channel vectors, RPB rows per sweep); thread owns one channel vector.
+// partial layout: [N][chunks][G][2] fp32 (sum, sum of squares)
+__global__ void k_gn_stats(float* __restrict__ partial, const half_t* __restrict__ x, const half_t* __restrict__ x2, int HW, int C1, int C2,
+                           int G, int chunks, int pix_per_chunk, int CV, int RPB) {
+  extern __shared__ float bins[];  // [G][2]
+  int n = blockIdx.y, chunk = blockIdx.x;
+  int C = C1 + C2, cpg = C / G;
+  int t = threadIdx.x;
+  int cv = t % CV, rr = t / CV;
+  for (int i = t; i < 2 * G; i += blockDim.x) bins[i] = 0.f;
+  __syncthreads();
+  int c = cv * 8;
+  const half_t* base;
+  int ld;
+  if (c < C1) { base = x + (long long)n * HW * C1 + c; ld = C1; }
+  else { base = x2 + (long long)n * HW * C2 + (c - C1); ld = C2; }
+  float s[8], ss[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
+  int p0 = chunk * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
+  if (rr < RPB) {
+    for (int p = p0 + rr; p < p1; p += RPB) {
+      h8 v = *reinterpret_cast<const h8*>(base + (long long)p * ld);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; ss[j] += f * f; }
+    }
+    // fold this thread's 8 channels into (at most a few) group bins
+    int g = c / cpg;
+    float as = 0.f, ass = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int gj = (c + j) / cpg;
+      if (gj != g) { atomicAdd(&bins[2 * g], as); atomicAdd(&bins[2 * g + 1], ass); as = 0.f; ass = 0.f; g = gj; }
+      as += s[j]; ass += ss[j];
+    }
+    atomicAdd(&bins[2 * g], as); atomicAdd(&bins[2 * g + 1], ass);
+  }
+  __syncthreads();
+  float* out = partial + ((long long)n * chunks + chunk) * G * 2;
+  for (int i = t; i < 2 * G; i += blockDim.x) out[i] = bins[i];
+}
+
+// ---- GroupNorm pass 2: y = silu?((x - mean) * rstd * gamma + beta) ----------------------------------
+__global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ x2, const half_t* __restrict__ gamma,
+                           const half_t* __restrict__ beta, const float* __restrict__ partial, int HW, int C1, int C2, int G, float eps,
+                           int do_silu, int chunks, int pix_per_block, int CV, int RPB) {
+  extern __shared__ float stat[];  // [G][2] : mean, rstd
+  int n = blockIdx.y;
+  int C = C1 + C2, cpg = C / G;
+  int t = threadIdx.x;
+  if (t < G) {
+    double S = 0.0, SS = 0.0;
+    const float* p = partial + (long long)n * chunks * G * 2 + t * 2;
+    for (int k = 0; k < chunks; ++k) { S += (double)p[(long long)k * G * 2]; SS += (double)p[(long long)k * G * 2 + 1]; }
+    double cnt = (double)HW * cpg;
+    double mean = S / cnt;
+    double var = SS / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stat[2 * t] = (float)mean;
+    stat[2 * t + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  int cv = t % CV, rr = t / CV;
+  if (rr >= RPB) return;
+  int c = cv * 8;
+  float a[8], b[8];
+  {
+    h8 gm, bt;
+    if (gamma) { gm = *reinterpret_cast<const h8*>(gamma + c); bt = *reinterpret_cast<const h8*>(beta + c); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int g = (c + j) / cpg;
+      float mean = stat[2 * g], rstd = stat[2 * g + 1];
+      float gmj = gamma ? (float)gm[j] : 1.0f, btj = gamma ? (float)bt[j] : 0.0f;
+      a[j] = rstd * gmj;
+      b[j] = btj - mean * a[j];
+    }
+  }
+  const half_t* base;
+  int ld;
+  if (c < C1) { base = x + (long long)n * HW * C1 + c; ld = C1; }
+  else { base = x2 + (long long)n * HW * C2 + (c - C1); ld = C2; }
+  half_t* yo = y + (long long)n * HW * C + c;
+  int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+  for (int p = p0 + rr; p < p1; p += RPB) {
+    h8 v = *reinterpret_cast<const h8*>(base + (long long)p * ld), o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = (float)v[j] * a[j] + b[j];
+      o[j] = (half_t)(do_silu ? silu_f(f) : f);
+    }
+    *reinterpret_cast<h8*>(yo + (long long)p * C) = o;
+  }
+}
+
+// ---- LayerNorm: one wave per row, row held in registers (C <= 64*8*LN_MAXV) ----------------------
+#define LN_MAXV 5
+__global__ void __launch_bounds__(256) k_layer_norm(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ gamma,
+                                                    const half_t* __restrict__ beta, int rows, int C, float eps) {
+  int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  int row = blockIdx.x * 4 + w;
+  if (row >= rows) return;
+  int CV = C >> 3;
+  const half_t* xr = x + (long long)row * C;
+  h8 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int cv = l + 64 * i;
+    if (cv < CV) {
+      v[i] = *reinterpret_cast<const h8*>(xr + cv * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)v[i][j];
+    }
+  }
+  s = wave_sum(s);
+  float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int cv = l + 64 * i;
+    if (cv < CV) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float d = (float)v[i][j] - mean; q += d * d; }
+    }
+  }
+  q = wave_sum(q);
+  float rstd = rsqrtf(q / (float)C + eps);
+  half_t* yr = y + (long long)row * C;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int cv = l + 64 * i;
+    if (cv < CV) {
+      h8 o;
+      if (gamma) {
+        h8 gm = *reinterpret_cast<const h8*>(gamma + cv * 8), bt = *reinterpret_cast<const h8*>(beta + cv * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)(((float)v[i][j] - mean) * rstd * (float)gm[j] + (float)bt[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)(((float)v[i][j] - mean) * rstd);
+      }
+      *reinterpret_cast<h8*>(yr + cv * 8) = o;
+    }
+  }
+}
+
+static void gn_geometry(int HW, int C, int N, int* CV, int* RPB, int* threads, int* chunks, int* ppc) {
+  *CV = C / 8;
+  *RPB = *CV >= 256 ? 1 : 256 / *CV;
+  if (*RPB > HW) *RPB = HW > 0 ? HW : 1;
+  *threads = *CV * *RPB;
+  int want = (512 + N - 1) / (N > 0 ? N : 1);          // ~2 blocks per CU over the whole launch
+  if (want > GN_MAX_CHUNKS) want = GN_MAX_CHUNKS;
+  int maxc = (HW + *RPB - 1) / *RPB;
+  if (want > maxc) want = maxc;
+  if (want < 1) want = 1;
+  int p = (HW + want - 1) / want;
+  p = ((p + *RPB - 1) / *RPB) * *RPB;
+  *ppc = p;
+  *chunks = (HW + p - 1) / p;
+}
+
+extern "C" {
+
+size_t tf_group_norm_workspace(int N, int HW, int C, int G) {
+  (void)HW; (void)C;
+  return (size_t)N * GN_MAX_CHUNKS * G * 2 * sizeof(float);
+}
+
+int tf_group_norm_f16(void* y, const void* x, const void* x2, const void* gamma, const void* beta, int N, int HW, int C1, int C2, int G,
+                      float eps, int silu, void* workspace, size_t workspace_bytes, tfStream_t s) {
+  int C = C1 + C2;
+  TF_REQUIRE(y && x && (C2 == 0 || x2), "tf_group_norm_f16: null tensor");
+  TF_REQUIRE((gamma == nullptr) == (beta == nullptr), "tf_group_norm_f16: gamma and beta must both be given or both NULL");
+  TF_REQUIRE(N >= 0 && HW >= 0 && G >= 1 && C > 0 && C % G == 0, "tf_group_norm_f16: C=%d not divisible by G=%d", C, G);
+  TF_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && C / 8 <= 1024, "tf_group_norm_f16: C1=%d C2=%d must be multiples of 8 and C <= 8192", C1, C2);
+  TF_REQUIRE(G <= 1024 && N <= 65535, "tf_group_norm_f16: G=%d N=%d out of range", G, N);
+  if (N == 0 || HW == 0) return TF_OK;
+  if (workspace_bytes < tf_group_norm_workspace(N, HW, C, G) || !workspace) {
+    tf_set_error("tf_group_norm_f16: workspace %zu B < required %zu B", workspace_bytes, tf_group_norm_workspace(N, HW, C, G));
+    return TF_E_WORKSPACE;
+  }
+  int CV, RPB, threads, chunks, ppc;
+  gn_geometry(HW, C, N, &CV, &RPB, &threads, &chunks, &ppc);
+  int tl = threads < G ? G : threads;  // pass 2 needs >= G threads for the finalize
+  hipLaunchKernelGGL(k_gn_stats, dim3(chunks, N), dim3(threads), 2 * G * sizeof(float), tf_hs(s), (float*)workspace, (const half_t*)x,
+                     (const half_t*)x2, HW, C1, C2, G, chunks, ppc, CV, RPB);
+  TF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_gn_apply, dim3(chunks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
+                     (const half_t*)gamma, (const half_t*)beta, (const float*)workspace, HW, C1, C2, G, eps, silu, chunks, ppc, CV, RPB);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+
+int tf_layer_norm_f16(void* y, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s) {
+  TF_REQUIRE(y && x && rows >= 0, "tf_layer_norm_f16: null tensor");
+  TF_REQUIRE((gamma == nullptr) == (beta == nullptr), "tf_layer_norm_f16: gamma and beta must both be given or both NULL");
+  TF_REQUIRE(C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXV, "tf_layer_norm_f16: C=%d must be a multiple of 8 and <= %d", C, 64 * 8 * LN_MAXV);
+  if (rows == 0) return TF_OK;
+  hipLaunchKernelGGL(k_layer_norm, dim3(ceil_div(rows, 4)), dim3(256), 0, tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)gamma,
+                     (const half_t*)beta, rows, C, eps);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+
+}  // extern "C"

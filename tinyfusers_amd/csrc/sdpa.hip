@@ -1,0 +1,249 @@
+// Fused flash-style scaled-dot-product attention for gfx950 (wave64, MFMA 16x16x32 f16, online softmax).
+// Replaces attention/sdpa.py:53-77 (cp.matmul -> softmax_kernel -> cp.matmul with the (B,NH,Tq,Tk) fp32
+// score matrix materialised twice in HBM): scores never leave registers.
+//
+// Block = 4 waves, 128 query rows (32 per wave); K/V tiles of 64 keys staged through LDS (register-staged
+// prefetch, two LDS stages).  Per wave and tile:
+//   S^T (64 keys x 32 queries) = K_tile . Q^T      -- K rows are the MFMA A operand (ds_read_b128),
+//                                                     Q fragments stay in registers for the whole kernel;
+//   softmax along keys is lane-local (query = lane & 15) plus two xor-shuffles across the 4 lane groups;
+//   O^T (d x 32 queries) += V^T . P^T              -- P^T is already in B-operand layout (accumulator ->
+//                                                     operand, keys permuted so each lane group owns 8
+//                                                     consecutive keys), V^T comes from the row-major V
+//                                                     tile with ds_read_b64_tr_b16.
+#include "common.h"
+#include "../../include/tinyfusers_hip.h"
+
+struct SdpaP {
+  const half_t* q; const half_t* k; const half_t* v; half_t* o;
+  int B, NH, Tq, Tk, HS;
+  long long q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st;
+  float scale_log2e;
+  int causal;
+};
+
+__device__ __forceinline__ s4v lds_tr16(const half_t* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)p);
+}
+
+template <int DQK, int DV>
+__global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
+  constexpr int KS = DQK + 8;                 // K row stride (halves); 16-B multiple
+  constexpr int VS = DV + 8;                  // V row stride (halves); 16-B multiple
+  constexpr int NKS = DQK / 32;               // k-steps of QK^T
+  constexpr int NDT = DV / 16;                // d tiles of PV
+  constexpr int CPR = DV / 8;                 // 16-B chunks per staged row (covers HS <= DV)
+  constexpr int NCH = (64 * CPR + 255) / 256; // staging rounds per tensor
+  constexpr int STAGE_H = 64 * KS + 64 * VS;  // halves per stage
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  half_t* smem = reinterpret_cast<half_t*>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qblk = blockIdx.x * 128 + wid * 32;
+  const half_t* qb = p.q + b * p.q_sb + h * p.q_sh;
+  const half_t* kb = p.k + b * p.k_sb + h * p.k_sh;
+  const half_t* vb = p.v + b * p.v_sb + h * p.v_sh;
+
+  // zero both stages once: padding columns [HS, DQK) of K and [HS, DV) of V are never written afterwards
+  for (int i = tid; i < 2 * STAGE_H / 8; i += 256) reinterpret_cast<h8*>(smem)[i] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+
+  // Q fragments (B operand of S^T = K Q^T): lane holds Q[query lr][d = 32 ks + 8 lg + j]
+  h8 qf[2][NKS];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    int qi = qblk + qt * 16 + lr;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      int d0 = ks * 32 + lg * 8;
+      qf[qt][ks] = (qi < p.Tq && d0 < p.HS) ? *reinterpret_cast<const h8*>(qb + qi * p.q_st + d0) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+
+  f4 ot[NDT][2];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) { ot[dt][0] = (f4){0, 0, 0, 0}; ot[dt][1] = (f4){0, 0, 0, 0}; }
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+  int ntiles = (p.Tk + 63) / 64;
+  if (p.causal) {   // keys beyond the block's last query are never needed
+    int last_q = min(p.Tq, blockIdx.x * 128 + 128) - 1;
+    ntiles = min(ntiles, last_q / 64 + 1);
+  }
+
+  h8 kreg[NCH], vreg[NCH];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int r = 0; r < NCH; ++r) {
+      int idx = tid + 256 * r;
+      int row = idx / CPR, col = (idx - row * CPR) * 8;
+      int key = t * 64 + row;
+      bool ok = row < 64 && key < p.Tk && col < p.HS;
+      kreg[r] = ok ? *reinterpret_cast<const h8*>(kb + key * p.k_st + col) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+      vreg[r] = ok ? *reinterpret_cast<const h8*>(vb + key * p.v_st + col) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  };
+  auto store_tile = [&](int buf) {
+    half_t* ks_ = smem + buf * STAGE_H;
+    half_t* vs_ = ks_ + 64 * KS;
+#pragma unroll
+    for (int r = 0; r < NCH; ++r) {
+      int idx = tid + 256 * r;
+      int row = idx / CPR, col = (idx - row * CPR) * 8;
+      if (row < 64 && col < p.HS) {
+        *reinterpret_cast<h8*>(ks_ + row * KS + col) = kreg[r];
+        *reinterpret_cast<h8*>(vs_ + row * VS + col) = vreg[r];
+      }
+    }
+  };
+
+  load_tile(0);
+  __syncthreads();           // zero-fill complete before the first tile lands on top of it
+  store_tile(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) load_tile(t + 1);
+    const half_t* ks_ = smem + buf * STAGE_H;
+    const half_t* vs_ = ks_ + 64 * KS;
+
+    // ---- S^T = K Q^T : st[kt][qt], key(kt, row) = 32 (kt>>1) + 8 (row>>2) + 4 (kt&1) + (row&3)
+    f4 st[4][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      st[kt][0] = (f4){0, 0, 0, 0}; st[kt][1] = (f4){0, 0, 0, 0};
+      int krow = 32 * (kt >> 1) + 8 * (lr >> 2) + 4 * (kt & 1) + (lr & 3);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        h8 kf = *reinterpret_cast<const h8*>(ks_ + krow * KS + ks * 32 + lg * 8);
+        st[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], st[kt][0], 0, 0, 0);
+        st[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], st[kt][1], 0, 0, 0);
+      }
+    }
+    // ---- masks: this lane's keys are t*64 + 32 (kt>>1) + 8 lg + 4 (kt&1) + reg
+    const int kbase = t * 64 + 8 * lg;
+    if (t * 64 + 64 > p.Tk || p.causal) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int key = kbase + 32 * (kt >> 1) + 4 * (kt & 1) + e;
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) {
+            int qi = qblk + qt * 16 + lr;
+            if (key >= p.Tk || (p.causal && key > qi)) st[kt][qt][e] = -INFINITY;
+          }
+        }
+    }
+    // ---- online softmax (per query column), P^T fragments
+    h8 pf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float mx = st[0][qt][0];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, st[kt][qt][e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float m_new = fmaxf(m_run[qt], mx);
+      float m_safe = m_new == -INFINITY ? 0.f : m_new;
+      float alpha = exp2f((m_run[qt] - m_safe) * p.scale_log2e);   // m_run = -inf -> 0
+      float mc = m_safe * p.scale_log2e;
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float pv = exp2f(st[kt][qt][e] * p.scale_log2e - mc);
+          sum += pv;
+          pf[kt >> 1][qt][(kt & 1) * 4 + e] = (half_t)pv;
+        }
+      l_run[qt] = l_run[qt] * alpha + sum;
+      m_run[qt] = m_new;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) ot[dt][qt] *= alpha;
+    }
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        const half_t* va = vs_ + (32 * kc + 8 * lg + (lr >> 2)) * VS + dt * 16 + 4 * (lr & 3);
+        s4v v0 = lds_tr16(va), v1 = lds_tr16(va + 4 * VS);
+        union { struct { s4v a, b; } s; h8 h; } u;
+        u.s.a = v0; u.s.b = v1;
+        ot[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.h, pf[kc][0], ot[dt][0], 0, 0, 0);
+        ot[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.h, pf[kc][1], ot[dt][1], 0, 0, 0);
+      }
+    }
+    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane holds O[query lr][d = 16 dt + 4 lg + {0..3}]
+  half_t* ob = p.o + b * p.o_sb + h * p.o_sh;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float l = l_run[qt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    float inv = l > 0.f ? 1.0f / l : 0.f;
+    int qi = qblk + qt * 16 + lr;
+    if (qi < p.Tq) {
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        int d = dt * 16 + lg * 4;
+        if (d < p.HS) {
+          h4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[dt][qt][e] * inv);
+          *reinterpret_cast<h4*>(ob + qi * p.o_st + d) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int DQK, int DV>
+static int launch_sdpa(const SdpaP& p, hipStream_t st) {
+  constexpr int smem = 2 * (64 * (DQK + 8) + 64 * (DV + 8)) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    TF_HIP(hipFuncSetAttribute((const void*)k_sdpa<DQK, DV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_sdpa<DQK, DV>), dim3((p.Tq + 127) / 128, p.NH, p.B), dim3(256), smem, st, p);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+
+extern "C" int tf_sdpa_f16(void* o, const void* q, const void* k, const void* v, int B, int NH, int Tq, int Tk, int HS, long long q_sb,
+                           long long q_sh, long long q_st, long long k_sb, long long k_sh, long long k_st, long long v_sb, long long v_sh,
+                           long long v_st, long long o_sb, long long o_sh, long long o_st, int causal, tfStream_t s) {
+  TF_REQUIRE(o && q && k && v, "tf_sdpa_f16: null tensor");
+  TF_REQUIRE(B >= 0 && NH >= 1 && Tq >= 0 && Tk >= 1, "tf_sdpa_f16: bad sizes B=%d NH=%d Tq=%d Tk=%d", B, NH, Tq, Tk);
+  TF_REQUIRE(HS >= 8 && HS % 8 == 0 && HS <= 160, "tf_sdpa_f16: head size %d must be a multiple of 8 in [8, 160]", HS);
+  TF_REQUIRE(NH <= 65535 && B <= 65535, "tf_sdpa_f16: NH / B exceed grid limits");
+  const long long str[] = {q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st};
+  for (int i = 0; i < 9; ++i) TF_REQUIRE(str[i] % 8 == 0, "tf_sdpa_f16: q/k/v strides must be multiples of 8 elements (16-B rows)");
+  TF_REQUIRE(o_sb % 4 == 0 && o_sh % 4 == 0 && o_st % 4 == 0, "tf_sdpa_f16: output strides must be multiples of 4 elements");
+  if (B == 0 || Tq == 0) return TF_OK;
+  SdpaP p;
+  p.q = (const half_t*)q; p.k = (const half_t*)k; p.v = (const half_t*)v; p.o = (half_t*)o;
+  p.B = B; p.NH = NH; p.Tq = Tq; p.Tk = Tk; p.HS = HS;
+  p.q_sb = q_sb; p.q_sh = q_sh; p.q_st = q_st; p.k_sb = k_sb; p.k_sh = k_sh; p.k_st = k_st;
+  p.v_sb = v_sb; p.v_sh = v_sh; p.v_st = v_st; p.o_sb = o_sb; p.o_sh = o_sh; p.o_st = o_st;
+  p.scale_log2e = (1.0f / sqrtf((float)HS)) * 1.4426950408889634f;
+  p.causal = causal;
+  hipStream_t st = tf_hs(s);
+  if (HS <= 32) return launch_sdpa<32, 32>(p, st);
+  if (HS <= 48) return launch_sdpa<64, 48>(p, st);
+  if (HS <= 64) return launch_sdpa<64, 64>(p, st);
+  if (HS <= 80) return launch_sdpa<96, 80>(p, st);
+  if (HS <= 96) return launch_sdpa<96, 96>(p, st);
+  if (HS <= 128) return launch_sdpa<128, 128>(p, st);
+  return launch_sdpa<160, 160>(p, st);
+}

@@ -1,0 +1,38 @@
+"""group_norm / GroupNorm -- mirrors tinyfusers/ff/group_norm.py:3-21 (7 CuPy kernels + a device sync).
+Here: two HBM-bound launches (partial statistics; normalise + affine [+ SiLU]) on NHWC fp16, and the
+channel concat of vision/unet.py:72 can be folded in by passing a pair ``(x, skip)``."""
+import numpy as np
+
+from ..native import hip
+from ..storage.tensor import DeviceArray, _sh, asarray
+from .linear import workspace
+
+
+def _gn(x, num_groups, eps, gamma, beta, silu):
+    x2 = None
+    if isinstance(x, (tuple, list)):
+        x, x2 = x
+    n, c1, h, w = x.shape
+    c2 = x2.shape[1] if x2 is not None else 0
+    y = DeviceArray.empty((n, c1 + c2, h, w), np.float16, "nhwc")
+    nb = hip.tf_group_norm_workspace(n, h * w, c1 + c2, num_groups)
+    ws = workspace(nb)
+    hip.tf_group_norm_f16(y.ptr, x.ptr, x2.ptr if x2 is not None else None, gamma.ptr if gamma is not None else None,
+                          beta.ptr if beta is not None else None, n, h * w, c1, c2, num_groups, float(eps), 1 if silu else 0,
+                          ws.ptr, nb, _sh())
+    return y
+
+
+def group_norm(x, num_groups, eps):
+    """ff/group_norm.py:3-11 -- no affine."""
+    return _gn(x, num_groups, eps, None, None, False)
+
+
+class GroupNorm:
+    def __init__(self, num_groups, num_channels, eps=1e-5, affine=True, init=True):
+        self.num_groups, self.num_channels, self.eps = num_groups, num_channels, eps
+        self.weight = (asarray(np.ones(num_channels, dtype=np.float16)) if init else None) if affine else None
+        self.bias = (asarray(np.zeros(num_channels, dtype=np.float16)) if init else None) if affine else None
+
+    def __call__(self, x, silu=False):
+        return _gn(x, self.num_groups, self.eps, self.weight, self.bias, silu)

@@ -1,0 +1,69 @@
+"""GEGLU / FeedForward -- mirrors tinyfusers/ff/nn.py:5-23.  The projection, the split and a * gelu(gate) are
+one GEMM launch: the (2*dim_out, dim_in) weight is re-packed once on the device into 16-row blocks
+alternating value / gate so that both halves of a pair land in the same MFMA lane (tf_linear_f16 act=1)."""
+import numpy as np
+
+from ..native import hip
+from ..storage.tensor import DeviceArray, Tensor, _sh
+from .linear import Linear, linear_f16
+
+
+def pack_geglu(weight, bias):
+    """(2N, K) [values ; gates] -> 16-row blocks v0 g0 v1 g1 ... (and the bias likewise), on the device."""
+    two_n, k = weight.shape
+    n = two_n // 2
+    assert n % 16 == 0, "GEGLU width must be a multiple of 16"
+    wp = DeviceArray.empty((two_n, k), np.float16, "row")
+    blk = 16 * k * 2
+    hip.tf_memcpy_2d_async(wp.ptr, 2 * blk, weight.ptr, blk, blk, n // 16, _sh())
+    hip.tf_memcpy_2d_async(wp.ptr + blk, 2 * blk, weight.ptr + n * k * 2, blk, blk, n // 16, _sh())
+    bp = DeviceArray.empty((two_n,), np.float16, "row")
+    hip.tf_memcpy_2d_async(bp.ptr, 64, bias.ptr, 32, 32, n // 16, _sh())
+    hip.tf_memcpy_2d_async(bp.ptr + 32, 64, bias.ptr + n * 2, 32, 32, n // 16, _sh())
+    return wp, bp
+
+
+class GEGLU:
+    def __init__(self, dim_in, dim_out, init=True):
+        self.proj = Linear(dim_in, dim_out * 2, init=init)
+        self.dim_out = dim_out
+        self._packed = None
+
+    def _pack(self):
+        key = (self.proj.weight.ptr, self.proj.bias.ptr)
+        if self._packed is None or self._packed[0] != key:
+            self._packed = (key,) + pack_geglu(self.proj.weight, self.proj.bias)
+        return self._packed[1], self._packed[2]
+
+    def __call__(self, x):
+        if self.dim_out % 16 == 0 and self.proj.bias is not None:
+            wp, bp = self._pack()
+            return linear_f16(x, wp, bp, None, act=1, out_features=self.dim_out)
+        h = self.proj(x)                                   # unfused fallback shape (still HIP): split + a*gelu(gate)
+        y = DeviceArray.empty(x.shape[:-1] + (self.dim_out,), np.float16, "row")
+        hip.tf_geglu_f16(y.ptr, h.ptr, h.size // h.shape[-1], self.dim_out, _sh())
+        return y
+
+
+class FeedForward:
+    def __init__(self, dim, mult=4, init=True):
+        self.net = [
+            GEGLU(dim, dim * mult, init=init),
+            lambda x: x,  # dropout slot: keeps list indices aligned with checkpoint keys (ff/nn.py:18)
+            Linear(dim * mult, dim, init=init),
+        ]
+
+    def __call__(self, x, residual=None):
+        h = self.net[0](x)
+        return self.net[2](h, residual=residual)
+
+
+class CLIPMLP:
+    """ff/nn.py:25-34 (CLIP text encoder; next-row f2)."""
+
+    def __init__(self, init=True):
+        self.fc1 = Linear(768, 3072, init=init)
+        self.fc2 = Linear(3072, 768, init=init)
+
+    def __call__(self, hidden_states):
+        return self.fc2(Tensor.quick_gelu(self.fc1(hidden_states)))

@@ -1,0 +1,83 @@
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libtinyfusers_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "tinyfusers_hip.h")
+
+_CT = {
+    "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "size_t": ctypes.c_size_t,
+    "long long": ctypes.c_longlong, "void*": ctypes.c_void_p, "const void*": ctypes.c_void_p,
+    "void**": ctypes.POINTER(ctypes.c_void_p), "int*": ctypes.POINTER(ctypes.c_int), "const int*": ctypes.POINTER(ctypes.c_int),
+    "float*": ctypes.POINTER(ctypes.c_float), "double*": ctypes.POINTER(ctypes.c_double),
+    "long long*": ctypes.POINTER(ctypes.c_longlong), "char*": ctypes.c_char_p, "const char*": ctypes.c_char_p,
+    "tfStream_t": ctypes.c_void_p, "tfEvent_t": ctypes.c_void_p, "tfGraph_t": ctypes.c_void_p,
+    "tfStream_t*": ctypes.POINTER(ctypes.c_void_p), "tfEvent_t*": ctypes.POINTER(ctypes.c_void_p),
+    "tfGraph_t*": ctypes.POINTER(ctypes.c_void_p), "void": None,
+}
+
+
+def _parse_header(path=HEADER_PATH):
+    """[(return type, name, [arg types])] for every prototype in include/tinyfusers_hip.h."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"^\s*#.*$", "", src, flags=re.M)
+    protos = []
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(tf_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        argt = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                mm = re.match(r"(.*?)(\w+)$", a)          # strip the parameter name
+                t = mm.group(1).strip() if mm and mm.group(1).strip() else a
+                t = re.sub(r"\s*\*\s*", "*", t)
+                argt.append(t)
+        protos.append((re.sub(r"\s*\*\s*", "*", ret), name, argt))
+    return protos
+
+
+def declared_symbols():
+    return [n for _, n, _ in _parse_header()]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m tinyfusers_amd.build` (hipcc --offload-arch=gfx950). "
+            "tinyfusers_amd has no CPU fallback.")
+    dll = ctypes.CDLL(LIB_PATH)
+    for ret, name, argt in _parse_header():
+        fn = getattr(dll, name)          # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = _CT[ret]
+        fn.argtypes = [_CT[t] for t in argt]
+    return dll
+
+
+lib = _load()
+
+
+def check(status, name):
+    if status != 0:
+        msg = lib.tf_last_error()
+        raise RuntimeError(f"{name} failed with status {status}" + (f": {msg.decode()}" if msg else ""))
+
+
+class _Hip:
+    """``hip.tf_xxx(args)`` calls the C entry and raises RuntimeError on a non-zero status
+    (the reference checks the status at every call site; here it is done once)."""
+
+    def __getattr__(self, name):
+        fn = getattr(lib, name)
+        if fn.restype is not ctypes.c_int:
+            return fn
+
+        def call(*args):
+            check(fn(*args), name)
+        call.__name__ = name
+        setattr(self, name, call)
+        return call
+
+
+hip = _Hip()

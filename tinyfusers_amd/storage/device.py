@@ -1,0 +1,60 @@
+"""Device -- mirrors tinyfusers/storage/device.py:11-233, the reference's own-runtime kernel launcher
+(NVRTC compile -> cuModuleLoadData -> cuLaunchKernel of five tiny .cu kernels, cached per Device).
+Here the kernels are pre-compiled gfx950 code objects inside libtinyfusers_hip.so, so ``load_func`` has
+nothing to compile; the wrappers keep the reference's signatures and its status -> RuntimeError behaviour."""
+import ctypes
+
+import numpy as np
+
+from ..native import hip
+
+
+def _p(ptr):
+    return ptr.value if isinstance(ptr, ctypes.c_void_p) else int(ptr)
+
+
+class Device:
+    def __init__(self, device: str):
+        self.device = device
+        self.func_lib = {}
+        self.device_id = 0
+
+    def __str__(self):
+        return str(self.device)
+
+    def load_func(self, code_str, func_name):
+        raise RuntimeError("load_func: no runtime compilation on this backend -- kernels ship pre-built for gfx950 "
+                           "in libtinyfusers_hip.so (build with `python -m tinyfusers_amd.build`)")
+
+    def add_bias(self, result_pntr, bias_pntr, m, n):
+        """storage/device.py:79-102 / add_bias_func.cu: bias add into a column-major (m x n) cuBLAS result."""
+        hip.tf_add_bias_colmajor_f32(_p(result_pntr), _p(bias_pntr), n, m, None)
+        return result_pntr
+
+    def scale_tensor(self, x_ptr, scaler, B, T, NH, OC):
+        """storage/device.py:104-127 / scale_tensor_func.cu: in-place scalar multiply of B*T*NH*OC floats."""
+        hip.tf_scale_f32(_p(x_ptr), float(np.asarray(scaler).reshape(-1)[0]), B * T * NH * OC, None)
+        return x_ptr
+
+    def softmax(self, out_tensor, inp_tensor):
+        """storage/device.py:129-157 / softmax_func.cu: row softmax over (N, OC) fp32."""
+        N, OC = inp_tensor.shape
+        hip.tf_softmax_rows_f32(_p(out_tensor.dt_ptr), _p(inp_tensor.dt_ptr), N, OC, None)
+        return out_tensor
+
+    def _permute(self, out_tensor, in_tensor, axes):
+        shape = tuple(in_tensor.shape)
+        nd = len(shape)
+        sh = (ctypes.c_int * nd)(*shape)
+        ax = (ctypes.c_int * nd)(*axes)
+        hip.tf_transpose_f32(_p(out_tensor.dt_ptr), _p(in_tensor.dt_ptr), nd, sh, ax, None)
+        out_tensor.shape = tuple(shape[a] for a in axes)
+        return out_tensor
+
+    def transpose(self, out_tensor, in_tensor, axes: tuple):
+        """storage/device.py:159-195 / transpose.cu: 2-D / 3-D axis permutation."""
+        return self._permute(out_tensor, in_tensor, tuple(axes))
+
+    def transpose4d(self, out_tensor, in_tensor, axes: tuple):
+        """storage/device.py:197-233 / transpose4d.cu: 4-D axis permutation."""
+        return self._permute(out_tensor, in_tensor, tuple(axes))

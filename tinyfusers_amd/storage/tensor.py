@@ -1,0 +1,308 @@
+"""Device arrays and activation statics.
+
+Mirrors tinyfusers/storage/tensor.py: the reference's ``Tensor`` is (a) a cudaMalloc/cudaMemcpy handle
+holder (:10-62) and (b) a bag of activation statics used as free functions over CuPy arrays (:64-86).
+Here the CuPy ndarray's role is played by ``DeviceArray`` -- a thin (pointer, logical shape, dtype,
+layout) handle over HIP memory obtained through the C-ABI (tf_malloc / tf_memcpy / tf_free).
+
+Layout: activations are fp16.  A 4-D array keeps the reference's *logical* NCHW shape but is stored
+channels-last (NHWC); (B, T, C) token arrays are plain row-major, so the NCHW<->(b,hw,c) transposes of
+attention/attention.py:71,74 are free re-views.  Weights of Conv2d keep logical (K,C,R,S) and are stored
+"KRSC" by the very same rule.
+"""
+import ctypes
+import functools
+import math
+import weakref
+
+import numpy as np
+
+from ..native import hip
+
+H2D, D2H, D2D = 1, 2, 3
+_ALIGN = 256
+
+
+# ------------------------------------------------------------------------------------------------
+# streams and allocation
+class Stream:
+    """An explicit HIP stream (the reference only ever uses the NULL stream, storage/device.py:98)."""
+
+    def __init__(self, handle=None):
+        if handle is None:
+            h = ctypes.c_void_p()
+            hip.tf_stream_create(ctypes.byref(h))
+            self.handle, self._own = h, True
+        else:
+            self.handle, self._own = handle, False
+
+    def synchronize(self):
+        hip.tf_stream_sync(self.handle)
+
+    def __del__(self):
+        if getattr(self, "_own", False) and self.handle:
+            try:
+                hip.tf_stream_destroy(self.handle)
+            except Exception:
+                pass
+
+
+_NULL_STREAM = Stream(ctypes.c_void_p(None))
+_stream_stack = [_NULL_STREAM]
+_initialised = [False]
+
+
+def ensure_init(device=None):
+    if not _initialised[0] or device is not None:
+        hip.tf_init(int(device or 0))
+        _initialised[0] = True
+
+
+def current_stream():
+    return _stream_stack[-1]
+
+
+class use_stream:
+    """``with use_stream(s):`` routes every op launched inside onto stream ``s``."""
+
+    def __init__(self, s): self.s = s
+    def __enter__(self): _stream_stack.append(self.s); return self.s
+    def __exit__(self, *a): _stream_stack.pop()
+
+
+def _sh():
+    return _stream_stack[-1].handle
+
+
+class Pool:
+    """Stream-ordered caching allocator: freed blocks are re-used (most recently freed first, so the
+    re-used block is still hot in L2 / Infinity Cache) instead of returned to the driver.  Allocation
+    order is deterministic, which is what makes whole-step HIP-graph capture of the eager op stream
+    possible: no hipMalloc/hipFree ever happens inside a captured region once the pool is warm."""
+
+    def __init__(self):
+        self.free_blocks = {}
+        self.allocated = 0
+        self.frozen = False      # True while capturing a graph: growing the pool would call hipMalloc
+
+    def alloc(self, nbytes):
+        n = max(_ALIGN, (int(nbytes) + _ALIGN - 1) // _ALIGN * _ALIGN)
+        lst = self.free_blocks.get(n)
+        if lst:
+            return lst.pop(), n
+        if self.frozen:
+            raise RuntimeError(f"Pool: allocation of {n} B while frozen (graph capture) -- warm up with one eager step first")
+        ensure_init()
+        p = ctypes.c_void_p()
+        hip.tf_malloc(ctypes.byref(p), n)
+        self.allocated += n
+        return p.value, n
+
+    def release(self, ptr, n):
+        self.free_blocks.setdefault(n, []).append(ptr)
+
+
+_pool = Pool()
+
+
+def pool():
+    return _pool
+
+
+def _pool_free(ptr, n):
+    _pool.release(ptr, n)
+
+
+_NP = {"f16": np.float16, "f32": np.float32}
+
+
+class DeviceArray:
+    """(ptr, logical shape, dtype, layout) handle.  layout: 'nhwc' (4-D, logical NCHW) or 'row'."""
+    __slots__ = ("ptr", "shape", "dtype", "layout", "_base", "_fin", "__weakref__")
+
+    def __init__(self, ptr, shape, dtype=np.float16, layout=None, base=None):
+        self.ptr = int(ptr)
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.layout = layout or ("nhwc" if len(self.shape) == 4 else "row")
+        self._base = base
+        self._fin = None
+
+    # -- construction
+    @staticmethod
+    def empty(shape, dtype=np.float16, layout=None):
+        shape = tuple(int(s) for s in shape)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        ptr, n = _pool.alloc(nbytes)
+        a = DeviceArray(ptr, shape, dtype, layout)
+        a._fin = weakref.finalize(a, _pool_free, ptr, n)
+        return a
+
+    @staticmethod
+    def from_numpy(x, dtype=np.float16, layout=None):
+        x = np.asarray(x)
+        a = DeviceArray.empty(x.shape, dtype, layout)
+        host = x.astype(dtype, copy=False)
+        if a.layout == "nhwc":
+            host = host.transpose(0, 2, 3, 1)
+        host = np.ascontiguousarray(host)
+        hip.tf_memcpy(a.ptr, host.ctypes.data, host.nbytes, H2D)
+        return a
+
+    @staticmethod
+    def zeros(shape, dtype=np.float16, layout=None):
+        a = DeviceArray.empty(shape, dtype, layout)
+        hip.tf_memset_async(a.ptr, 0, a.nbytes, _sh())
+        return a
+
+    # -- properties
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def numpy(self):
+        """Blocking download in the *logical* layout (NCHW for images), as float32."""
+        hip.tf_stream_sync(_sh())
+        if self.layout == "nhwc":
+            n, c, h, w = self.shape
+            host = np.empty((n, h, w, c), dtype=self.dtype)
+        else:
+            host = np.empty(self.shape, dtype=self.dtype)
+        if host.nbytes:
+            hip.tf_memcpy(host.ctypes.data, self.ptr, host.nbytes, D2H)
+        if self.layout == "nhwc":
+            host = host.transpose(0, 3, 1, 2)
+        return np.ascontiguousarray(host).astype(np.float32)
+
+    def view(self, shape, layout="row", offset_elems=0):
+        """Re-view of the same memory (no copy); keeps the parent alive."""
+        return DeviceArray(self.ptr + offset_elems * self.dtype.itemsize, shape, self.dtype, layout, base=self)
+
+    def reshape(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        shape = list(shape)
+        if -1 in shape:
+            i = shape.index(-1)
+            shape[i] = self.size // max(1, -int(np.prod(shape)))
+        assert int(np.prod(shape)) == self.size, (self.shape, shape)
+        assert self.layout == "row", "reshape of an NHWC image: use .tokens() / .image()"
+        return self.view(tuple(shape), "row")
+
+    def tokens(self):
+        """(b,c,h,w) image -> (b, h*w, c) tokens: attention/attention.py:71 as a free re-view."""
+        assert self.layout == "nhwc"
+        n, c, h, w = self.shape
+        return self.view((n, h * w, c), "row")
+
+    def image(self, b, c, h, w):
+        """(b, h*w, c) tokens -> (b,c,h,w) image: attention/attention.py:74 as a free re-view."""
+        assert self.layout == "row" and self.size == b * c * h * w
+        return self.view((b, c, h, w), "nhwc")
+
+    def astype(self, dtype):
+        dtype = np.dtype(dtype)
+        if dtype == self.dtype:
+            return self
+        out = DeviceArray.empty(self.shape, dtype, self.layout)
+        if dtype == np.float16 and self.dtype == np.float32:
+            hip.tf_cast_f32_to_f16(out.ptr, self.ptr, self.size, _sh())
+        elif dtype == np.float32 and self.dtype == np.float16:
+            hip.tf_cast_f16_to_f32(out.ptr, self.ptr, self.size, _sh())
+        else:
+            raise TypeError(f"astype {self.dtype} -> {dtype}")
+        return out
+
+    def __add__(self, other):
+        assert isinstance(other, DeviceArray) and other.size == self.size and self.dtype == np.float16
+        out = DeviceArray.empty(self.shape, self.dtype, self.layout)
+        hip.tf_add_f16(out.ptr, self.ptr, other.ptr, self.size, _sh())
+        return out
+
+    def __repr__(self):
+        return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, layout={self.layout}, ptr=0x{self.ptr:x})"
+
+
+def asarray(x, dtype=np.float16, layout=None):
+    """numpy / torch-CPU / DeviceArray -> DeviceArray (cp.asarray in the reference, storage/state.py:20)."""
+    if isinstance(x, DeviceArray):
+        return x
+    if hasattr(x, "detach"):
+        x = x.detach().cpu().numpy()
+    return DeviceArray.from_numpy(np.asarray(x), dtype, layout)
+
+
+def _unary(fn_name, x):
+    out = DeviceArray.empty(x.shape, x.dtype, x.layout)
+    getattr(hip, fn_name)(out.ptr, x.ptr, x.size, _sh())
+    return out
+
+
+class Tensor:
+    """Activation statics of storage/tensor.py:64-86 (used as free functions throughout the model),
+    plus the from_np / zeros / eval / to handle-holder API of :10-62 mapped onto DeviceArray."""
+
+    def __init__(self, shape, dtype=np.float32, device=None, data=None):
+        self.shape = shape if data is None else data.shape
+        self.dtype = np.dtype(dtype if data is None else data.dtype)
+        self.data = data
+        self.num_elem = math.prod(self.shape)
+        self.nbytes = self.num_elem * self.dtype.itemsize
+        self.dt_ptr = ctypes.c_void_p()
+        self.device = device or "hip"
+
+    def eval(self):
+        """cudaMalloc + H2D copy (storage/tensor.py:20-34)."""
+        ensure_init()
+        hip.tf_malloc(ctypes.byref(self.dt_ptr), self.nbytes)
+        if self.data is not None:
+            host = np.ascontiguousarray(self.data)
+            hip.tf_memcpy(self.dt_ptr, host.ctypes.data, host.nbytes, H2D)
+        else:
+            hip.tf_memset_async(self.dt_ptr, 0, self.nbytes, None)
+        return self
+
+    def to(self, device):
+        """D2H copy + free (storage/tensor.py:36-50)."""
+        if device == "cpu" and self.dt_ptr:
+            if self.data is None or not self.data.flags.writeable:
+                self.data = np.empty(self.shape, dtype=self.dtype)
+            self.data = np.ascontiguousarray(self.data)
+            hip.tf_device_sync()
+            hip.tf_memcpy(self.data.ctypes.data, self.dt_ptr, self.data.nbytes, D2H)
+            hip.tf_free(self.dt_ptr)
+            self.dt_ptr = ctypes.c_void_p()
+            self.device = "cpu"
+        return self
+
+    @staticmethod
+    def from_np(data):
+        return Tensor(data.shape, data.dtype, data=data)
+
+    @staticmethod
+    def zeros(shape, dtype):
+        return Tensor.from_np(np.zeros(shape, dtype=dtype))
+
+    # -- activations
+    @staticmethod
+    def sigmoid(x): return _unary("tf_sigmoid_f16", x)
+    @staticmethod
+    def silu(x): return _unary("tf_silu_f16", x)
+    @staticmethod
+    def swish(x): return _unary("tf_silu_f16", x)
+    @staticmethod
+    def quick_gelu(x): return _unary("tf_quick_gelu_f16", x)
+    @staticmethod
+    def gelu(x): return _unary("tf_gelu_f16", x)
+
+    @staticmethod
+    def sequential(iterable, init):
+        return functools.reduce(lambda x, f: f(x), iterable, init)

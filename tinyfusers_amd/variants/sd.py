@@ -1,0 +1,136 @@
+"""StableDiffusion sampler object -- mirrors tinyfusers/variants/sd.py:7-65.
+
+Same call surface: ``sd(unconditional_context, context, latent, timestep, alphas, alphas_prev, guidance)``
+returns x_{t-1}.  Differences, all MI355X-first:
+  * no host round trip / device syncs per step (variants/sd.py:34-41); CFG duplicate, CFG combine and the DDIM
+    update are two tiny kernels; the latent state stays fp32 NCHW on the device;
+  * batch generalised from the reference's hard-coded 1 (D8) to [uncond x B ; cond x B];
+  * ``compile()`` captures the whole step (≈450 launches) into one HIP graph replayed per step.
+Only the UNet denoising path is built: first_stage_model (VAE) and cond_stage_model (CLIP) are
+next-row items and are None here.
+"""
+import ctypes
+from collections import namedtuple
+
+import numpy as np
+
+from ..native import hip
+from ..storage.tensor import DeviceArray, Stream, _sh, asarray, pool, use_stream
+from ..vision.unet import SD15, StepParams, UNetModel
+
+
+def get_alphas_cumprod(beta_start=0.00085, beta_end=0.0120, n_training_steps=1000):
+    """variants/sd.py:61-65 (host fp32: a 1000-entry table, not device work)."""
+    betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, n_training_steps, dtype=np.float32) ** 2
+    alphas = 1.0 - betas
+    return np.cumprod(alphas, axis=0)
+
+
+def _scalar(v):
+    return float(np.asarray(v.numpy() if isinstance(v, DeviceArray) else v, dtype=np.float32).reshape(-1)[0])
+
+
+class StableDiffusion:
+    def __init__(self, cfg=SD15, init=False):
+        self.alphas_cumprod = get_alphas_cumprod()
+        self.model = namedtuple("DiffusionModel", ["diffusion_model"])(diffusion_model=UNetModel(cfg, init=init))
+        self.first_stage_model = None    # AutoencoderKL: SURVEY 8(f1), not on the per-step path
+        self.cond_stage_model = None     # CLIPTextTransformer: SURVEY 8(f2)
+        self._params = None
+        self._graph = None
+
+    # -- reference surface -------------------------------------------------------------------------
+    def get_model_output(self, unconditional_context, context, latent, timestep, unconditional_guidance_scale, params=None):
+        """variants/sd.py:27-46.  Returns the raw UNet output for [uncond x B ; cond x B] (2B,4,H,W) -- the CFG
+        combine is fused with the DDIM update in __call__ (use cfg_combine() to get e_t on its own)."""
+        b, c, h, w = latent.shape
+        x2 = DeviceArray.empty((2 * b, c, h, w), np.float16, "nhwc")
+        hip.tf_cfg_duplicate_f16(x2.ptr, latent.ptr, b, c, h, w, _sh())
+        ctx = self._stack_context(unconditional_context, context)
+        sp = params if params is not None else self._step_params().set(_scalar(timestep), 1.0, 1.0, _scalar(unconditional_guidance_scale))
+        return self.model.diffusion_model(x2, sp, ctx)
+
+    def get_x_prev_and_pred_x0(self, x, e_t, a_t, a_prev):
+        """variants/sd.py:14-25 on host arrays (kept for API parity / tests; the device path is tf_cfg_ddim_step_f32)."""
+        x, e_t = np.asarray(x, dtype=np.float32), np.asarray(e_t, dtype=np.float32)
+        a_t, a_prev = np.float32(_scalar(a_t)), np.float32(_scalar(a_prev))
+        sqrt_one_minus_at = np.sqrt(1 - a_t)
+        pred_x0 = (x - sqrt_one_minus_at * e_t) / np.sqrt(a_t)
+        dir_xt = np.sqrt(1.0 - a_prev) * e_t
+        return np.sqrt(a_prev) * pred_x0 + dir_xt, pred_x0
+
+    def __call__(self, unconditional_context, context, latent, timestep, alphas, alphas_prev, guidance):
+        """variants/sd.py:56-59: one denoising step; latent (B,4,H,W) fp32 device array -> new latent."""
+        sp = self._step_params().set(_scalar(timestep), _scalar(alphas), _scalar(alphas_prev), _scalar(guidance))
+        out = self.get_model_output(unconditional_context, context, latent, timestep, guidance, params=sp)
+        b, c, h, w = latent.shape
+        x_prev = DeviceArray.empty(latent.shape, np.float32, "row")
+        hip.tf_memcpy_async(x_prev.ptr, latent.ptr, latent.nbytes, 3, _sh())
+        hip.tf_cfg_ddim_step_f32(x_prev.ptr, out.ptr, sp.dev.ptr, b, c, h, w, _sh())
+        return x_prev
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _step_params(self):
+        if self._params is None:
+            self._params = StepParams()
+        return self._params
+
+    @staticmethod
+    def _stack_context(unconditional_context, context):
+        b, t, d = context.shape
+        ctx = DeviceArray.empty((2 * b, t, d), np.float16, "row")
+        hip.tf_memcpy_async(ctx.ptr, unconditional_context.ptr, context.nbytes, 3, _sh())
+        hip.tf_memcpy_async(ctx.ptr + context.nbytes, context.ptr, context.nbytes, 3, _sh())
+        return ctx
+
+    @staticmethod
+    def latent_from_numpy(x):
+        """(B,4,H,W) host array -> fp32 NCHW device latent (the sampler state)."""
+        return DeviceArray.from_numpy(np.ascontiguousarray(x, dtype=np.float32), np.float32, "row")
+
+    # -- whole-step HIP graph ------------------------------------------------------------------------
+    def compile(self, unconditional_context, context, latent, stream=None, warmup=2):
+        """Capture one denoising step for these (static) buffers into a HIP graph.  Afterwards
+        ``step(timestep, a_t, a_prev, guidance)`` updates ``latent`` in place with one graph launch."""
+        self._stream = stream or Stream()
+        self._latent, self._unc, self._ctx = latent, unconditional_context, context
+        sp = self._step_params()
+        with use_stream(self._stream):
+            self._ctx2 = self._stack_context(unconditional_context, context)
+            saved = DeviceArray.empty(latent.shape, np.float32, "row")
+            hip.tf_memcpy_async(saved.ptr, latent.ptr, latent.nbytes, 3, _sh())
+            for _ in range(warmup):                 # warms the pool and builds the lazily packed weights
+                sp.set(981.0, 0.5, 0.6, 7.5)
+                self._eager_step(sp)
+            hip.tf_memcpy_async(latent.ptr, saved.ptr, latent.nbytes, 3, _sh())
+            self._stream.synchronize()
+            pool().frozen = True
+            try:
+                hip.tf_graph_begin_capture(self._stream.handle)
+                self._eager_step(sp)
+                g = ctypes.c_void_p()
+                hip.tf_graph_end_capture(self._stream.handle, ctypes.byref(g))
+            finally:
+                pool().frozen = False
+            self._graph = g
+        return self
+
+    def _eager_step(self, sp):
+        b, c, h, w = self._latent.shape
+        x2 = DeviceArray.empty((2 * b, c, h, w), np.float16, "nhwc")
+        hip.tf_cfg_duplicate_f16(x2.ptr, self._latent.ptr, b, c, h, w, _sh())
+        out = self.model.diffusion_model(x2, sp, self._ctx2)
+        hip.tf_cfg_ddim_step_f32(self._latent.ptr, out.ptr, sp.dev.ptr, b, c, h, w, _sh())
+        self._keep = (x2, out)      # graph nodes reference these blocks: keep them out of the pool
+
+    def step(self, timestep, a_t, a_prev, guidance, eager=False):
+        sp = self._params
+        with use_stream(self._stream):
+            sp.set(timestep, a_t, a_prev, guidance)
+            if eager or self._graph is None:
+                self._eager_step(sp)
+            else:
+                hip.tf_graph_launch(self._graph, self._stream.handle)
+
+    def synchronize(self):
+        self._stream.synchronize()

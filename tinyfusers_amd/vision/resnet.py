@@ -1,0 +1,52 @@
+"""ResBlock -- mirrors tinyfusers/vision/resnet.py:6-31.  Same attribute tree (weight names), fused execution:
+GN+SiLU (2 launches) -> conv3x3 (+bias +emb) -> GN+SiLU -> conv3x3 (+bias +skip), skip = 1x1 conv or identity.
+``x`` may be the pair (x, skip) of the UNet's output path: the concat of vision/unet.py:72 is never built."""
+from ..ff.group_norm import GroupNorm
+from ..ff.linear import Linear
+from ..storage.tensor import Tensor
+from .conv2d import Conv2d
+
+
+class ResBlock:
+    def __init__(self, channels, emb_channels, out_channels, init=True):
+        self.in_layers = [
+            GroupNorm(32, channels, init=init),
+            Tensor.silu,
+            Conv2d(channels, out_channels, kernel_size=[3, 3], padding=[1, 1], init=init),
+        ]
+        self.emb_layers = [
+            Tensor.silu,
+            Linear(emb_channels, out_channels, init=init),
+        ]
+        self.out_layers = [
+            GroupNorm(32, out_channels, init=init),
+            Tensor.silu,
+            lambda x: x,  # dropout slot (vision/resnet.py:20)
+            Conv2d(out_channels, out_channels, kernel_size=[3, 3], padding=[1, 1], init=init),
+        ]
+        self.skip_connection = Conv2d(channels, out_channels, kernel_size=[1, 1], init=init) if channels != out_channels else lambda x: x
+
+    def __call__(self, x, emb, emb_out=None):
+        h = self.in_layers[0](x, silu=True)
+        if emb_out is None:
+            emb_out = self.emb_layers[1](emb, silu_input=True)         # Linear(SiLU(emb)): (rows, Cout)
+        h = self.in_layers[2](h, bias_nc=emb_out)                      # conv + bias + emb[:, :, None, None]
+        h = self.out_layers[0](h, silu=True)
+        skip = self.skip_connection(x)
+        assert not isinstance(skip, (tuple, list)), "identity skip needs a single tensor (cin == cout)"
+        return self.out_layers[3](h, residual=skip)
+
+
+class ResnetBlock:
+    """vision/resnet.py:33-45 (VAE; next-row f1)."""
+
+    def __init__(self, in_channels, out_channels=None, init=True):
+        self.norm1 = GroupNorm(32, in_channels, init=init)
+        self.conv1 = Conv2d(in_channels, out_channels, kernel_size=[3, 3], padding=[1, 1], init=init)
+        self.norm2 = GroupNorm(32, out_channels, init=init)
+        self.conv2 = Conv2d(out_channels, out_channels, kernel_size=[3, 3], padding=[1, 1], init=init)
+        self.nin_shortcut = Conv2d(in_channels, out_channels, kernel_size=[1, 1], init=init) if in_channels != out_channels else lambda x: x
+
+    def __call__(self, x):
+        h = self.conv1(self.norm1(x, silu=True))
+        return self.conv2(self.norm2(h, silu=True), residual=self.nin_shortcut(x))

@@ -1,0 +1,205 @@
+"""UNetModel / Upsample / Downsample / timestep_embedding -- mirrors tinyfusers/vision/unet.py:9-97.
+
+Same module tree and attribute names as the reference (they are the LDM checkpoint keys that update_state
+walks), generated from a channel plan so that a down-scaled graph can be built for tests; the default plan
+is exactly the SD-1.x one hard-coded in vision/unet.py:12-49.
+
+Step-level batching that the reference does not do (results unchanged):
+  * the 22 ResBlock ``emb_layers`` Linear(SiLU(emb)) run as ONE weight-streaming GEMV over a device-side
+    concatenated weight at the top of the step;
+  * the 32 cross-attention to_k / to_v projections of the context run as ONE GEMM (N = sum 2C) -- every
+    layer then reads its K|V column slice through SDPA strides;
+  * the channel concat of :72 is never materialised (GroupNorm / conv read both tensors), the nearest-2x
+    upsample of :81-83 is folded into the following conv's gather.
+"""
+from dataclasses import dataclass
+from typing import Tuple
+
+import numpy as np
+
+from ..attention.attention import SpatialTransformer, _concat_rows
+from ..ff.group_norm import GroupNorm
+from ..ff.linear import Linear, gemv_f16, linear_f16
+from ..native import hip
+from ..storage.tensor import DeviceArray, Tensor, _sh, asarray
+from .conv2d import Conv2d
+from .resnet import ResBlock
+
+
+@dataclass(frozen=True)
+class UNetConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    model_channels: int = 320
+    channel_mult: Tuple[int, ...] = (1, 2, 4, 4)
+    num_res_blocks: int = 2
+    attention_levels: Tuple[int, ...] = (0, 1, 2)
+    n_heads: int = 8
+    context_dim: int = 768
+
+
+SD15 = UNetConfig()
+TINY = UNetConfig(model_channels=64, channel_mult=(1, 2, 2), attention_levels=(0, 1), n_heads=2, context_dim=64)
+
+
+class Upsample:
+    def __init__(self, channels, init=True):
+        self.conv = Conv2d(channels, channels, kernel_size=[3, 3], padding=[1, 1], init=init)
+
+    def __call__(self, x):
+        return self.conv(x, upsample=True)       # nearest-2x (unet.py:81-83) folded into the conv gather
+
+
+class Downsample:
+    def __init__(self, channels, init=True):
+        self.op = Conv2d(channels, channels, stride=[2, 2], kernel_size=[3, 3], padding=[1, 1], init=init)
+
+    def __call__(self, x):
+        return self.op(x)
+
+
+class StepParams:
+    """Device-resident per-step scalars [timestep, a_t, a_prev, guidance] (fp32) fed by an async copy from
+    pinned host memory, so the whole step can be replayed as one HIP graph."""
+
+    def __init__(self):
+        import ctypes
+        self.dev = DeviceArray.zeros((4,), np.float32, "row")
+        p = ctypes.c_void_p()
+        hip.tf_host_alloc(ctypes.byref(p), 16)
+        self._host_ptr = p
+        self.host = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_float)), shape=(4,))
+        self.host[:] = 0
+
+    def set(self, timestep, a_t=1.0, a_prev=1.0, guidance=1.0):
+        self.host[:] = (float(timestep), float(a_t), float(a_prev), float(guidance))
+        hip.tf_memcpy_async(self.dev.ptr, self._host_ptr, 16, 1, _sh())
+        return self
+
+    def __del__(self):
+        try:
+            hip.tf_host_free(self._host_ptr)
+        except Exception:
+            pass
+
+
+def _as_params(timesteps):
+    if isinstance(timesteps, StepParams):
+        return timesteps
+    if isinstance(timesteps, DeviceArray):
+        sp = StepParams.__new__(StepParams)
+        sp.dev, sp._host_ptr = timesteps, None
+        return sp
+    t = float(np.asarray(timesteps, dtype=np.float32).reshape(-1)[0])
+    return StepParams().set(t)
+
+
+def timestep_embedding(timesteps, dim, max_period=10000):
+    """unet.py:92-97: (1, dim) = [cos(t f), sin(t f)].  timesteps: host scalar/array, or StepParams / a device
+    fp32 array whose element 0 is the timestep."""
+    sp = _as_params(timesteps)
+    out = DeviceArray.empty((1, dim), np.float16, "row")
+    hip.tf_timestep_embedding_f16(out.ptr, sp.dev.ptr, dim, float(max_period), _sh())
+    out._base = sp
+    return out
+
+
+class UNetModel:
+    def __init__(self, cfg: UNetConfig = SD15, init=False):
+        self.cfg = cfg
+        mc, emb = cfg.model_channels, cfg.model_channels * 4
+        nh, cd = cfg.n_heads, cfg.context_dim
+        R = lambda i, o: ResBlock(i, emb, o, init=init)
+        S = lambda c: SpatialTransformer(c, cd, nh, c // nh, init=init)
+        self.time_embed = [Linear(mc, emb, init=init), Tensor.silu, Linear(emb, emb, init=init)]
+        self.input_blocks = [[Conv2d(cfg.in_channels, mc, kernel_size=[3, 3], padding=[1, 1], init=init)]]
+        chans, ch, nlev = [mc], mc, len(cfg.channel_mult)
+        for lev, mult in enumerate(cfg.channel_mult):
+            for _ in range(cfg.num_res_blocks):
+                blk = [R(ch, mc * mult)]
+                ch = mc * mult
+                if lev in cfg.attention_levels:
+                    blk.append(S(ch))
+                self.input_blocks.append(blk)
+                chans.append(ch)
+            if lev != nlev - 1:
+                self.input_blocks.append([Downsample(ch, init=init)])
+                chans.append(ch)
+        self.middle_block = [R(ch, ch), S(ch), R(ch, ch)]
+        self.output_blocks = []
+        for lev in reversed(range(nlev)):
+            mult = cfg.channel_mult[lev]
+            for i in range(cfg.num_res_blocks + 1):
+                blk = [R(ch + chans.pop(), mc * mult)]
+                ch = mc * mult
+                if lev in cfg.attention_levels:
+                    blk.append(S(ch))
+                if lev > 0 and i == cfg.num_res_blocks:
+                    blk.append(Upsample(ch, init=init))
+                self.output_blocks.append(blk)
+        self.out = [GroupNorm(32, mc, init=init), Tensor.silu, Conv2d(mc, cfg.out_channels, kernel_size=[3, 3], padding=[1, 1], init=init)]
+        self._batched = None
+
+    # -- step-level batched projections (built once per weight set, on the device)
+    def _all(self, kind):
+        blocks = [bb for b in self.input_blocks for bb in b] + list(self.middle_block) + [bb for b in self.output_blocks for bb in b]
+        return [bb for bb in blocks if isinstance(bb, kind)]
+
+    def _prepare(self):
+        res, sts = self._all(ResBlock), self._all(SpatialTransformer)
+        key = tuple(r.emb_layers[1].weight.ptr for r in res) + tuple(s.transformer_blocks[0].attn2.to_k.weight.ptr for s in sts)
+        if self._batched is not None and self._batched["key"] == key:
+            return self._batched
+        emb_w = _concat_rows([r.emb_layers[1].weight for r in res])
+        emb_b = _concat_rows([r.emb_layers[1].bias.view((r.emb_layers[1].bias.size, 1)) for r in res]).view((emb_w.shape[0],))
+        emb_off, off = {}, 0
+        for r in res:
+            emb_off[id(r)] = (off, r.emb_layers[1].weight.shape[0]); off += r.emb_layers[1].weight.shape[0]
+        kv_w, kv_off, off = None, {}, 0
+        if sts:
+            ws = []
+            for s in sts:
+                a = s.transformer_blocks[0].attn2
+                ws += [a.to_k.weight, a.to_v.weight]
+                kv_off[id(s)] = off; off += 2 * a.to_k.weight.shape[0]
+            kv_w = _concat_rows(ws)
+        self._batched = dict(key=key, emb_w=emb_w, emb_b=emb_b, emb_off=emb_off, kv_w=kv_w, kv_off=kv_off, kv_n=off)
+        return self._batched
+
+    def __call__(self, x, timesteps=None, context=None):
+        cfg = self.cfg
+        bt = self._prepare()
+        t_emb = timestep_embedding(timesteps, cfg.model_channels)
+        emb = self.time_embed[2](self.time_embed[0](t_emb), silu_input=True)          # Linear -> SiLU -> Linear
+        emb_all = gemv_f16(emb, bt["emb_w"], bt["emb_b"], silu_input=True)            # every ResBlock's Linear(SiLU(emb))
+        kv_all = linear_f16(context, bt["kv_w"]) if bt["kv_w"] is not None else None  # every attn2's K|V of the context
+
+        def run(x, bb):
+            if isinstance(bb, ResBlock):
+                off, n = bt["emb_off"][id(bb)]
+                return bb(x, emb, emb_out=emb_all.view((emb_all.shape[0], n), "row", off))
+            if isinstance(bb, SpatialTransformer):
+                c = bb.proj_in.weight.shape[0]
+                return bb(x, context, kv=KVSlice(kv_all, bt["kv_off"][id(bb)], c, bt["kv_n"]))
+            return bb(x)
+
+        saved_inputs = []
+        for b in self.input_blocks:
+            for bb in b:
+                x = run(x, bb)
+            saved_inputs.append(x)
+        for bb in self.middle_block:
+            x = run(x, bb)
+        for b in self.output_blocks:
+            x = (x, saved_inputs.pop())            # channel concat (unet.py:72), consumed un-materialised
+            for bb in b:
+                x = run(x, bb)
+        return self.out[2](self.out[0](x, silu=True))
+
+
+class KVSlice:
+    """Column slice [off, off+2C) of the step-level (b, tk, kv_n) K|V projection."""
+    __slots__ = ("arr", "off", "c", "ld")
+
+    def __init__(self, arr, off, c, ld):
+        self.arr, self.off, self.c, self.ld = arr, off, c, ld
