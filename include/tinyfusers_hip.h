@@ -164,8 +164,10 @@ int tf_add_bias_colmajor_f32(void* out, const void* bias, int BT, int OC, tfStre
 int tf_transpose_f32(void* out, const void* inp, int ndim, const int* shape, const int* axes, tfStream_t s); /* transpose.cu, transpose4d.cu */
 
 /* ---- sampler pieces (vision/unet.py:92-97; variants/sd.py:14-25, :27-46) ------------------------
- * step_params (device, fp32): [0] timestep, [1] a_t, [2] a_prev, [3] guidance -- written by the host once per
- * step with tf_memcpy_async so that the whole step can live in one HIP graph. */
+ * step_params (device, fp32): [0] timestep, [1] a_t, [2] a_prev, [3] guidance -- written once per step by
+ * tf_set_step_params (values travel as kernel arguments, so there is no host buffer to race with) ahead of the
+ * replay of the step's HIP graph, whose kernels read them from device memory. */
+int tf_set_step_params(void* step_params, float timestep, float a_t, float a_prev, float guidance, tfStream_t s);
 int tf_timestep_embedding_f16(void* out, const void* step_params, int dim, float max_period, tfStream_t s);
 /* latent (B,C,H,W) f32 NCHW  ->  unet input (2B,H,W,C) f16 NHWC = [latent ; latent]  (variants/sd.py:31) */
 int tf_cfg_duplicate_f16(void* x2b_nhwc, const void* latent_nchw_f32, int B, int C, int H, int W, tfStream_t s);

@@ -226,6 +226,9 @@ __global__ void __launch_bounds__(256) k_softmax_rows(float* __restrict__ out, c
 }
 
 // ---- sampler pieces ----------------------------------------------------------------------------
+__global__ void k_set_params(float* p, float t, float a_t, float a_prev, float g) {
+  if (threadIdx.x == 0) { p[0] = t; p[1] = a_t; p[2] = a_prev; p[3] = g; }
+}
 // out (1, dim) f16 = [cos(t f_i), sin(t f_i)], f_i = exp(-ln(max_period) i / half)   (vision/unet.py:92-97)
 __global__ void k_timestep_embedding(half_t* out, const float* params, int dim, float max_period) {
   int half_dim = dim / 2;
@@ -393,6 +396,12 @@ int tf_softmax_rows_f32(void* out, const void* inp, int N, int C, tfStream_t s) 
   TF_REQUIRE(out && inp && N >= 0 && C >= 1, "tf_softmax_rows_f32: bad arguments");
   if (N == 0) return TF_OK;
   hipLaunchKernelGGL(k_softmax_rows, dim3(N), dim3(256), 0, tf_hs(s), (float*)out, (const float*)inp, C);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_set_step_params(void* step_params, float timestep, float a_t, float a_prev, float guidance, tfStream_t s) {
+  TF_REQUIRE(step_params, "tf_set_step_params: null pointer");
+  hipLaunchKernelGGL(k_set_params, dim3(1), dim3(64), 0, tf_hs(s), (float*)step_params, timestep, a_t, a_prev, guidance);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }

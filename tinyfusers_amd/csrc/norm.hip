@@ -10,42 +10,43 @@
 // partial layout: [N][chunks][G][2] fp32 (sum, sum of squares)
 __global__ void k_gn_stats(float* __restrict__ partial, const half_t* __restrict__ x, const half_t* __restrict__ x2, int HW, int C1, int C2,
                            int G, int chunks, int pix_per_chunk, int CV, int RPB) {
-  extern __shared__ float bins[];  // [G][2]
+  extern __shared__ float red[];  // [RPB*CV][16]: per-thread channel sums, then reduced in a fixed order
   int n = blockIdx.y, chunk = blockIdx.x;
   int C = C1 + C2, cpg = C / G;
   int t = threadIdx.x;
   int cv = t % CV, rr = t / CV;
-  for (int i = t; i < 2 * G; i += blockDim.x) bins[i] = 0.f;
-  __syncthreads();
   int c = cv * 8;
-  const half_t* base;
-  int ld;
-  if (c < C1) { base = x + (long long)n * HW * C1 + c; ld = C1; }
-  else { base = x2 + (long long)n * HW * C2 + (c - C1); ld = C2; }
-  float s[8], ss[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
-  int p0 = chunk * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
   if (rr < RPB) {
+    const half_t* base;
+    int ld;
+    if (c < C1) { base = x + (long long)n * HW * C1 + c; ld = C1; }
+    else { base = x2 + (long long)n * HW * C2 + (c - C1); ld = C2; }
+    float s[8], ss[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
+    int p0 = chunk * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
     for (int p = p0 + rr; p < p1; p += RPB) {
       h8 v = *reinterpret_cast<const h8*>(base + (long long)p * ld);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; ss[j] += f * f; }
     }
-    // fold this thread's 8 channels into (at most a few) group bins
-    int g = c / cpg;
-    float as = 0.f, ass = 0.f;
+    float* r = red + (long long)t * 16;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      int gj = (c + j) / cpg;
-      if (gj != g) { atomicAdd(&bins[2 * g], as); atomicAdd(&bins[2 * g + 1], ass); as = 0.f; ass = 0.f; g = gj; }
-      as += s[j]; ass += ss[j];
-    }
-    atomicAdd(&bins[2 * g], as); atomicAdd(&bins[2 * g + 1], ass);
+    for (int j = 0; j < 8; ++j) { r[j] = s[j]; r[8 + j] = ss[j]; }
   }
   __syncthreads();
+  // deterministic fold: thread g sums its group's channels over the RPB row-threads in a fixed order
   float* out = partial + ((long long)n * chunks + chunk) * G * 2;
-  for (int i = t; i < 2 * G; i += blockDim.x) out[i] = bins[i];
+  for (int g = t; g < G; g += blockDim.x) {
+    int c0 = g * cpg, c1 = c0 + cpg;
+    float S = 0.f, SS = 0.f;
+    for (int r_ = 0; r_ < RPB; ++r_)
+      for (int ch = c0; ch < c1; ++ch) {
+        const float* r = red + ((long long)r_ * CV + (ch >> 3)) * 16;
+        S += r[ch & 7]; SS += r[8 + (ch & 7)];
+      }
+    out[2 * g] = S; out[2 * g + 1] = SS;
+  }
 }
 
 // ---- GroupNorm pass 2: y = silu?((x - mean) * rstd * gamma + beta) ----------------------------------
@@ -192,7 +193,7 @@ int tf_group_norm_f16(void* y, const void* x, const void* x2, const void* gamma,
   int CV, RPB, threads, chunks, ppc;
   gn_geometry(HW, C, N, &CV, &RPB, &threads, &chunks, &ppc);
   int tl = threads < G ? G : threads;  // pass 2 needs >= G threads for the finalize
-  hipLaunchKernelGGL(k_gn_stats, dim3(chunks, N), dim3(threads), 2 * G * sizeof(float), tf_hs(s), (float*)workspace, (const half_t*)x,
+  hipLaunchKernelGGL(k_gn_stats, dim3(chunks, N), dim3(threads), (size_t)threads * 16 * sizeof(float), tf_hs(s), (float*)workspace, (const half_t*)x,
                      (const half_t*)x2, HW, C1, C2, G, chunks, ppc, CV, RPB);
   TF_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_gn_apply, dim3(chunks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,

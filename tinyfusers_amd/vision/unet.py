@@ -59,28 +59,15 @@ class Downsample:
 
 
 class StepParams:
-    """Device-resident per-step scalars [timestep, a_t, a_prev, guidance] (fp32) fed by an async copy from
-    pinned host memory, so the whole step can be replayed as one HIP graph."""
+    """Device-resident per-step scalars [timestep, a_t, a_prev, guidance] (fp32).  ``set`` is a 1-thread kernel
+    whose arguments carry the values, so it is stream-ordered with the step graph that reads them."""
 
     def __init__(self):
-        import ctypes
         self.dev = DeviceArray.zeros((4,), np.float32, "row")
-        p = ctypes.c_void_p()
-        hip.tf_host_alloc(ctypes.byref(p), 16)
-        self._host_ptr = p
-        self.host = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_float)), shape=(4,))
-        self.host[:] = 0
 
     def set(self, timestep, a_t=1.0, a_prev=1.0, guidance=1.0):
-        self.host[:] = (float(timestep), float(a_t), float(a_prev), float(guidance))
-        hip.tf_memcpy_async(self.dev.ptr, self._host_ptr, 16, 1, _sh())
+        hip.tf_set_step_params(self.dev.ptr, float(timestep), float(a_t), float(a_prev), float(guidance), _sh())
         return self
-
-    def __del__(self):
-        try:
-            hip.tf_host_free(self._host_ptr)
-        except Exception:
-            pass
 
 
 def _as_params(timesteps):
@@ -88,7 +75,7 @@ def _as_params(timesteps):
         return timesteps
     if isinstance(timesteps, DeviceArray):
         sp = StepParams.__new__(StepParams)
-        sp.dev, sp._host_ptr = timesteps, None
+        sp.dev = timesteps
         return sp
     t = float(np.asarray(timesteps, dtype=np.float32).reshape(-1)[0])
     return StepParams().set(t)
