@@ -83,6 +83,7 @@ int tf_graph_destroy(tfGraph_t g);
  * (bench.py roofline leg): enable, run eagerly, then read back accumulated ms / flops / launches. */
 int tf_prof_enable(int on);
 int tf_prof_read(double* gemm_ms, double* gemm_flops, long long* gemm_launches);
+int tf_prof_dump(const char* csv_path);   /* per-shape table: M,N,K,taps,tile,split-K,launches,ms,TFLOP/s */
 /* test / tuning hook: force the GEMM tile (bm x bn in {128,64} x {160,128,64}) and split-K; 0,0,0 = heuristic */
 int tf_gemm_force_config(int bm, int bn, int splitk);
 

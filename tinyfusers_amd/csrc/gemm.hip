@@ -10,7 +10,9 @@
 //
 // Tiling: block = 4 waves (2 x 2), block tile BM x BN, BK = 64.  Both operands are K-contiguous 128-B
 // rows, staged global -> LDS with global_load_lds_dwordx4 (LDS image lane-linear, XOR swizzle applied on
-// the per-lane SOURCE chunk and again on the ds_read_b128), two LDS stages, one barrier per K tile.
+// the per-lane SOURCE chunk and again on the ds_read_b128) into a 4-slot LDS ring: one raw s_barrier per
+// K tile and a counted s_waitcnt vmcnt(N) that leaves two tiles in flight across it (at batch 1 most shapes
+// run one block per CU, so the pipeline, not occupancy, has to hide the L2/HBM latency).
 // The weight tile is the MFMA "A" operand and the activation tile the "B" operand, so each lane ends up
 // with 4 consecutive output channels of one pixel: 8-byte stores, vector bias/residual loads.
 #include "common.h"
@@ -21,7 +23,7 @@ struct GemmP {
   const half_t* x; const half_t* x2; const half_t* w; half_t* y;
   const half_t* bias; const half_t* bias_nc; const half_t* residual; float* partial;
   long long bias_nc_stride;
-  const half_t* zeros;
+  unsigned x_bytes, x2_bytes, w_bytes;
   int M, N, K;          // N = rows of w (2x the output width for GEGLU)
   int C1, C2, C;
   int H, W, Ho, Wo, HoWo;
@@ -29,23 +31,128 @@ struct GemmP {
   int ktiles, ktiles_per_split, splitk;
   int act;              // 0 none, 1 GEGLU
   int ntm, ntn;         // tile counts
+  int dbg;              // diagnostic builds only (tools/gemm_bench.py): 1 no stores, 2 no MFMA, 4 no staging
 };
 
-__device__ __forceinline__ void glds16(const half_t* src, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+typedef __amdgpu_buffer_rsrc_t rsrc_t;   // 128-bit buffer resource
+#define TF_OOB 0x80000000u   // voffset beyond every tensor: the buffer range check returns 0 -> zero padding in LDS
+
+// LDS-DMA: 16 B per lane, LDS destination = wave-uniform base + lane*16; out-of-range lanes write zeros
+__device__ __forceinline__ void bload_lds16(rsrc_t rsrc, unsigned voffset_bytes, char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset_bytes, 0, 0, 0);
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int NSTAGE = 4;
+
+// GENERIC = false: every channel count is a multiple of 64, so a 64-wide K tile lies inside one filter tap and one
+// concat source and (tap, channel) advance as wave-uniform scalars; GENERIC = true recomputes them per lane.
+// ---- epilogue (consumer waves): write the wave's TM x TN fp32 tile through a per-wave row-major LDS scratch so
+// that global stores / residual loads are 16-B coalesced row segments instead of MFMA-layout 8-B fragments.
 template <int BM, int BN>
-__global__ void __launch_bounds__(256) k_igemm(const GemmP p) {
+__device__ __forceinline__ void igemm_epilogue(const GemmP& p, f4 (&acc)[BN / 32][BM / 32], char* smem, int m0, int n0, int split, int w4, int lane) {
   constexpr int TM = BM / 2, TN = BN / 2, MJ = TM / 16, NI = TN / 16;
-  constexpr int A_ROUNDS = BM / 32, B_ROUNDS = BN / 32;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  const int wave_m = w4 & 1, wave_n = w4 >> 1;
+  const int lr = lane & 15, lg = lane >> 4;
+  constexpr int RS = TN + 4, ROWS = TM;                   // row stride (floats) keeps the f4 writes ~conflict-free
+  float* sc = reinterpret_cast<float*>(smem) + (size_t)w4 * (ROWS * RS);
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MJ; ++j)
+      *reinterpret_cast<f4*>(sc + (j * 16 + lr) * RS + i * 16 + lg * 4) = acc[i][j];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the same wave wrote it: no barrier needed
+  const int mb = m0 + wave_m * TM;
+  const int nb = n0 + wave_n * TN;                       // first (packed) column
+  if (p.act == 1) {
+    // GEGLU: packed columns come in 16-wide blocks value|gate; out column = (n>>5)*16 + (n&15)
+    constexpr int CPR = TN / 16;                          // 8-wide output chunks per row
+    const int No = p.N >> 1;
+    for (int idx = lane; idx < ROWS * CPR; idx += 64) {
+      int row = idx / CPR, c8 = idx - row * CPR;
+      int m = mb + row;
+      int pc = 32 * (c8 >> 1) + 8 * (c8 & 1);            // packed column of the value chunk inside the wave tile
+      int n = nb + pc;
+      if (m >= p.M || n >= p.N) continue;
+      int no = (n >> 5) * 16 + (n & 15);
+      const float* r = sc + row * RS + pc;
+      f4 a0 = *reinterpret_cast<const f4*>(r), a1 = *reinterpret_cast<const f4*>(r + 4);
+      f4 g0 = *reinterpret_cast<const f4*>(r + 16), g1 = *reinterpret_cast<const f4*>(r + 20);
+      h8 ba = *reinterpret_cast<const h8*>(p.bias + n), bg = *reinterpret_cast<const h8*>(p.bias + n + 16);
+      h8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (half_t)((a0[e] + (float)ba[e]) * gelu_f(g0[e] + (float)bg[e]));
+        o[4 + e] = (half_t)((a1[e] + (float)ba[4 + e]) * gelu_f(g1[e] + (float)bg[4 + e]));
+      }
+      if (p.residual) {
+        h8 rv = *reinterpret_cast<const h8*>(p.residual + (long long)m * No + no);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rv[e]);
+      }
+      *reinterpret_cast<h8*>(p.y + (long long)m * No + no) = o;
+    }
+    return;
+  }
+  constexpr int CPR = TN / 8;
+  const bool vec = (p.N & 7) == 0;
+  float* part = p.splitk > 1 ? p.partial + (long long)split * p.M * p.N : nullptr;
+  for (int idx = lane; idx < ROWS * CPR; idx += 64) {
+    int row = idx / CPR, c8 = idx - row * CPR;
+    int m = mb + row, n = nb + c8 * 8;
+    if (m >= p.M || n >= p.N) continue;
+    const float* r = sc + row * RS + c8 * 8;
+    f4 v0 = *reinterpret_cast<const f4*>(r), v1 = *reinterpret_cast<const f4*>(r + 4);
+    const long long o = (long long)m * p.N + n;
+    if (part) {
+      if (vec) { *reinterpret_cast<f4*>(part + o) = v0; *reinterpret_cast<f4*>(part + o + 4) = v1; }
+      else { for (int e = 0; e < 8 && n + e < p.N; ++e) part[o + e] = e < 4 ? v0[e] : v1[e - 4]; }
+      continue;
+    }
+    const long long bo = p.bias_nc ? (long long)(m / p.HoWo) * p.bias_nc_stride + n : 0;
+    if (vec) {
+      if (p.bias) { h8 b = *reinterpret_cast<const h8*>(p.bias + n); for (int e = 0; e < 4; ++e) { v0[e] += (float)b[e]; v1[e] += (float)b[4 + e]; } }
+      if (p.bias_nc) { h8 b = *reinterpret_cast<const h8*>(p.bias_nc + bo); for (int e = 0; e < 4; ++e) { v0[e] += (float)b[e]; v1[e] += (float)b[4 + e]; } }
+      if (p.residual) { h8 b = *reinterpret_cast<const h8*>(p.residual + o); for (int e = 0; e < 4; ++e) { v0[e] += (float)b[e]; v1[e] += (float)b[4 + e]; } }
+      h8 out;
+      for (int e = 0; e < 4; ++e) { out[e] = (half_t)v0[e]; out[4 + e] = (half_t)v1[e]; }
+      *reinterpret_cast<h8*>(p.y + o) = out;
+    } else {
+      for (int e = 0; e < 8 && n + e < p.N; ++e) {
+        float f = e < 4 ? v0[e] : v1[e - 4];
+        if (p.bias) f += (float)p.bias[n + e];
+        if (p.bias_nc) f += (float)p.bias_nc[bo + e];
+        if (p.residual) f += (float)p.residual[o + e];
+        p.y[o + e] = (half_t)f;
+      }
+    }
+  }
+}
+
+// GENERIC = false: every channel count is a multiple of 64, so a 64-wide K tile lies inside one filter tap and one
+// concat source and (tap, channel) advance as wave-uniform scalars; GENERIC = true recomputes them per lane.
+//
+// 8 waves with split roles: waves 0-3 are CONSUMERS (2 x 2 wave tiles: ds_read_b128 fragments + MFMA), waves 4-7 are
+// LOADERS (LDS-DMA only).  One consumer and one loader share each SIMD, so the loader's LDS-DMA issue stalls (~60-100
+// cycles per 1-KiB piece) never hold up MFMA issue; a single s_barrier per K tile hands ring slots back and forth.
+template <int BM, int BN, bool GENERIC>
+__global__ void __launch_bounds__(512) k_igemm(const GemmP p) {
+  constexpr int TM = BM / 2, TN = BN / 2, MJ = TM / 16, NI = TN / 16;
+  constexpr int NG = (BM + BN) / 8;                       // 8-row staging groups: activation rows first, then weight rows
+  constexpr int LPS = NG / 4;                             // LDS-DMA pieces per loader wave per stage
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(NG % 4 == 0 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wid >= 4;
+  const int w4 = wid & 3;
   // XCD-aware tile order: blocks b and b+8 share an XCD's L2; give every XCD a contiguous run of tiles
   // (n fastest, so a run re-uses the same activation rows and sweeps the weight tiles).
   const int nblk = p.ntm * p.ntn;
@@ -60,170 +167,166 @@ __global__ void __launch_bounds__(256) k_igemm(const GemmP p) {
   const int kt_begin = split * p.ktiles_per_split;
   const int kt_end = min(p.ktiles, kt_begin + p.ktiles_per_split);
 
-  // ---- per-thread staging geometry: each glds round moves 32 rows x 128 B (8 rows per wave) -----
-  const int rir = wid * 8 + (lane >> 3);                   // row within a round
-  const int cs = (lane & 7) ^ ((rir >> 1) & 7);            // source 16-B chunk (swizzle on the source side)
-  // activation rows owned by this thread
-  int a_hi0[A_ROUNDS], a_wi0[A_ROUNDS];
-  long long a_img[A_ROUNDS];
+  if (loader) {
+    // =============================== LOADER WAVES ===============================================
+    const rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x), 0, p.x2_bytes, 0x00020000);
+    const rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    // loader wave w4 owns groups g = w4 + 4 i; lane -> row 8 g + (lane >> 3), 16-B chunk lane & 7.
+    // XOR swizzle on the SOURCE chunk (LDS image stays lane-linear): chunk ^ ((row >> 1) & 7); g = w4 (mod 4), so the
+    // swizzle term (4 (g & 1) + (sub >> 1)) & 7 is a per-thread constant.
+    const int sub = lane >> 3;
+    const int cs = (lane & 7) ^ ((4 * (w4 & 1) + (sub >> 1)) & 7);
+    int g_a[LPS], g_b[LPS], g_c[LPS];                     // A row: (hi0, wi0, pixel base); W row: (-, -, byte offset)
 #pragma unroll
-  for (int i = 0; i < A_ROUNDS; ++i) {
-    int m = m0 + i * 32 + rir;
-    if (m < p.M) {
-      int img = m / p.HoWo, rem = m - img * p.HoWo;
-      int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-      a_hi0[i] = ho * p.stride - p.pad;
-      a_wi0[i] = wo * p.stride - p.pad;
-      a_img[i] = (long long)img * p.H * p.W;
-    } else {
-      a_hi0[i] = -(1 << 28);   // always out of range -> zero page
-      a_wi0[i] = 0;
-      a_img[i] = 0;
+    for (int i = 0; i < LPS; ++i) {
+      const int row = 8 * (w4 + 4 * i) + sub;
+      g_a[i] = -(1 << 28); g_b[i] = 0; g_c[i] = (int)TF_OOB;
+      if (row < BM) {
+        int m = m0 + row;
+        if (m < p.M) {
+          int img = m / p.HoWo, rem = m - img * p.HoWo;
+          int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+          g_a[i] = ho * p.stride - p.pad;
+          g_b[i] = wo * p.stride - p.pad;
+          g_c[i] = img * p.H * p.W;
+        }
+      } else {
+        int n = n0 + row - BM;
+        if (n < p.N) g_c[i] = (int)((unsigned)(n * p.K + cs * 8) * 2u);
+      }
     }
+    const int Hl = p.H << p.ups, Wl = p.W << p.ups;        // logical (post-upsample) input extent
+    int st_r, st_s, st_c;                                  // wave-uniform (tap, channel) of the next tile to stage
+    {
+      int kg0 = kt_begin * 64;
+      int tap = kg0 / p.C;
+      st_c = kg0 - tap * p.C;
+      st_r = tap / p.S;
+      st_s = tap - st_r * p.S;
+    }
+    auto stage = [&](int buf, int kt) {
+      if (p.dbg & 4) return;
+      char* base = smem + buf * STAGE;
+      int r, s_, cc, ld;
+      bool kvalid = true, second;
+      if (GENERIC) {
+        int kg = kt * 64 + cs * 8;
+        int tap = kg / p.C;
+        int c = kg - tap * p.C;
+        r = tap / p.S; s_ = tap - r * p.S;
+        kvalid = kg < p.K;
+        second = c >= p.C1;
+        ld = second ? p.C2 : p.C1;
+        cc = second ? c - p.C1 : c;
+      } else {
+        r = st_r; s_ = st_s;                               // all wave-uniform (SGPR)
+        second = st_c >= p.C1;
+        ld = second ? p.C2 : p.C1;
+        cc = (second ? st_c - p.C1 : st_c) + cs * 8;
+        st_c += 64;
+        if (st_c >= p.C) { st_c = 0; if (++st_s == p.S) { st_s = 0; ++st_r; } }
+      }
+      const unsigned kb = (unsigned)kt * 128u;
+#pragma unroll
+      for (int i = 0; i < LPS; ++i) {
+        const int g = w4 + 4 * i;                          // wave-uniform
+        char* dst = base + g * 1024;
+        if (g * 8 < BM) {
+          int hi = g_a[i] + r, wi = g_b[i] + s_;
+          bool ok = kvalid && (unsigned)hi < (unsigned)Hl && (unsigned)wi < (unsigned)Wl;
+          int pix = g_c[i] + (hi >> p.ups) * p.W + (wi >> p.ups);
+          unsigned off = ok ? (unsigned)(pix * ld + cc) * 2u : TF_OOB;
+          if (GENERIC) {
+            if (second) bload_lds16(rs_x2, off, dst); else bload_lds16(rs_x, off, dst);
+          } else {
+            bload_lds16(second ? rs_x2 : rs_x, off, dst);
+          }
+        } else {
+          unsigned wo = (unsigned)g_c[i];
+          unsigned off = (kvalid && wo != TF_OOB) ? wo + kb : TF_OOB;
+          bload_lds16(rs_w, off, dst);
+        }
+      }
+    };
+    static_assert(NSTAGE == 4, "wait ladder below is written for a 4-slot ring");
+#pragma unroll
+    for (int s_ = 0; s_ < NSTAGE - 1; ++s_)
+      if (kt_begin + s_ < kt_end) stage(s_, kt_begin + s_);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int it = kt - kt_begin;
+      const int newer = kt_end - 1 - kt;                   // tiles issued after tile kt
+      if (newer >= 2) wait_vm<2 * LPS>();
+      else if (newer == 1) wait_vm<LPS>();
+      else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();                       // tile kt handed to the consumers; slot (it-1)%4 handed back
+      asm volatile("" ::: "memory");
+      if (kt + NSTAGE - 1 < kt_end) stage((it + NSTAGE - 1) % NSTAGE, kt + NSTAGE - 1);
+    }
+    __builtin_amdgcn_s_barrier();                         // matches the consumers' "ring is free" barrier
+    return;
   }
-  const int Hl = p.H << p.ups, Wl = p.W << p.ups;   // logical (post-upsample) input extent
 
-  auto stage = [&](int buf, int kt) {
-    char* base = smem + buf * STAGE;
-    int kg = kt * 64 + cs * 8;              // this thread's K position (same for all rounds)
-    // ---- activations
-    int tap = kg / p.C, c = kg - tap * p.C;
-    int r = tap / p.S, s = tap - r * p.S;
-    const half_t* xs; int ld;
-    if (c < p.C1) { xs = p.x + c; ld = p.C1; } else { xs = p.x2 + (c - p.C1); ld = p.C2; }
-    bool kvalid = kg < p.K;
-#pragma unroll
-    for (int i = 0; i < A_ROUNDS; ++i) {
-      int hi = a_hi0[i] + r, wi = a_wi0[i] + s;
-      bool ok = kvalid && hi >= 0 && hi < Hl && wi >= 0 && wi < Wl;
-      const half_t* src = ok ? xs + (a_img[i] + (long long)(hi >> p.ups) * p.W + (wi >> p.ups)) * ld : p.zeros;
-      glds16(src, base + (i * 32 + wid * 8) * 128);
-    }
-    // ---- weights
-#pragma unroll
-    for (int i = 0; i < B_ROUNDS; ++i) {
-      int n = n0 + i * 32 + rir;
-      const half_t* src = (kvalid && n < p.N) ? p.w + (long long)n * p.K + kg : p.zeros;
-      glds16(src, base + A_BYTES + (i * 32 + wid * 8) * 128);
-    }
-  };
-
-  const int wave_m = wid & 1, wave_n = wid >> 1;
+  // ================================= CONSUMER WAVES ===============================================
+  const int wave_m = w4 & 1, wave_n = w4 >> 1;
   const int lr = lane & 15, lg = lane >> 4;
   f4 acc[NI][MJ];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < MJ; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
-
-  if (kt_begin < kt_end) stage(0, kt_begin);
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int buf = (kt - kt_begin) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < kt_end) stage(buf ^ 1, kt + 1);
-    const char* sa = smem + buf * STAGE;             // activation rows
-    const char* sb = sa + A_BYTES;                   // weight rows
+  // fragment addresses inside a stage (swizzled chunk for k-step 0; k-step 1 is chunk ^ 4)
+  int wa[NI], xa[MJ];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      h8 wf[NI], xf[MJ];
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        int row = wave_n * TN + i * 16 + lr;
-        int ch = (ks * 4 + lg) ^ ((row >> 1) & 7);
-        wf[i] = *reinterpret_cast<const h8*>(sb + row * 128 + ch * 16);
-      }
-#pragma unroll
-      for (int j = 0; j < MJ; ++j) {
-        int row = wave_m * TM + j * 16 + lr;
-        int ch = (ks * 4 + lg) ^ ((row >> 1) & 7);
-        xf[j] = *reinterpret_cast<const h8*>(sa + row * 128 + ch * 16);
-      }
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    }
-  }
-
-  // ---- epilogue: lane holds n = nb + 4*lg + {0..3} for pixel m = mb + lr --------------------------
-  if (p.splitk > 1) {
-    float* part = p.partial + (long long)split * p.M * p.N;
-#pragma unroll
-    for (int j = 0; j < MJ; ++j) {
-      int m = m0 + wave_m * TM + j * 16 + lr;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        int n = n0 + wave_n * TN + i * 16 + lg * 4;
-        if (n + 3 < p.N && (p.N & 3) == 0) {
-          *reinterpret_cast<f4*>(part + (long long)m * p.N + n) = acc[i][j];
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (n + e < p.N) part[(long long)m * p.N + n + e] = acc[i][j][e];
-        }
-      }
-    }
-    return;
-  }
-  if (p.act == 1) {
-    // GEGLU: w rows come in 16-row blocks alternating value / gate, so acc[2i] / acc[2i+1] pair up per lane
-    const int No = p.N >> 1;
-#pragma unroll
-    for (int j = 0; j < MJ; ++j) {
-      int m = m0 + wave_m * TM + j * 16 + lr;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int i = 0; i + 1 < NI; i += 2) {
-        int n = n0 + wave_n * TN + i * 16 + lg * 4;    // packed row index of the value block
-        if (n >= p.N) continue;
-        int no = (n >> 5) * 16 + (n & 15);              // output column
-        h4 ba = *reinterpret_cast<const h4*>(p.bias + n), bg = *reinterpret_cast<const h4*>(p.bias + n + 16);
-        h4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float a = acc[i][j][e] + (float)ba[e], g = acc[i + 1][j][e] + (float)bg[e];
-          o[e] = (half_t)(a * gelu_f(g));
-        }
-        if (p.residual) {
-          h4 rv = *reinterpret_cast<const h4*>(p.residual + (long long)m * No + no);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (half_t)((float)o[e] + (float)rv[e]);
-        }
-        *reinterpret_cast<h4*>(p.y + (long long)m * No + no) = o;
-      }
-    }
-    return;
+  for (int i = 0; i < NI; ++i) {
+    int row = wave_n * TN + i * 16 + lr;
+    wa[i] = BM * 128 + row * 128 + ((lg ^ ((row >> 1) & 7)) << 4);
   }
 #pragma unroll
   for (int j = 0; j < MJ; ++j) {
-    int m = m0 + wave_m * TM + j * 16 + lr;
-    if (m >= p.M) continue;
-    int img = p.bias_nc ? m / p.HoWo : 0;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      int n = n0 + wave_n * TN + i * 16 + lg * 4;
-      if (n >= p.N) continue;
-      f4 v = acc[i][j];
-      if (n + 3 < p.N && (p.N & 3) == 0) {
-        if (p.bias) { h4 b = *reinterpret_cast<const h4*>(p.bias + n); for (int e = 0; e < 4; ++e) v[e] += (float)b[e]; }
-        if (p.bias_nc) { h4 b = *reinterpret_cast<const h4*>(p.bias_nc + (long long)img * p.bias_nc_stride + n); for (int e = 0; e < 4; ++e) v[e] += (float)b[e]; }
-        if (p.residual) { h4 b = *reinterpret_cast<const h4*>(p.residual + (long long)m * p.N + n); for (int e = 0; e < 4; ++e) v[e] += (float)b[e]; }
-        h4 o;
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-        *reinterpret_cast<h4*>(p.y + (long long)m * p.N + n) = o;
-      } else {
-        for (int e = 0; e < 4; ++e) {
-          if (n + e >= p.N) break;
-          float f = v[e];
-          if (p.bias) f += (float)p.bias[n + e];
-          if (p.bias_nc) f += (float)p.bias_nc[(long long)img * p.bias_nc_stride + n + e];
-          if (p.residual) f += (float)p.residual[(long long)m * p.N + n + e];
-          p.y[(long long)m * p.N + n + e] = (half_t)f;
-        }
-      }
-    }
+    int row = wave_m * TM + j * 16 + lr;
+    xa[j] = row * 128 + ((lg ^ ((row >> 1) & 7)) << 4);
   }
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) % NSTAGE;
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* sb = smem + buf * STAGE;
+    h8 wf0[NI], xf0[MJ], wf1[NI], xf1[MJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wf0[i] = *reinterpret_cast<const h8*>(sb + wa[i]);
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) xf0[j] = *reinterpret_cast<const h8*>(sb + xa[j]);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wf1[i] = *reinterpret_cast<const h8*>(sb + (wa[i] ^ 64));
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) xf1[j] = *reinterpret_cast<const h8*>(sb + (xa[j] ^ 64));
+    if (p.dbg & 2) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) { asm volatile("" ::"v"(wf0[i])); asm volatile("" ::"v"(wf1[i])); }
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) { asm volatile("" ::"v"(xf0[j])); asm volatile("" ::"v"(xf1[j])); }
+      continue;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[i], xf0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[i], xf1[j], acc[i][j], 0, 0, 0);
+  }
+  __builtin_amdgcn_s_barrier();                           // every consumer is done with the ring: reuse it for the epilogue
+  asm volatile("" ::: "memory");
+  if (p.dbg & 1) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
+  igemm_epilogue<BM, BN>(p, acc, smem, m0, n0, split, w4, lane);
 }
 
 // split-K reduce + epilogue: y[m,n] = sum_z partial[z,m,n] + bias + bias_nc + residual   (N % 4 == 0 fast path)
@@ -297,27 +400,25 @@ __global__ void __launch_bounds__(256) k_gemv(half_t* __restrict__ y, const half
 }
 
 // ------------------------------------------------------------------------------------------------
-static half_t* g_zeros = nullptr;
-static int ensure_zeros() {
-  if (g_zeros) return TF_OK;
-  TF_HIP(hipMalloc((void**)&g_zeros, 4096));
-  TF_HIP(hipMemset(g_zeros, 0, 4096));
-  return TF_OK;
-}
-
 // per-launch event profiling of this kernel family (bench.py roofline leg)
 static bool g_prof = false;
 static double g_prof_ms = 0.0, g_prof_flops = 0.0;
 static long long g_prof_launches = 0;
-struct ProfRec { hipEvent_t a, b; double flops; };
+struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, taps, bm, bn, splitk; };
+#include <map>
+#include <array>
+static std::map<std::array<int, 7>, std::pair<long long, double>> g_prof_shapes;
 static std::vector<ProfRec> g_prof_pending;
 
+static int g_dbg = 0;
 struct TileCfg { int bm, bn, splitk; };
 
+// Cost model (microseconds) calibrated on MI355X with tools/gemm_bench.py: a K tile costs the larger of its LDS-DMA
+// ingest time ((bm+bn)*128 B at ~90 GB/s per CU) and its MFMA time (~7 TFLOP/s per CU sustained), one block per CU per
+// wave of blocks; split-K adds a reduce launch and an fp32 round trip of the output.
 static TileCfg choose_tiles(int M, int N, int K, int act, bool allow_split) {
   static const int cand[][2] = {{128, 160}, {64, 160}, {128, 128}, {64, 128}, {128, 64}, {64, 64}};
   const int ncand = 6;
-  const double CUS = 256.0;
   int ktiles = (K + 63) / 64;
   TileCfg best = {64, 64, 1};
   double best_t = 1e30;
@@ -326,41 +427,41 @@ static TileCfg choose_tiles(int M, int N, int K, int act, bool allow_split) {
     if (act == 1 && (bn % 64) != 0) continue;           // GEGLU pairs 16-row blocks inside a wave tile
     int ntm = (M + bm - 1) / bm, ntn = (N + bn - 1) / bn;
     double tiles = (double)ntm * ntn;
-    // relative MFMA efficiency of the tile shape (LDS bytes per MFMA) -- refined from measurements
-    double eff = (bm == 128 ? 1.0 : 0.82) * (bn >= 128 ? 1.0 : 0.8);
+    double t_ing = (bm + bn) * 128.0 / 90e3, t_mfma = (double)bm * bn * 128.0 / 7.0e6;
+    double t_tile = (t_ing > t_mfma ? t_ing : t_mfma) + 0.05;
     int max_split = (allow_split && act == 0) ? 32 : 1;
     for (int sk = 1; sk <= max_split; sk *= 2) {
-      if (sk > 1 && ktiles / sk < 4) break;
+      if (sk > 1 && ktiles / sk < 8) break;
       double blocks = tiles * sk;
-      double waves = ceil(blocks / CUS);
-      double per_block = (double)bm * bn * ((ktiles + sk - 1) / sk) * 64.0 / eff;
-      double t = waves * per_block;
-      // padding waste is already in bm*bn; split-K pays an fp32 round trip of the output
-      if (sk > 1) t += (double)M * N * (sk + 1) * 4.0 * 40.0 / CUS;   // ~bytes -> mfma-equivalent cost units
-      t += 3.0e4 * 64.0;                                              // fixed per-launch latency
+      double waves = ceil(blocks / 256.0);
+      double t = 3.0 + waves * ((ktiles + sk - 1) / sk) * t_tile;
+      if (sk > 1) t += 4.0 + (double)M * N * 4.0 * (sk + 1) / 3.0e6;
       if (t < best_t) { best_t = t; best = {bm, bn, sk}; }
     }
   }
   return best;
 }
 
-template <int BM, int BN>
-static int launch_cfg(const GemmP& p, hipStream_t st) {
-  constexpr int smem = 2 * (BM + BN) * 128;
+template <int BM, int BN, bool GENERIC>
+static int launch_cfg2(const GemmP& p, hipStream_t st) {
+  constexpr int smem = NSTAGE * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    TF_HIP(hipFuncSetAttribute((const void*)k_igemm<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    TF_HIP(hipFuncSetAttribute((const void*)k_igemm<BM, BN, GENERIC>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_igemm<BM, BN>), dim3(p.ntm * p.ntn, p.splitk), dim3(256), smem, st, p);
+  hipLaunchKernelGGL((k_igemm<BM, BN, GENERIC>), dim3(p.ntm * p.ntn, p.splitk), dim3(512), smem, st, p);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
+template <int BM, int BN>
+static int launch_cfg(const GemmP& p, hipStream_t st) {
+  bool generic = (p.C1 % 64) != 0 || (p.C2 % 64) != 0;
+  return generic ? launch_cfg2<BM, BN, true>(p, st) : launch_cfg2<BM, BN, false>(p, st);
+}
 
 static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_bm, int force_bn, int force_split, hipStream_t st) {
-  int rc = ensure_zeros();
-  if (rc) return rc;
-  p.zeros = g_zeros;
+  int rc = 0;
   p.ktiles = (p.K + 63) / 64;
   TileCfg c = choose_tiles(p.M, p.N, p.K, p.act, true);
   if (force_bm) { c.bm = force_bm; c.bn = force_bn; c.splitk = force_split > 0 ? force_split : 1; }
@@ -372,12 +473,14 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
   p.ktiles_per_split = (p.ktiles + c.splitk - 1) / c.splitk;
   p.splitk = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
   p.partial = (float*)workspace;
+  p.dbg = g_dbg;
   p.ntm = (p.M + c.bm - 1) / c.bm;
   p.ntn = (p.N + c.bn - 1) / c.bn;
   ProfRec rec;
   if (g_prof) {
     TF_HIP(hipEventCreate(&rec.a)); TF_HIP(hipEventCreate(&rec.b));
-    rec.flops = 2.0 * p.M * (double)(p.act == 1 ? p.N : p.N) * p.K;
+    rec.flops = 2.0 * p.M * (double)p.N * p.K;
+    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.taps = p.K / p.C; rec.bm = c.bm; rec.bn = c.bn; rec.splitk = p.splitk;
     TF_HIP(hipEventRecord(rec.a, st));
   }
   if (c.bm == 128 && c.bn == 160) rc = launch_cfg<128, 160>(p, st);
@@ -411,11 +514,12 @@ static int g_force_bm = 0, g_force_bn = 0, g_force_split = 0;
 
 extern "C" {
 
+int tf_gemm_debug(int flags) { g_dbg = flags; return TF_OK; }
 int tf_gemm_force_config(int bm, int bn, int splitk) { g_force_bm = bm; g_force_bn = bn; g_force_split = splitk; return TF_OK; }
 
 int tf_prof_enable(int on) {
   g_prof = on != 0;
-  if (on) { g_prof_ms = 0.0; g_prof_flops = 0.0; g_prof_launches = 0; g_prof_pending.clear(); }
+  if (on) { g_prof_ms = 0.0; g_prof_flops = 0.0; g_prof_launches = 0; g_prof_pending.clear(); g_prof_shapes.clear(); }
   return TF_OK;
 }
 int tf_prof_read(double* ms, double* flops, long long* launches) {
@@ -424,12 +528,31 @@ int tf_prof_read(double* ms, double* flops, long long* launches) {
     TF_HIP(hipEventSynchronize(r.b));
     TF_HIP(hipEventElapsedTime(&t, r.a, r.b));
     g_prof_ms += t; g_prof_flops += r.flops; g_prof_launches += 1;
+    auto& e = g_prof_shapes[{r.M, r.N, r.K, r.taps, r.bm, r.bn, r.splitk}];
+    e.first += 1; e.second += t;
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
   g_prof_pending.clear();
   if (ms) *ms = g_prof_ms;
   if (flops) *flops = g_prof_flops;
   if (launches) *launches = g_prof_launches;
+  return TF_OK;
+}
+
+int tf_prof_dump(const char* path) {
+  TF_REQUIRE(path, "tf_prof_dump: null path");
+  int rc = tf_prof_read(nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  FILE* f = fopen(path, "w");
+  TF_REQUIRE(f, "tf_prof_dump: cannot open %s", path);
+  fprintf(f, "M,N,K,taps,bm,bn,splitk,launches,total_ms,avg_us,tflops\n");
+  for (auto& kv : g_prof_shapes) {
+    const auto& k = kv.first;
+    double ms = kv.second.second; long long n = kv.second.first;
+    double tf = 2.0 * k[0] * (double)k[1] * k[2] * n / (ms * 1e-3) / 1e12;
+    fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%lld,%.4f,%.2f,%.1f\n", k[0], k[1], k[2], k[3], k[4], k[5], k[6], n, ms, ms * 1e3 / n, tf);
+  }
+  fclose(f);
   return TF_OK;
 }
 
@@ -464,6 +587,11 @@ int tf_conv2d_f16(void* y, const void* x, const void* x2, const void* w, const v
   TF_REQUIRE(bias_nc_stride % 4 == 0 || Cout % 4 != 0, "tf_conv2d_f16: bias_nc_stride must be a multiple of 4");
   p.M = N * Ho * Wo; p.N = Cout; p.C1 = C1; p.C2 = C2; p.C = C1 + C2; p.K = R * S * p.C;
   p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.HoWo = Ho * Wo; p.S = S; p.stride = stride; p.pad = pad; p.ups = ups; p.act = 0;
+  {
+    long long xb = (long long)N * H * W * C1 * 2, x2b = (long long)N * H * W * C2 * 2, wb = (long long)Cout * p.K * 2;
+    TF_REQUIRE(xb < (1LL << 31) && x2b < (1LL << 31) && wb < (1LL << 31), "tf_conv2d_f16: tensors must be < 2 GiB each");
+    p.x_bytes = (unsigned)xb; p.x2_bytes = C2 ? (unsigned)x2b : (unsigned)xb; p.w_bytes = (unsigned)wb;
+  }
   return run_gemm(p, workspace, workspace_bytes, g_force_bm, g_force_bn, g_force_split, tf_hs(s));
 }
 
@@ -480,6 +608,11 @@ int tf_linear_f16(void* y, const void* x, const void* w, const void* bias, const
   p.x = (const half_t*)x; p.w = (const half_t*)w; p.y = (half_t*)y; p.bias = (const half_t*)bias; p.residual = (const half_t*)residual;
   p.M = M; p.N = act == 1 ? 2 * N : N; p.K = K; p.C1 = K; p.C2 = 0; p.C = K;
   p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.HoWo = M; p.S = 1; p.stride = 1; p.pad = 0; p.ups = 0; p.act = act;
+  {
+    long long xb = (long long)M * K * 2, wb = (long long)p.N * K * 2;
+    TF_REQUIRE(xb < (1LL << 31) && wb < (1LL << 31), "tf_linear_f16: tensors must be < 2 GiB each");
+    p.x_bytes = (unsigned)xb; p.x2_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+  }
   return run_gemm(p, workspace, workspace_bytes, g_force_bm, g_force_bn, g_force_split, tf_hs(s));
 }
 

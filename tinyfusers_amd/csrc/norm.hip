@@ -3,7 +3,7 @@
 #include "common.h"
 #include "../../include/tinyfusers_hip.h"
 
-#define GN_MAX_CHUNKS 64
+#define GN_MAX_CHUNKS 128
 
 // ---- GroupNorm pass 1: per-(image, pixel-chunk) partial sums per group ---------------------------
 // block = CV * RPB threads (CV = C/8 channel vectors, RPB rows per sweep); thread owns one channel vector.
@@ -49,29 +49,34 @@ __global__ void k_gn_stats(float* __restrict__ partial, const half_t* __restrict
   }
 }
 
-// ---- GroupNorm pass 2: y = silu?((x - mean) * rstd * gamma + beta) ----------------------------------
-__global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ x2, const half_t* __restrict__ gamma,
-                           const half_t* __restrict__ beta, const float* __restrict__ partial, int HW, int C1, int C2, int G, float eps,
-                           int do_silu, int chunks, int pix_per_block, int CV, int RPB) {
-  extern __shared__ float stat[];  // [G][2] : mean, rstd
-  int n = blockIdx.y;
-  int C = C1 + C2, cpg = C / G;
-  int t = threadIdx.x;
-  if (t < G) {
+// ---- GroupNorm pass 2: fold the per-chunk partials into (mean, rstd) per (image, group): one block per image
+__global__ void __launch_bounds__(256) k_gn_finalize(float* __restrict__ stats, const float* __restrict__ partial, int HW, int cpg, int G, int chunks,
+                                                     float eps) {
+  int n = blockIdx.x;
+  for (int g = threadIdx.x; g < G; g += 256) {
     double S = 0.0, SS = 0.0;
-    const float* p = partial + (long long)n * chunks * G * 2 + t * 2;
+    const float* p = partial + (long long)n * chunks * G * 2 + g * 2;
     for (int k = 0; k < chunks; ++k) { S += (double)p[(long long)k * G * 2]; SS += (double)p[(long long)k * G * 2 + 1]; }
     double cnt = (double)HW * cpg;
     double mean = S / cnt;
     double var = SS / cnt - mean * mean;
     if (var < 0.0) var = 0.0;
-    stat[2 * t] = (float)mean;
-    stat[2 * t + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    stats[((long long)n * G + g) * 2] = (float)mean;
+    stats[((long long)n * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
-  __syncthreads();
+}
+
+// ---- GroupNorm pass 3: y = silu?((x - mean) * rstd * gamma + beta); many small blocks (latency-bound otherwise)
+__global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ x2, const half_t* __restrict__ gamma,
+                           const half_t* __restrict__ beta, const float* __restrict__ stats, int HW, int C1, int C2, int G, int do_silu,
+                           int pix_per_block, int CV, int RPB) {
+  int n = blockIdx.y;
+  int C = C1 + C2, cpg = C / G;
+  int t = threadIdx.x;
   int cv = t % CV, rr = t / CV;
   if (rr >= RPB) return;
   int c = cv * 8;
+  const float* st = stats + (long long)n * G * 2;
   float a[8], b[8];
   {
     h8 gm, bt;
@@ -79,7 +84,7 @@ __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x,
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       int g = (c + j) / cpg;
-      float mean = stat[2 * g], rstd = stat[2 * g + 1];
+      float mean = st[2 * g], rstd = st[2 * g + 1];
       float gmj = gamma ? (float)gm[j] : 1.0f, btj = gamma ? (float)bt[j] : 0.0f;
       a[j] = rstd * gmj;
       b[j] = btj - mean * a[j];
@@ -91,14 +96,19 @@ __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x,
   else { base = x2 + (long long)n * HW * C2 + (c - C1); ld = C2; }
   half_t* yo = y + (long long)n * HW * C + c;
   int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
-  for (int p = p0 + rr; p < p1; p += RPB) {
-    h8 v = *reinterpret_cast<const h8*>(base + (long long)p * ld), o;
+  for (int p = p0 + rr; p < p1; p += 2 * RPB) {          // two independent loads in flight per thread
+    int q = p + RPB;
+    h8 v0 = *reinterpret_cast<const h8*>(base + (long long)p * ld), v1;
+    if (q < p1) v1 = *reinterpret_cast<const h8*>(base + (long long)q * ld);
+    h8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float f = (float)v[j] * a[j] + b[j];
-      o[j] = (half_t)(do_silu ? silu_f(f) : f);
-    }
+    for (int j = 0; j < 8; ++j) { float f = (float)v0[j] * a[j] + b[j]; o[j] = (half_t)(do_silu ? silu_f(f) : f); }
     *reinterpret_cast<h8*>(yo + (long long)p * C) = o;
+    if (q < p1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float f = (float)v1[j] * a[j] + b[j]; o[j] = (half_t)(do_silu ? silu_f(f) : f); }
+      *reinterpret_cast<h8*>(yo + (long long)q * C) = o;
+    }
   }
 }
 
@@ -154,27 +164,26 @@ __global__ void __launch_bounds__(256) k_layer_norm(half_t* __restrict__ y, cons
   }
 }
 
-static void gn_geometry(int HW, int C, int N, int* CV, int* RPB, int* threads, int* chunks, int* ppc) {
+static void gn_geometry(int HW, int C, int N, int* CV, int* RPB, int* threads, int* chunks, int* ppc, int* ablocks, int* appb) {
   *CV = C / 8;
   *RPB = *CV >= 256 ? 1 : 256 / *CV;
   if (*RPB > HW) *RPB = HW > 0 ? HW : 1;
   *threads = *CV * *RPB;
-  int want = (512 + N - 1) / (N > 0 ? N : 1);          // ~2 blocks per CU over the whole launch
-  if (want > GN_MAX_CHUNKS) want = GN_MAX_CHUNKS;
-  int maxc = (HW + *RPB - 1) / *RPB;
-  if (want > maxc) want = maxc;
-  if (want < 1) want = 1;
-  int p = (HW + want - 1) / want;
-  p = ((p + *RPB - 1) / *RPB) * *RPB;
-  *ppc = p;
-  *chunks = (HW + p - 1) / p;
+  // stats: a thread sums ~8 pixels (enough loads in flight to hide latency); <= GN_MAX_CHUNKS chunks per image
+  int p = *RPB * 8;
+  int c = (HW + p - 1) / p;
+  if (c > GN_MAX_CHUNKS) { c = GN_MAX_CHUNKS; p = (HW + c - 1) / c; p = ((p + *RPB - 1) / *RPB) * *RPB; c = (HW + p - 1) / p; }
+  *ppc = p; *chunks = c;
+  // apply: 4 pixels per thread
+  int q = *RPB * 4;
+  *appb = q; *ablocks = (HW + q - 1) / q;
 }
 
 extern "C" {
 
 size_t tf_group_norm_workspace(int N, int HW, int C, int G) {
   (void)HW; (void)C;
-  return (size_t)N * GN_MAX_CHUNKS * G * 2 * sizeof(float);
+  return (size_t)N * (GN_MAX_CHUNKS + 1) * G * 2 * sizeof(float);   // per-chunk partials + the (mean, rstd) table
 }
 
 int tf_group_norm_f16(void* y, const void* x, const void* x2, const void* gamma, const void* beta, int N, int HW, int C1, int C2, int G,
@@ -190,14 +199,17 @@ int tf_group_norm_f16(void* y, const void* x, const void* x2, const void* gamma,
     tf_set_error("tf_group_norm_f16: workspace %zu B < required %zu B", workspace_bytes, tf_group_norm_workspace(N, HW, C, G));
     return TF_E_WORKSPACE;
   }
-  int CV, RPB, threads, chunks, ppc;
-  gn_geometry(HW, C, N, &CV, &RPB, &threads, &chunks, &ppc);
-  int tl = threads < G ? G : threads;  // pass 2 needs >= G threads for the finalize
-  hipLaunchKernelGGL(k_gn_stats, dim3(chunks, N), dim3(threads), (size_t)threads * 16 * sizeof(float), tf_hs(s), (float*)workspace, (const half_t*)x,
+  int CV, RPB, threads, chunks, ppc, ablocks, appb;
+  gn_geometry(HW, C, N, &CV, &RPB, &threads, &chunks, &ppc, &ablocks, &appb);
+  float* partial = (float*)workspace;
+  float* stats = partial + (size_t)N * GN_MAX_CHUNKS * G * 2;
+  hipLaunchKernelGGL(k_gn_stats, dim3(chunks, N), dim3(threads), (size_t)threads * 16 * sizeof(float), tf_hs(s), partial, (const half_t*)x,
                      (const half_t*)x2, HW, C1, C2, G, chunks, ppc, CV, RPB);
   TF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_gn_apply, dim3(chunks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
-                     (const half_t*)gamma, (const half_t*)beta, (const float*)workspace, HW, C1, C2, G, eps, silu, chunks, ppc, CV, RPB);
+  hipLaunchKernelGGL(k_gn_finalize, dim3(N), dim3(256), 0, tf_hs(s), stats, (const float*)partial, HW, C / G, G, chunks, eps);
+  TF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(threads), 0, tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
+                     (const half_t*)gamma, (const half_t*)beta, (const float*)stats, HW, C1, C2, G, silu, appb, CV, RPB);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
