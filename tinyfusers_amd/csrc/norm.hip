@@ -25,10 +25,17 @@ __global__ void k_gn_stats(float* __restrict__ partial, const half_t* __restrict
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
     int p0 = chunk * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
-    for (int p = p0 + rr; p < p1; p += RPB) {
-      h8 v = *reinterpret_cast<const h8*>(base + (long long)p * ld);
+    for (int p = p0 + rr; p < p1; p += 4 * RPB) {          // four independent loads in flight per thread
+      h8 v[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; ss[j] += f * f; }
+      for (int u = 0; u < 4; ++u) {
+        int q = p + u * RPB;
+        v[u] = q < p1 ? *reinterpret_cast<const h8*>(base + (long long)q * ld) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { float f = (float)v[u][j]; s[j] += f; ss[j] += f * f; }
     }
     float* r = red + (long long)t * 16;
 #pragma unroll
@@ -49,20 +56,28 @@ __global__ void k_gn_stats(float* __restrict__ partial, const half_t* __restrict
   }
 }
 
-// ---- GroupNorm pass 2: fold the per-chunk partials into (mean, rstd) per (image, group): one block per image
+// ---- GroupNorm pass 2: fold the per-chunk partials into (mean, rstd) per (image, group): one block per image,
+// 8 lanes per group (strided over the chunks, then three xor-shuffles), fixed summation order.
 __global__ void __launch_bounds__(256) k_gn_finalize(float* __restrict__ stats, const float* __restrict__ partial, int HW, int cpg, int G, int chunks,
                                                      float eps) {
   int n = blockIdx.x;
-  for (int g = threadIdx.x; g < G; g += 256) {
+  int sub = threadIdx.x & 7;
+  for (int g = threadIdx.x >> 3; g < ((G + 31) & ~31); g += 32) {
     double S = 0.0, SS = 0.0;
-    const float* p = partial + (long long)n * chunks * G * 2 + g * 2;
-    for (int k = 0; k < chunks; ++k) { S += (double)p[(long long)k * G * 2]; SS += (double)p[(long long)k * G * 2 + 1]; }
-    double cnt = (double)HW * cpg;
-    double mean = S / cnt;
-    double var = SS / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[((long long)n * G + g) * 2] = (float)mean;
-    stats[((long long)n * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (g < G) {
+      const float* p = partial + (long long)n * chunks * G * 2 + g * 2;
+      for (int k = sub; k < chunks; k += 8) { S += (double)p[(long long)k * G * 2]; SS += (double)p[(long long)k * G * 2 + 1]; }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { S += __shfl_xor(S, o, 64); SS += __shfl_xor(SS, o, 64); }
+    if (g < G && sub == 0) {
+      double cnt = (double)HW * cpg;
+      double mean = S / cnt;
+      double var = SS / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      stats[((long long)n * G + g) * 2] = (float)mean;
+      stats[((long long)n * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
   }
 }
 

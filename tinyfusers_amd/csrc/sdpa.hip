@@ -72,16 +72,31 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
     ntiles = min(ntiles, last_q / 64 + 1);
   }
 
+  // K/V tiles: raw buffer loads with 32-bit offsets; rows >= Tk and padding columns fall outside the range check
+  // and come back as zeros (no branches, no 64-bit address math)
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, (unsigned)(((long long)(p.Tk - 1) * p.k_st + p.HS) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (unsigned)(((long long)(p.Tk - 1) * p.v_st + p.HS) * 2), 0x00020000);
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  union U4H8 { u4 u; h8 h; };
   h8 kreg[NCH], vreg[NCH];
+  int st_row[NCH], st_col[NCH];
+#pragma unroll
+  for (int r = 0; r < NCH; ++r) {
+    int idx = tid + 256 * r;
+    st_row[r] = idx / CPR;
+    st_col[r] = (idx - st_row[r] * CPR) * 8;
+  }
   auto load_tile = [&](int t) {
 #pragma unroll
     for (int r = 0; r < NCH; ++r) {
-      int idx = tid + 256 * r;
-      int row = idx / CPR, col = (idx - row * CPR) * 8;
-      int key = t * 64 + row;
-      bool ok = row < 64 && key < p.Tk && col < p.HS;
-      kreg[r] = ok ? *reinterpret_cast<const h8*>(kb + key * p.k_st + col) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
-      vreg[r] = ok ? *reinterpret_cast<const h8*>(vb + key * p.v_st + col) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+      int key = t * 64 + st_row[r];
+      bool ok = st_row[r] < 64 && key < p.Tk && st_col[r] < p.HS;
+      unsigned ko = ok ? (unsigned)(key * (int)p.k_st + st_col[r]) * 2u : 0x80000000u;
+      unsigned vo = ok ? (unsigned)(key * (int)p.v_st + st_col[r]) * 2u : 0x80000000u;
+      U4H8 a, b2;
+      a.u = __builtin_amdgcn_raw_buffer_load_b128(rs_k, ko, 0, 0);
+      b2.u = __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo, 0, 0);
+      kreg[r] = a.h; vreg[r] = b2.h;
     }
   };
   auto store_tile = [&](int buf) {
@@ -89,11 +104,9 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
     half_t* vs_ = ks_ + 64 * KS;
 #pragma unroll
     for (int r = 0; r < NCH; ++r) {
-      int idx = tid + 256 * r;
-      int row = idx / CPR, col = (idx - row * CPR) * 8;
-      if (row < 64 && col < p.HS) {
-        *reinterpret_cast<h8*>(ks_ + row * KS + col) = kreg[r];
-        *reinterpret_cast<h8*>(vs_ + row * VS + col) = vreg[r];
+      if (st_row[r] < 64 && st_col[r] < p.HS) {
+        *reinterpret_cast<h8*>(ks_ + st_row[r] * KS + st_col[r]) = kreg[r];
+        *reinterpret_cast<h8*>(vs_ + st_row[r] * VS + st_col[r]) = vreg[r];
       }
     }
   };
@@ -137,34 +150,45 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
           }
         }
     }
-    // ---- online softmax (per query column), P^T fragments
+    // ---- online softmax (per query column) in log2 units, P^T fragments.  The running reference max only moves when
+    // some query's tile max exceeds it by more than RESCALE_THR (then every accumulator of the wave is rescaled once),
+    // so P <= 2^RESCALE_THR: harmless in fp16 (fp32 accumulation), and the O-wide multiply leaves the steady state.
+    constexpr float RESCALE_THR = 6.0f;
+    float mx[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float m0_ = fmaxf(fmaxf(st[0][qt][0], st[0][qt][1]), fmaxf(st[0][qt][2], st[0][qt][3]));
+#pragma unroll
+      for (int kt = 1; kt < 4; ++kt) m0_ = fmaxf(fmaxf(m0_, fmaxf(st[kt][qt][0], st[kt][qt][1])), fmaxf(st[kt][qt][2], st[kt][qt][3]));
+      m0_ = fmaxf(m0_, __shfl_xor(m0_, 16, 64));
+      m0_ = fmaxf(m0_, __shfl_xor(m0_, 32, 64));
+      mx[qt] = m0_ * p.scale_log2e;
+    }
+    if (__any((mx[0] > m_run[0] + RESCALE_THR) || (mx[1] > m_run[1] + RESCALE_THR))) {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        float m_new = fmaxf(m_run[qt], mx[qt]);
+        float alpha = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f(m_run[qt] - m_new);   // m_run = -inf -> 0
+        l_run[qt] *= alpha;
+        m_run[qt] = m_new;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) ot[dt][qt] *= alpha;
+      }
+    }
     h8 pf[2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      float mx = st[0][qt][0];
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, st[kt][qt][e]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float m_new = fmaxf(m_run[qt], mx);
-      float m_safe = m_new == -INFINITY ? 0.f : m_new;
-      float alpha = exp2f((m_run[qt] - m_safe) * p.scale_log2e);   // m_run = -inf -> 0
-      float mc = m_safe * p.scale_log2e;
+      const float mc = m_run[qt] == -INFINITY ? 0.f : m_run[qt];
       float sum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float pv = exp2f(st[kt][qt][e] * p.scale_log2e - mc);
+          float pv = __builtin_amdgcn_exp2f(st[kt][qt][e] * p.scale_log2e - mc);
           sum += pv;
           pf[kt >> 1][qt][(kt & 1) * 4 + e] = (half_t)pv;
         }
-      l_run[qt] = l_run[qt] * alpha + sum;
-      m_run[qt] = m_new;
-#pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) ot[dt][qt] *= alpha;
+      l_run[qt] += sum;
     }
     // ---- O^T += V^T P^T
 #pragma unroll
