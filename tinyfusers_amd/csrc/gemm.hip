@@ -249,19 +249,28 @@ __global__ void __launch_bounds__(512) k_igemm(const GemmP p) {
         }
       }
     };
+    // Ring protocol (4 slots, tile t lives in slot t % 4).  Barrier P hands tile 0 to the consumers; barrier(it)
+    // guarantees tile it+1 has landed (the consumers prefetch its fragments while multiplying tile it) and hands slot
+    // it % 4 back (the consumers drained their reads of tile it before arriving).  Three tiles stay in flight.
     static_assert(NSTAGE == 4, "wait ladder below is written for a 4-slot ring");
+    const int nt = kt_end - kt_begin;
 #pragma unroll
-    for (int s_ = 0; s_ < NSTAGE - 1; ++s_)
-      if (kt_begin + s_ < kt_end) stage(s_, kt_begin + s_);
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const int it = kt - kt_begin;
-      const int newer = kt_end - 1 - kt;                   // tiles issued after tile kt
-      if (newer >= 2) wait_vm<2 * LPS>();
-      else if (newer == 1) wait_vm<LPS>();
-      else wait_vm<0>();
-      __builtin_amdgcn_s_barrier();                       // tile kt handed to the consumers; slot (it-1)%4 handed back
+    for (int s_ = 0; s_ < NSTAGE; ++s_)
+      if (s_ < nt) stage(s_, kt_begin + s_);
+    {
+      const int newer = nt - 1;                            // stages issued after tile 0
+      if (newer >= 3) wait_vm<3 * LPS>(); else if (newer == 2) wait_vm<2 * LPS>(); else if (newer == 1) wait_vm<LPS>(); else wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();                         // barrier P
+    asm volatile("" ::: "memory");
+    for (int it = 0; it < nt; ++it) {
+      if (it + 1 < nt) {
+        const int newer = min(nt - 2 - it, 2);             // stages issued after tile it+1 (ring holds up to it+3 here)
+        if (newer >= 2) wait_vm<2 * LPS>(); else if (newer == 1) wait_vm<LPS>(); else wait_vm<0>();
+      }
+      __builtin_amdgcn_s_barrier();                       // barrier(it)
       asm volatile("" ::: "memory");
-      if (kt + NSTAGE - 1 < kt_end) stage((it + NSTAGE - 1) % NSTAGE, kt + NSTAGE - 1);
+      if (it + NSTAGE < nt) stage(it % NSTAGE, kt_begin + it + NSTAGE);
     }
     __builtin_amdgcn_s_barrier();                         // matches the consumers' "ring is free" barrier
     return;
@@ -287,35 +296,58 @@ __global__ void __launch_bounds__(512) k_igemm(const GemmP p) {
     int row = wave_m * TM + j * 16 + lr;
     xa[j] = row * 128 + ((lg ^ ((row >> 1) & 7)) << 4);
   }
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int buf = (kt - kt_begin) % NSTAGE;
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const char* sb = smem + buf * STAGE;
-    h8 wf0[NI], xf0[MJ], wf1[NI], xf1[MJ];
+  // fragments of the current and of the next K tile (software pipeline across the barrier: the ds_reads of tile t+1
+  // are in flight while the MFMAs of tile t issue)
+  h8 wfA[2][NI], xfA[2][MJ], wfB[2][NI], xfB[2][MJ];
+  auto read_frags = [&](int slot, h8 (&wf)[2][NI], h8 (&xf)[2][MJ]) {
+    const char* sb = smem + slot * STAGE;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) wf0[i] = *reinterpret_cast<const h8*>(sb + wa[i]);
+    for (int i = 0; i < NI; ++i) wf[0][i] = *reinterpret_cast<const h8*>(sb + wa[i]);
 #pragma unroll
-    for (int j = 0; j < MJ; ++j) xf0[j] = *reinterpret_cast<const h8*>(sb + xa[j]);
+    for (int j = 0; j < MJ; ++j) xf[0][j] = *reinterpret_cast<const h8*>(sb + xa[j]);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) wf1[i] = *reinterpret_cast<const h8*>(sb + (wa[i] ^ 64));
+    for (int i = 0; i < NI; ++i) wf[1][i] = *reinterpret_cast<const h8*>(sb + (wa[i] ^ 64));
 #pragma unroll
-    for (int j = 0; j < MJ; ++j) xf1[j] = *reinterpret_cast<const h8*>(sb + (xa[j] ^ 64));
+    for (int j = 0; j < MJ; ++j) xf[1][j] = *reinterpret_cast<const h8*>(sb + (xa[j] ^ 64));
+  };
+  auto mma = [&](h8 (&wf)[2][NI], h8 (&xf)[2][MJ]) {
     if (p.dbg & 2) {
 #pragma unroll
-      for (int i = 0; i < NI; ++i) { asm volatile("" ::"v"(wf0[i])); asm volatile("" ::"v"(wf1[i])); }
+      for (int k2 = 0; k2 < 2; ++k2) {
 #pragma unroll
-      for (int j = 0; j < MJ; ++j) { asm volatile("" ::"v"(xf0[j])); asm volatile("" ::"v"(xf1[j])); }
-      continue;
+        for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(wf[k2][i]));
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) asm volatile("" ::"v"(xf[k2][j]));
+      }
+      return;
     }
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-      for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[i], xf0[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[i], xf1[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[k2][i], xf[k2][j], acc[i][j], 0, 0, 0);
+  };
+  const int nt = kt_end - kt_begin;
+  __builtin_amdgcn_s_barrier();                           // barrier P: tile 0 landed
+  asm volatile("" ::: "memory");
+  if (nt > 0) read_frags(0, wfA, xfA);
+  for (int it = 0; it < nt; it += 2) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // fragments of tile it are in registers: its slot may be refilled
+    __builtin_amdgcn_s_barrier();                         // barrier(it): tile it+1 landed
+    asm volatile("" ::: "memory");
+    if (it + 1 < nt) read_frags((it + 1) % NSTAGE, wfB, xfB);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(wfA, xfA);
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + 1 >= nt) break;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // barrier(it+1)
+    asm volatile("" ::: "memory");
+    if (it + 2 < nt) read_frags((it + 2) % NSTAGE, wfA, xfA);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(wfB, xfB);
+    __builtin_amdgcn_sched_barrier(0);
   }
   __builtin_amdgcn_s_barrier();                           // every consumer is done with the ring: reuse it for the epilogue
   asm volatile("" ::: "memory");

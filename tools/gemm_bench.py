@@ -12,16 +12,24 @@ st = T.Stream()
 CFGS = [(128, 160), (64, 160), (128, 128), (64, 128), (128, 64), (64, 64)]
 
 
-def time_call(fn, reps=30):
+def time_call(fn, reps=20):
+    """Average device time per call: `reps` calls captured into a HIP graph (no host launch bound), replayed 5x."""
     ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()
     hip.tf_event_create(ctypes.byref(ev0)); hip.tf_event_create(ctypes.byref(ev1))
-    for _ in range(3): fn()
-    hip.tf_event_record(ev0, st.handle)
+    for _ in range(2): fn()
+    hip.tf_stream_sync(st.handle)
+    hip.tf_graph_begin_capture(st.handle)
     for _ in range(reps): fn()
+    g = ctypes.c_void_p()
+    hip.tf_graph_end_capture(st.handle, ctypes.byref(g))
+    hip.tf_graph_launch(g, st.handle)
+    hip.tf_event_record(ev0, st.handle)
+    for _ in range(5): hip.tf_graph_launch(g, st.handle)
     hip.tf_event_record(ev1, st.handle)
     hip.tf_stream_sync(st.handle)
     ms = ctypes.c_float(); hip.tf_event_elapsed_ms(ctypes.byref(ms), ev0, ev1)
-    return ms.value * 1e3 / reps
+    hip.tf_graph_destroy(g)
+    return ms.value * 1e3 / (reps * 5)
 
 
 def bench_conv(n, h, w, cin, cout, k, stride=1, splits=(1,), cfgs=CFGS, label=""):
