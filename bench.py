@@ -50,11 +50,9 @@ def build_weight_arena(unet, rank, world, device_index):
     from tinyfusers_amd.storage.synth import synth_tensor
     from tinyfusers_amd.storage.tensor import DeviceArray
     from tinyfusers_amd.native import hip
+    from tinyfusers_amd.dist import broadcast_arena, pack_tensor, plan_arena
     shapes = unet_param_shapes(unet)
-    offs, off = {}, 0
-    for k, s in shapes.items():
-        offs[k] = off
-        off += (int(np.prod(s)) * 2 + 255) // 256 * 256
+    offs, off = plan_arena(shapes)
     arena = torch.empty(off, dtype=torch.uint8, device=f"cuda:{device_index}")
     base = arena.data_ptr()
     t0 = time.time()
@@ -62,10 +60,7 @@ def build_weight_arena(unet, rank, world, device_index):
         from concurrent.futures import ThreadPoolExecutor
 
         def gen(k):
-            w = synth_tensor(0, k, shapes[k])
-            if w.ndim == 4:
-                w = np.ascontiguousarray(w.transpose(0, 2, 3, 1))     # KRSC
-            return k, w
+            return k, pack_tensor(synth_tensor(0, k, shapes[k]))
         with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
             for k, w in ex.map(gen, list(shapes)):
                 hip.tf_memcpy(base + offs[k], w.ctypes.data, w.nbytes, 1)
@@ -76,7 +71,7 @@ def build_weight_arena(unet, rank, world, device_index):
         torch.cuda.synchronize()
         dist.barrier()
         t1 = time.time()
-        dist.broadcast(arena, src=0)
+        broadcast_arena(arena, src=0)          # the ONLY collective of the path (RCCL over xGMI)
         torch.cuda.synchronize()
         t_bcast = time.time() - t1
     state = {k: DeviceArray(base + offs[k], shapes[k], np.float16, None, base=arena) for k in shapes}
@@ -167,11 +162,8 @@ def main():
     wall = time.perf_counter() - t0
     ms = ctypes.c_float()
     hip.tf_event_elapsed_ms(ctypes.byref(ms), ev0, ev1)
-    if world > 1:
-        import torch.distributed as dist
-        tmax = torch.tensor([wall], device=f"cuda:{local_rank}", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall = float(tmax.item())
+    from tinyfusers_amd.dist import max_over_ranks
+    wall = max_over_ranks(wall, device=f"cuda:{local_rank}")
     final = lat.numpy()
     assert np.isfinite(final).all(), "non-finite latent after the timed steps"
 
