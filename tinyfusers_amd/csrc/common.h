@@ -50,13 +50,16 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// fast activations: v_exp_f32 / v_rcp_f32 (1 ulp) instead of the IEEE division sequence; inputs are fp16-range
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 // tanh-GELU of storage/tensor.py:80-82: 0.5 x (1 + tanh(0.7978845608 x (1 + 0.044715 x^2)))
 __device__ __forceinline__ float gelu_f(float x) {
   float u = 0.7978845608f * x * (1.0f + 0.044715f * x * x);
-  // tanh(u) = 1 - 2/(exp(2u)+1)
-  float t = 1.0f - 2.0f / (__expf(2.0f * u) + 1.0f);
-  return 0.5f * x * (1.0f + t);
+  // 0.5 (1 + tanh(u)) = sigmoid(2u)
+  return x * sigmoid_f(2.0f * u);
 }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }

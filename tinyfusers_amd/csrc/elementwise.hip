@@ -17,9 +17,9 @@ enum { OP_SILU = 0, OP_SIGMOID = 1, OP_GELU = 2, OP_QGELU = 3 };
 template <int OP>
 __device__ __forceinline__ float act(float x) {
   if (OP == OP_SILU) return silu_f(x);
-  if (OP == OP_SIGMOID) return 1.0f / (1.0f + __expf(-x));
+  if (OP == OP_SIGMOID) return sigmoid_f(x);
   if (OP == OP_GELU) return gelu_f(x);
-  return x / (1.0f + __expf(-1.702f * x));
+  return x * sigmoid_f(1.702f * x);
 }
 
 template <int OP>

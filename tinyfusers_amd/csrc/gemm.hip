@@ -31,10 +31,22 @@ struct GemmP {
   int ktiles, ktiles_per_split, splitk;
   int act;              // 0 none, 1 GEGLU
   int ntm, ntn;         // tile counts
+  unsigned dv_howo_mul, dv_howo_shr, dv_wo_mul, dv_wo_shr;   // magic numbers: n / HoWo, n / Wo without a divide
   int dbg;              // diagnostic builds only (tools/gemm_bench.py): 1 no stores, 2 no MFMA, 4 no staging
 };
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;   // 128-bit buffer resource
+
+// n / d for n < 2^31 via a precomputed multiplier: q = (umulhi(mul, n) + n) >> shr   (round-up method)
+__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
+  return (int)(((unsigned long long)__umulhi(mul, (unsigned)n) + (unsigned)n) >> shr);
+}
+static void fast_div_magic(unsigned d, unsigned* mul, unsigned* shr) {
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  *mul = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+  *shr = l;
+}
 #define TF_OOB 0x80000000u   // voffset beyond every tensor: the buffer range check returns 0 -> zero padding in LDS
 
 // LDS-DMA: 16 B per lane, LDS destination = wave-uniform base + lane*16; out-of-range lanes write zeros
@@ -54,19 +66,26 @@ constexpr int NSTAGE = 4;
 // ---- epilogue (consumer waves): write the wave's TM x TN fp32 tile through a per-wave row-major LDS scratch so
 // that global stores / residual loads are 16-B coalesced row segments instead of MFMA-layout 8-B fragments.
 template <int BM, int BN>
-__device__ __forceinline__ void igemm_epilogue(const GemmP& p, f4 (&acc)[BN / 32][BM / 32], char* smem, int m0, int n0, int split, int w4, int lane) {
+__device__ __forceinline__ void igemm_scratch_write(f4 (&acc)[BN / 32][BM / 32], char* smem, int w4, int lane) {
   constexpr int TM = BM / 2, TN = BN / 2, MJ = TM / 16, NI = TN / 16;
-  const int wave_m = w4 & 1, wave_n = w4 >> 1;
+  constexpr int RS = TN + 4;                               // row stride (floats) keeps the f4 writes ~conflict-free
   const int lr = lane & 15, lg = lane >> 4;
-  constexpr int RS = TN + 4, ROWS = TM;                   // row stride (floats) keeps the f4 writes ~conflict-free
-  float* sc = reinterpret_cast<float*>(smem) + (size_t)w4 * (ROWS * RS);
+  float* sc = reinterpret_cast<float*>(smem) + (size_t)w4 * (TM * RS);
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < MJ; ++j)
       *reinterpret_cast<f4*>(sc + (j * 16 + lr) * RS + i * 16 + lg * 4) = acc[i][j];
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the same wave wrote it: no barrier needed
-  const int mb = m0 + wave_m * TM;
+}
+
+// all 8 waves: wave (w4, half) stores rows [half*TM/2, (half+1)*TM/2) of consumer w4's tile
+template <int BM, int BN>
+__device__ __forceinline__ void igemm_epilogue(const GemmP& p, const char* smem, int m0, int n0, int split, int w4, int half, int lane) {
+  constexpr int TM = BM / 2, TN = BN / 2;
+  const int wave_m = w4 & 1, wave_n = w4 >> 1;
+  constexpr int RS = TN + 4, ROWS = TM / 2;
+  const float* sc = reinterpret_cast<const float*>(smem) + (size_t)w4 * (TM * RS) + (size_t)half * ROWS * RS;
+  const int mb = m0 + wave_m * TM + half * ROWS;
   const int nb = n0 + wave_n * TN;                       // first (packed) column
   if (p.act == 1) {
     // GEGLU: packed columns come in 16-wide blocks value|gate; out column = (n>>5)*16 + (n&15)
@@ -185,8 +204,8 @@ __global__ void __launch_bounds__(512) k_igemm(const GemmP p) {
       if (row < BM) {
         int m = m0 + row;
         if (m < p.M) {
-          int img = m / p.HoWo, rem = m - img * p.HoWo;
-          int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+          int img = fast_div(m, p.dv_howo_mul, p.dv_howo_shr), rem = m - img * p.HoWo;
+          int ho = fast_div(rem, p.dv_wo_mul, p.dv_wo_shr), wo = rem - ho * p.Wo;
           g_a[i] = ho * p.stride - p.pad;
           g_b[i] = wo * p.stride - p.pad;
           g_c[i] = img * p.H * p.W;
@@ -272,7 +291,12 @@ __global__ void __launch_bounds__(512) k_igemm(const GemmP p) {
       asm volatile("" ::: "memory");
       if (it + NSTAGE < nt) stage(it % NSTAGE, kt_begin + it + NSTAGE);
     }
-    __builtin_amdgcn_s_barrier();                         // matches the consumers' "ring is free" barrier
+    __builtin_amdgcn_s_barrier();                         // barrier X: matches the consumers' "ring is free" barrier
+    asm volatile("" ::: "memory");
+    if (p.dbg & 1) return;
+    __builtin_amdgcn_s_barrier();                         // barrier Y: the consumers' tiles are in the LDS scratch
+    asm volatile("" ::: "memory");
+    igemm_epilogue<BM, BN>(p, smem, m0, n0, split, w4, 1, lane);
     return;
   }
 
@@ -349,7 +373,7 @@ __global__ void __launch_bounds__(512) k_igemm(const GemmP p) {
     mma(wfB, xfB);
     __builtin_amdgcn_sched_barrier(0);
   }
-  __builtin_amdgcn_s_barrier();                           // every consumer is done with the ring: reuse it for the epilogue
+  __builtin_amdgcn_s_barrier();                           // barrier X: every consumer is done with the ring
   asm volatile("" ::: "memory");
   if (p.dbg & 1) {
 #pragma unroll
@@ -358,7 +382,11 @@ __global__ void __launch_bounds__(512) k_igemm(const GemmP p) {
       for (int j = 0; j < MJ; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-  igemm_epilogue<BM, BN>(p, acc, smem, m0, n0, split, w4, lane);
+  igemm_scratch_write<BM, BN>(acc, smem, w4, lane);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                           // barrier Y
+  asm volatile("" ::: "memory");
+  igemm_epilogue<BM, BN>(p, smem, m0, n0, split, w4, 0, lane);
 }
 
 // split-K reduce + epilogue: y[m,n] = sum_z partial[z,m,n] + bias + bias_nc + residual   (N % 4 == 0 fast path)
@@ -506,6 +534,8 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
   p.splitk = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
   p.partial = (float*)workspace;
   p.dbg = g_dbg;
+  fast_div_magic((unsigned)p.HoWo, &p.dv_howo_mul, &p.dv_howo_shr);
+  fast_div_magic((unsigned)p.Wo, &p.dv_wo_mul, &p.dv_wo_shr);
   p.ntm = (p.M + c.bm - 1) / c.bm;
   p.ntn = (p.N + c.bn - 1) / c.bn;
   ProfRec rec;

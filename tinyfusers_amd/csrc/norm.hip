@@ -3,7 +3,7 @@
 #include "common.h"
 #include "../../include/tinyfusers_hip.h"
 
-#define GN_MAX_CHUNKS 128
+#define GN_MAX_CHUNKS 64
 
 // ---- GroupNorm pass 1: per-(image, pixel-chunk) partial sums per group ---------------------------
 // block = CV * RPB threads (CV = C/8 channel vectors, RPB rows per sweep); thread owns one channel vector.
@@ -42,63 +42,72 @@ __global__ void k_gn_stats(float* __restrict__ partial, const half_t* __restrict
     for (int j = 0; j < 8; ++j) { r[j] = s[j]; r[8 + j] = ss[j]; }
   }
   __syncthreads();
-  // deterministic fold: thread g sums its group's channels over the RPB row-threads in a fixed order
+  // deterministic fold: 8 lanes per group walk the (row-thread, channel) pairs of the group in a fixed strided order,
+  // then three xor-shuffles
   float* out = partial + ((long long)n * chunks + chunk) * G * 2;
-  for (int g = t; g < G; g += blockDim.x) {
-    int c0 = g * cpg, c1 = c0 + cpg;
+  const int sub = t & 7, gstep = blockDim.x >> 3;
+  const int npairs = RPB * cpg;
+  for (int g0 = 0; g0 < G; g0 += gstep) {
+    int g = g0 + (t >> 3);
     float S = 0.f, SS = 0.f;
-    for (int r_ = 0; r_ < RPB; ++r_)
-      for (int ch = c0; ch < c1; ++ch) {
+    if (g < G && (t >> 3) < gstep) {
+      for (int q = sub; q < npairs; q += 8) {
+        int r_ = q / cpg, ch = g * cpg + (q - r_ * cpg);
         const float* r = red + ((long long)r_ * CV + (ch >> 3)) * 16;
         S += r[ch & 7]; SS += r[8 + (ch & 7)];
       }
-    out[2 * g] = S; out[2 * g + 1] = SS;
-  }
-}
-
-// ---- GroupNorm pass 2: fold the per-chunk partials into (mean, rstd) per (image, group): one block per image,
-// 8 lanes per group (strided over the chunks, then three xor-shuffles), fixed summation order.
-__global__ void __launch_bounds__(256) k_gn_finalize(float* __restrict__ stats, const float* __restrict__ partial, int HW, int cpg, int G, int chunks,
-                                                     float eps) {
-  int n = blockIdx.x;
-  int sub = threadIdx.x & 7;
-  for (int g = threadIdx.x >> 3; g < ((G + 31) & ~31); g += 32) {
-    double S = 0.0, SS = 0.0;
-    if (g < G) {
-      const float* p = partial + (long long)n * chunks * G * 2 + g * 2;
-      for (int k = sub; k < chunks; k += 8) { S += (double)p[(long long)k * G * 2]; SS += (double)p[(long long)k * G * 2 + 1]; }
     }
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) { S += __shfl_xor(S, o, 64); SS += __shfl_xor(SS, o, 64); }
-    if (g < G && sub == 0) {
-      double cnt = (double)HW * cpg;
-      double mean = S / cnt;
-      double var = SS / cnt - mean * mean;
-      if (var < 0.0) var = 0.0;
-      stats[((long long)n * G + g) * 2] = (float)mean;
-      stats[((long long)n * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-    }
+    if (g < G && sub == 0 && (t >> 3) < gstep) { out[2 * g] = S; out[2 * g + 1] = SS; }
   }
 }
 
-// ---- GroupNorm pass 3: y = silu?((x - mean) * rstd * gamma + beta); many small blocks (latency-bound otherwise)
+// ---- GroupNorm pass 2: y = silu?((x - mean) * rstd * gamma + beta).  Every block first folds the per-chunk
+// partials of its image into (mean, rstd) per group (8 lanes per group strided over the chunks + xor-shuffles, fp64,
+// fixed order -> every block gets the same bits) -- cheaper than a separate finalize launch; then many small blocks
+// stream the tensor (the kernel is latency-bound otherwise).
 __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ x2, const half_t* __restrict__ gamma,
-                           const half_t* __restrict__ beta, const float* __restrict__ stats, int HW, int C1, int C2, int G, int do_silu,
-                           int pix_per_block, int CV, int RPB) {
+                           const half_t* __restrict__ beta, const float* __restrict__ partial, int HW, int C1, int C2, int G, float eps,
+                           int do_silu, int chunks, int pix_per_block, int CV, int RPB) {
+  extern __shared__ float st[];  // [G][2] : mean, rstd
   int n = blockIdx.y;
   int C = C1 + C2, cpg = C / G;
   int t = threadIdx.x;
+  {
+    const int sub = t & 7;
+    const int gstep = blockDim.x >> 3;               // blockDim.x is a multiple of 8 (CV*RPB threads, padded below)
+    for (int g0 = 0; g0 < G; g0 += gstep) {
+      int g = g0 + (t >> 3);
+      double S = 0.0, SS = 0.0;
+      if (g < G) {
+        const float* p = partial + (long long)n * chunks * G * 2 + g * 2;
+        for (int k = sub; k < chunks; k += 8) { S += (double)p[(long long)k * G * 2]; SS += (double)p[(long long)k * G * 2 + 1]; }
+      }
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) { S += __shfl_xor(S, o, 64); SS += __shfl_xor(SS, o, 64); }
+      if (g < G && sub == 0) {
+        double cnt = (double)HW * cpg;
+        double mean = S / cnt;
+        double var = SS / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        st[2 * g] = (float)mean;
+        st[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+      }
+    }
+  }
+  __syncthreads();
   int cv = t % CV, rr = t / CV;
   if (rr >= RPB) return;
   int c = cv * 8;
-  const float* st = stats + (long long)n * G * 2;
   float a[8], b[8];
   {
     h8 gm, bt;
     if (gamma) { gm = *reinterpret_cast<const h8*>(gamma + c); bt = *reinterpret_cast<const h8*>(beta + c); }
+    int g = c / cpg, gend = (g + 1) * cpg;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      int g = (c + j) / cpg;
+      if (c + j >= gend) { ++g; gend += cpg; }
       float mean = st[2 * g], rstd = st[2 * g + 1];
       float gmj = gamma ? (float)gm[j] : 1.0f, btj = gamma ? (float)bt[j] : 0.0f;
       a[j] = rstd * gmj;
@@ -127,43 +136,50 @@ __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x,
   }
 }
 
-// ---- LayerNorm: one wave per row, row held in registers (C <= 64*8*LN_MAXV) ----------------------
+// ---- LayerNorm: LPR lanes per row (8/16/32/64 so that a lane holds <= 5 vectors), 64/LPR rows per wave: several
+// independent 16-B loads in flight per lane and only log2(LPR) shuffle steps per reduction.
 #define LN_MAXV 5
+template <int LPR>
 __global__ void __launch_bounds__(256) k_layer_norm(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ gamma,
                                                     const half_t* __restrict__ beta, int rows, int C, float eps) {
+  constexpr int RPW = 64 / LPR;                          // rows per wave
   int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  int row = blockIdx.x * 4 + w;
-  if (row >= rows) return;
+  int row = (blockIdx.x * 4 + w) * RPW + l / LPR;
+  int li = l % LPR;
   int CV = C >> 3;
-  const half_t* xr = x + (long long)row * C;
+  bool live = row < rows;
+  const half_t* xr = x + (long long)(live ? row : 0) * C;
   h8 v[LN_MAXV];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
-    int cv = l + 64 * i;
+    int cv = li + LPR * i;
     if (cv < CV) {
       v[i] = *reinterpret_cast<const h8*>(xr + cv * 8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += (float)v[i][j];
     }
   }
-  s = wave_sum(s);
+#pragma unroll
+  for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o, 64);
   float mean = s / (float)C;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
-    int cv = l + 64 * i;
+    int cv = li + LPR * i;
     if (cv < CV) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { float d = (float)v[i][j] - mean; q += d * d; }
     }
   }
-  q = wave_sum(q);
+#pragma unroll
+  for (int o = 1; o < LPR; o <<= 1) q += __shfl_xor(q, o, 64);
   float rstd = rsqrtf(q / (float)C + eps);
+  if (!live) return;
   half_t* yr = y + (long long)row * C;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
-    int cv = l + 64 * i;
+    int cv = li + LPR * i;
     if (cv < CV) {
       h8 o;
       if (gamma) {
@@ -198,7 +214,7 @@ extern "C" {
 
 size_t tf_group_norm_workspace(int N, int HW, int C, int G) {
   (void)HW; (void)C;
-  return (size_t)N * (GN_MAX_CHUNKS + 1) * G * 2 * sizeof(float);   // per-chunk partials + the (mean, rstd) table
+  return (size_t)N * GN_MAX_CHUNKS * G * 2 * sizeof(float);   // per-chunk partial (sum, sum of squares) per group
 }
 
 int tf_group_norm_f16(void* y, const void* x, const void* x2, const void* gamma, const void* beta, int N, int HW, int C1, int C2, int G,
@@ -217,14 +233,12 @@ int tf_group_norm_f16(void* y, const void* x, const void* x2, const void* gamma,
   int CV, RPB, threads, chunks, ppc, ablocks, appb;
   gn_geometry(HW, C, N, &CV, &RPB, &threads, &chunks, &ppc, &ablocks, &appb);
   float* partial = (float*)workspace;
-  float* stats = partial + (size_t)N * GN_MAX_CHUNKS * G * 2;
-  hipLaunchKernelGGL(k_gn_stats, dim3(chunks, N), dim3(threads), (size_t)threads * 16 * sizeof(float), tf_hs(s), partial, (const half_t*)x,
+  int tl = (threads + 7) & ~7;                         // the folds work in groups of 8 lanes
+  hipLaunchKernelGGL(k_gn_stats, dim3(chunks, N), dim3(tl), (size_t)threads * 16 * sizeof(float), tf_hs(s), partial, (const half_t*)x,
                      (const half_t*)x2, HW, C1, C2, G, chunks, ppc, CV, RPB);
   TF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_gn_finalize, dim3(N), dim3(256), 0, tf_hs(s), stats, (const float*)partial, HW, C / G, G, chunks, eps);
-  TF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(threads), 0, tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
-                     (const half_t*)gamma, (const half_t*)beta, (const float*)stats, HW, C1, C2, G, silu, appb, CV, RPB);
+  hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
+                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
@@ -234,8 +248,15 @@ int tf_layer_norm_f16(void* y, const void* x, const void* gamma, const void* bet
   TF_REQUIRE((gamma == nullptr) == (beta == nullptr), "tf_layer_norm_f16: gamma and beta must both be given or both NULL");
   TF_REQUIRE(C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXV, "tf_layer_norm_f16: C=%d must be a multiple of 8 and <= %d", C, 64 * 8 * LN_MAXV);
   if (rows == 0) return TF_OK;
-  hipLaunchKernelGGL(k_layer_norm, dim3(ceil_div(rows, 4)), dim3(256), 0, tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)gamma,
-                     (const half_t*)beta, rows, C, eps);
+  int cv = C / 8;
+#define LN_LAUNCH(LPR_)                                                                                                            \
+  hipLaunchKernelGGL(k_layer_norm<LPR_>, dim3(ceil_div(rows, 4 * (64 / LPR_))), dim3(256), 0, tf_hs(s), (half_t*)y, (const half_t*)x, \
+                     (const half_t*)gamma, (const half_t*)beta, rows, C, eps)
+  if (cv <= 8 * LN_MAXV) LN_LAUNCH(8);
+  else if (cv <= 16 * LN_MAXV) LN_LAUNCH(16);
+  else if (cv <= 32 * LN_MAXV) LN_LAUNCH(32);
+  else LN_LAUNCH(64);
+#undef LN_LAUNCH
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
