@@ -86,6 +86,10 @@ int tf_prof_read(double* gemm_ms, double* gemm_flops, long long* gemm_launches);
 int tf_prof_dump(const char* csv_path);   /* per-shape table: M,N,K,taps,tile,split-K,launches,ms,TFLOP/s */
 /* test / tuning hook: force the GEMM tile (bm x bn in {128,64} x {160,128,64}) and split-K; 0,0,0 = heuristic */
 int tf_gemm_force_config(int bm, int bn, int splitk);
+/* per-shape autotuning of (tile, split-K, ring variant) on the first eager call of a shape (default on) */
+int tf_gemm_autotune(int on);
+/* diagnostic builds of tools/: bit 0 no stores, 1 no MFMA, 2 no staging, 3 force deep ring, 4 force wide ring */
+int tf_gemm_debug(int flags);
 
 /* ---- layout / dtype converters (the API edge: the reference's arrays are fp32 NCHW) ----------- */
 int tf_nchw_f32_to_nhwc_f16(void* dst, const void* src, int N, int C, int H, int W, tfStream_t s);

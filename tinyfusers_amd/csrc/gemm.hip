@@ -158,8 +158,11 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, const char* smem,
 // 8 waves with split roles: waves 0-3 are CONSUMERS (2 x 2 wave tiles: ds_read_b128 fragments + MFMA), waves 4-7 are
 // LOADERS (LDS-DMA only).  One consumer and one loader share each SIMD, so the loader's LDS-DMA issue stalls (~60-100
 // cycles per 1-KiB piece) never hold up MFMA issue; a single s_barrier per K tile hands ring slots back and forth.
-template <int BM, int BN, bool GENERIC>
-__global__ void __launch_bounds__(512) k_igemm(const GemmP p) {
+// WIDE = true is the short-K variant: 2-slot ring, one fragment set, <= 128 VGPRs, so TWO blocks share a CU and one
+// block's prologue / epilogue overlaps the other's K loop (shapes with many tiles and few K tiles per tile);
+// WIDE = false is the deep variant: 4-slot ring, fragments of tile t+1 prefetched during tile t, one block per CU.
+template <int BM, int BN, bool GENERIC, bool WIDE>
+__global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   constexpr int TM = BM / 2, TN = BN / 2, MJ = TM / 16, NI = TN / 16;
   constexpr int NG = (BM + BN) / 8;                       // 8-row staging groups: activation rows first, then weight rows
   constexpr int LPS = NG / 4;                             // LDS-DMA pieces per loader wave per stage
@@ -268,28 +271,40 @@ __global__ void __launch_bounds__(512) k_igemm(const GemmP p) {
         }
       }
     };
-    // Ring protocol (4 slots, tile t lives in slot t % 4).  Barrier P hands tile 0 to the consumers; barrier(it)
-    // guarantees tile it+1 has landed (the consumers prefetch its fragments while multiplying tile it) and hands slot
-    // it % 4 back (the consumers drained their reads of tile it before arriving).  Three tiles stay in flight.
-    static_assert(NSTAGE == 4, "wait ladder below is written for a 4-slot ring");
     const int nt = kt_end - kt_begin;
-#pragma unroll
-    for (int s_ = 0; s_ < NSTAGE; ++s_)
-      if (s_ < nt) stage(s_, kt_begin + s_);
-    {
-      const int newer = nt - 1;                            // stages issued after tile 0
-      if (newer >= 3) wait_vm<3 * LPS>(); else if (newer == 2) wait_vm<2 * LPS>(); else if (newer == 1) wait_vm<LPS>(); else wait_vm<0>();
-    }
-    __builtin_amdgcn_s_barrier();                         // barrier P
-    asm volatile("" ::: "memory");
-    for (int it = 0; it < nt; ++it) {
-      if (it + 1 < nt) {
-        const int newer = min(nt - 2 - it, 2);             // stages issued after tile it+1 (ring holds up to it+3 here)
-        if (newer >= 2) wait_vm<2 * LPS>(); else if (newer == 1) wait_vm<LPS>(); else wait_vm<0>();
+    if (WIDE) {
+      // 2-slot ring: barrier(it) hands tile it to the consumers and slot (it-1) % 2 back; tile it+1 is in flight
+      // while tile it is multiplied.
+      if (nt > 0) stage(0, kt_begin);
+      for (int it = 0; it < nt; ++it) {
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                     // barrier(it)
+        asm volatile("" ::: "memory");
+        if (it + 1 < nt) stage((it + 1) & 1, kt_begin + it + 1);
       }
-      __builtin_amdgcn_s_barrier();                       // barrier(it)
+    } else {
+      // Ring protocol (4 slots, tile t lives in slot t % 4).  Barrier P hands tile 0 to the consumers; barrier(it)
+      // guarantees tile it+1 has landed (the consumers prefetch its fragments while multiplying tile it) and hands
+      // slot it % 4 back (the consumers drained their reads of tile it before arriving).  Three tiles stay in flight.
+      static_assert(NSTAGE == 4, "wait ladder below is written for a 4-slot ring");
+#pragma unroll
+      for (int s_ = 0; s_ < NSTAGE; ++s_)
+        if (s_ < nt) stage(s_, kt_begin + s_);
+      {
+        const int newer = nt - 1;                          // stages issued after tile 0
+        if (newer >= 3) wait_vm<3 * LPS>(); else if (newer == 2) wait_vm<2 * LPS>(); else if (newer == 1) wait_vm<LPS>(); else wait_vm<0>();
+      }
+      __builtin_amdgcn_s_barrier();                       // barrier P
       asm volatile("" ::: "memory");
-      if (it + NSTAGE < nt) stage(it % NSTAGE, kt_begin + it + NSTAGE);
+      for (int it = 0; it < nt; ++it) {
+        if (it + 1 < nt) {
+          const int newer = min(nt - 2 - it, 2);           // stages issued after tile it+1 (ring holds up to it+3 here)
+          if (newer >= 2) wait_vm<2 * LPS>(); else if (newer == 1) wait_vm<LPS>(); else wait_vm<0>();
+        }
+        __builtin_amdgcn_s_barrier();                     // barrier(it)
+        asm volatile("" ::: "memory");
+        if (it + NSTAGE < nt) stage(it % NSTAGE, kt_begin + it + NSTAGE);
+      }
     }
     __builtin_amdgcn_s_barrier();                         // barrier X: matches the consumers' "ring is free" barrier
     asm volatile("" ::: "memory");
@@ -320,6 +335,33 @@ __global__ void __launch_bounds__(512) k_igemm(const GemmP p) {
     int row = wave_m * TM + j * 16 + lr;
     xa[j] = row * 128 + ((lg ^ ((row >> 1) & 7)) << 4);
   }
+  const int nt = kt_end - kt_begin;
+  if (WIDE) {
+    for (int it = 0; it < nt; ++it) {
+      __builtin_amdgcn_s_barrier();                       // barrier(it): tile it landed
+      asm volatile("" ::: "memory");
+      const char* sb = smem + (it & 1) * STAGE;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        h8 wf[NI], xf[MJ];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const h8*>(sb + (wa[i] ^ (k2 * 64)));
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) xf[j] = *reinterpret_cast<const h8*>(sb + (xa[j] ^ (k2 * 64)));
+        if (p.dbg & 2) {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(wf[i]));
+#pragma unroll
+          for (int j = 0; j < MJ; ++j) asm volatile("" ::"v"(xf[j]));
+          continue;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  } else {
   // fragments of the current and of the next K tile (software pipeline across the barrier: the ds_reads of tile t+1
   // are in flight while the MFMAs of tile t issue)
   h8 wfA[2][NI], xfA[2][MJ], wfB[2][NI], xfB[2][MJ];
@@ -352,7 +394,6 @@ __global__ void __launch_bounds__(512) k_igemm(const GemmP p) {
 #pragma unroll
         for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[k2][i], xf[k2][j], acc[i][j], 0, 0, 0);
   };
-  const int nt = kt_end - kt_begin;
   __builtin_amdgcn_s_barrier();                           // barrier P: tile 0 landed
   asm volatile("" ::: "memory");
   if (nt > 0) read_frags(0, wfA, xfA);
@@ -372,6 +413,7 @@ __global__ void __launch_bounds__(512) k_igemm(const GemmP p) {
     __builtin_amdgcn_sched_barrier(0);
     mma(wfB, xfB);
     __builtin_amdgcn_sched_barrier(0);
+  }
   }
   __builtin_amdgcn_s_barrier();                           // barrier X: every consumer is done with the ring
   asm volatile("" ::: "memory");
@@ -470,7 +512,7 @@ struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, taps, bm, bn, split
 static std::map<std::array<int, 7>, std::pair<long long, double>> g_prof_shapes;
 static std::vector<ProfRec> g_prof_pending;
 
-static int g_dbg = 0;
+static int g_dbg = 0, g_force_wide = -1;
 struct TileCfg { int bm, bn, splitk; };
 
 // Cost model (microseconds) calibrated on MI355X with tools/gemm_bench.py: a K tile costs the larger of its LDS-DMA
@@ -502,55 +544,42 @@ static TileCfg choose_tiles(int M, int N, int K, int act, bool allow_split) {
   return best;
 }
 
-template <int BM, int BN, bool GENERIC>
-static int launch_cfg2(const GemmP& p, hipStream_t st) {
-  constexpr int smem = NSTAGE * (BM + BN) * 128;
+template <int BM, int BN, bool GENERIC, bool WIDE>
+static int launch_cfg3(const GemmP& p, hipStream_t st) {
+  constexpr int TM = BM / 2, TN = BN / 2;
+  constexpr int ring = (WIDE ? 2 : NSTAGE) * (BM + BN) * 128;
+  constexpr int scratch = 4 * TM * (TN + 4) * 4;         // epilogue transpose scratch overlays the ring
+  constexpr int smem = ring > scratch ? ring : scratch;
   static bool attr_set = false;
   if (!attr_set) {
-    TF_HIP(hipFuncSetAttribute((const void*)k_igemm<BM, BN, GENERIC>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    TF_HIP(hipFuncSetAttribute((const void*)k_igemm<BM, BN, GENERIC, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_igemm<BM, BN, GENERIC>), dim3(p.ntm * p.ntn, p.splitk), dim3(512), smem, st, p);
+  hipLaunchKernelGGL((k_igemm<BM, BN, GENERIC, WIDE>), dim3(p.ntm * p.ntn, p.splitk), dim3(512), smem, st, p);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
-template <int BM, int BN>
-static int launch_cfg(const GemmP& p, hipStream_t st) {
+template <int BM, int BN, bool WIDE_OK>
+static int launch_cfg(const GemmP& p, hipStream_t st, bool wide) {
   bool generic = (p.C1 % 64) != 0 || (p.C2 % 64) != 0;
-  return generic ? launch_cfg2<BM, BN, true>(p, st) : launch_cfg2<BM, BN, false>(p, st);
+  if (WIDE_OK && wide) return generic ? launch_cfg3<BM, BN, true, WIDE_OK>(p, st) : launch_cfg3<BM, BN, false, WIDE_OK>(p, st);
+  return generic ? launch_cfg3<BM, BN, true, false>(p, st) : launch_cfg3<BM, BN, false, false>(p, st);
 }
 
-static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_bm, int force_bn, int force_split, hipStream_t st) {
+// one fully specified launch (tile, split-K, ring variant) of the kernel family (+ the split-K reduce)
+static int launch_one(GemmP p, TileCfg c, bool wide, void* workspace, hipStream_t st) {
   int rc = 0;
-  p.ktiles = (p.K + 63) / 64;
-  TileCfg c = choose_tiles(p.M, p.N, p.K, p.act, true);
-  if (force_bm) { c.bm = force_bm; c.bn = force_bn; c.splitk = force_split > 0 ? force_split : 1; }
-  if (c.splitk > 1) {
-    size_t need = (size_t)c.splitk * p.M * p.N * sizeof(float);
-    if (!workspace || workspace_bytes < need) c.splitk = 1;   // degrade gracefully: correctness does not depend on split-K
-  }
-  p.splitk = c.splitk;
   p.ktiles_per_split = (p.ktiles + c.splitk - 1) / c.splitk;
   p.splitk = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
   p.partial = (float*)workspace;
-  p.dbg = g_dbg;
-  fast_div_magic((unsigned)p.HoWo, &p.dv_howo_mul, &p.dv_howo_shr);
-  fast_div_magic((unsigned)p.Wo, &p.dv_wo_mul, &p.dv_wo_shr);
   p.ntm = (p.M + c.bm - 1) / c.bm;
   p.ntn = (p.N + c.bn - 1) / c.bn;
-  ProfRec rec;
-  if (g_prof) {
-    TF_HIP(hipEventCreate(&rec.a)); TF_HIP(hipEventCreate(&rec.b));
-    rec.flops = 2.0 * p.M * (double)p.N * p.K;
-    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.taps = p.K / p.C; rec.bm = c.bm; rec.bn = c.bn; rec.splitk = p.splitk;
-    TF_HIP(hipEventRecord(rec.a, st));
-  }
-  if (c.bm == 128 && c.bn == 160) rc = launch_cfg<128, 160>(p, st);
-  else if (c.bm == 64 && c.bn == 160) rc = launch_cfg<64, 160>(p, st);
-  else if (c.bm == 128 && c.bn == 128) rc = launch_cfg<128, 128>(p, st);
-  else if (c.bm == 64 && c.bn == 128) rc = launch_cfg<64, 128>(p, st);
-  else if (c.bm == 128 && c.bn == 64) rc = launch_cfg<128, 64>(p, st);
-  else if (c.bm == 64 && c.bn == 64) rc = launch_cfg<64, 64>(p, st);
+  if (c.bm == 128 && c.bn == 160) rc = launch_cfg<128, 160, false>(p, st, wide);     // scratch 86 KB: one block per CU only
+  else if (c.bm == 64 && c.bn == 160) rc = launch_cfg<64, 160, true>(p, st, wide);
+  else if (c.bm == 128 && c.bn == 128) rc = launch_cfg<128, 128, true>(p, st, wide);
+  else if (c.bm == 64 && c.bn == 128) rc = launch_cfg<64, 128, true>(p, st, wide);
+  else if (c.bm == 128 && c.bn == 64) rc = launch_cfg<128, 64, true>(p, st, wide);
+  else if (c.bm == 64 && c.bn == 64) rc = launch_cfg<64, 64, true>(p, st, wide);
   else { tf_set_error("run_gemm: no kernel for tile %dx%d", c.bm, c.bn); return TF_E_UNSUPPORTED; }
   if (rc) return rc;
   if (p.splitk > 1) {
@@ -562,13 +591,108 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
                        p.HoWo, p.splitk, p.bias_nc_stride);
     TF_LAUNCH_CHECK();
   }
+  return TF_OK;
+}
+
+// ---- per-shape autotuner ("measure, don't guess"): the first eager call of a shape times every admissible
+// (tile, split-K, ring variant) on the caller's own buffers with HIP events and caches the winner.  Never runs
+// inside a stream capture (a captured shape that was never seen eagerly falls back to the cost model).
+#define TF_SPLITK_WS_CAP ((size_t)64 << 20)
+static bool g_autotune = true;
+struct TunedCfg { TileCfg c; bool wide; };
+static std::map<std::array<int, 10>, TunedCfg> g_tuned;
+
+static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hipStream_t st, TunedCfg* out) {
+  static const int cand[][2] = {{128, 160}, {64, 160}, {128, 128}, {64, 128}, {128, 64}, {64, 64}};
+  hipEvent_t a, b;
+  TF_HIP(hipEventCreate(&a)); TF_HIP(hipEventCreate(&b));
+  float best = 1e30f;
+  TunedCfg bc = {choose_tiles(p.M, p.N, p.K, p.act, true), false};
+  for (int ci = 0; ci < 6; ++ci) {
+    int bm = cand[ci][0], bn = cand[ci][1];
+    if (p.act == 1 && (bn % 64) != 0) continue;
+    if (bm == 128 && p.M <= 64) continue;
+    if (bn >= 128 && p.N <= 64 && ci != 5) continue;
+    for (int sk = 1; sk <= 32; sk *= 2) {
+      if (sk > 1 && (p.act == 1 || p.ktiles / sk < 4 || !workspace || (size_t)sk * p.M * p.N * 4 > workspace_bytes)) break;
+      long long blocks = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * sk;
+      if (sk > 1 && blocks > 1024) break;
+      for (int wide = 0; wide < 2; ++wide) {
+        if (wide && (bm == 128 && bn == 160)) continue;
+        if (wide && blocks <= 256) continue;               // two blocks per CU need more blocks than CUs
+        TileCfg c = {bm, bn, sk};
+        int rc = launch_one(p, c, wide != 0, workspace, st);   // warm-up
+        if (rc) return rc;
+        TF_HIP(hipEventRecord(a, st));
+        for (int r = 0; r < 8; ++r) { rc = launch_one(p, c, wide != 0, workspace, st); if (rc) return rc; }
+        TF_HIP(hipEventRecord(b, st));
+        TF_HIP(hipEventSynchronize(b));
+        float ms = 0.f;
+        TF_HIP(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) { best = ms; bc = {c, wide != 0}; }
+      }
+    }
+  }
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  *out = bc;
+  return TF_OK;
+}
+
+static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_bm, int force_bn, int force_split, hipStream_t st) {
+  p.ktiles = (p.K + 63) / 64;
+  p.dbg = g_dbg;
+  fast_div_magic((unsigned)p.HoWo, &p.dv_howo_mul, &p.dv_howo_shr);
+  fast_div_magic((unsigned)p.Wo, &p.dv_wo_mul, &p.dv_wo_shr);
+  TunedCfg t = {choose_tiles(p.M, p.N, p.K, p.act, true), false};
+  bool tuned = false;
+  if (force_bm) {
+    t.c = {force_bm, force_bn, force_split > 0 ? force_split : 1};
+  } else if (g_autotune && !g_dbg) {
+    std::array<int, 10> key = {p.M, p.N, p.K, p.C1, p.C2, p.S, p.stride, p.ups, p.act, (p.bias ? 1 : 0) | (p.residual ? 2 : 0) | (p.bias_nc ? 4 : 0)};
+    auto it = g_tuned.find(key);
+    if (it != g_tuned.end()) { t = it->second; tuned = true; }
+    else {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing(st, &cs);
+      if (cs == hipStreamCaptureStatusNone) {
+        int rc = autotune(p, workspace, workspace_bytes, st, &t);
+        if (rc) return rc;
+        g_tuned[key] = t;
+        tuned = true;
+      }
+    }
+  }
+  if (t.c.splitk > 1) {
+    size_t need = (size_t)t.c.splitk * p.M * p.N * sizeof(float);
+    if (!workspace || workspace_bytes < need) t.c.splitk = 1;   // degrade gracefully: correctness does not depend on split-K
+  }
+  bool wide = t.wide;
+  if (!tuned) {
+    // cost-model fallback: WIDE (two blocks per CU) pays when a CU gets several tiles with a short K loop each
+    long long blocks = (long long)((p.M + t.c.bm - 1) / t.c.bm) * ((p.N + t.c.bn - 1) / t.c.bn) * t.c.splitk;
+    wide = blocks > 256 && p.ktiles / t.c.splitk <= 24;
+  }
+  if (g_force_wide >= 0) wide = g_force_wide != 0;
+  ProfRec rec;
+  if (g_prof) {
+    TF_HIP(hipEventCreate(&rec.a)); TF_HIP(hipEventCreate(&rec.b));
+    rec.flops = 2.0 * p.M * (double)p.N * p.K;
+    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.taps = p.K / p.C; rec.bm = t.c.bm; rec.bn = t.c.bn; rec.splitk = t.c.splitk * (wide ? -1 : 1);
+    TF_HIP(hipEventRecord(rec.a, st));
+  }
+  int rc = launch_one(p, t.c, wide, workspace, st);
+  if (rc) return rc;
   if (g_prof) { TF_HIP(hipEventRecord(rec.b, st)); g_prof_pending.push_back(rec); }
   return TF_OK;
 }
 
+// workspace the caller must provide: enough for any split-K the tuner may pick (capped)
 static size_t gemm_workspace(int M, int N, int K, int act) {
-  TileCfg c = choose_tiles(M, N, K, act, true);
-  return c.splitk > 1 ? (size_t)c.splitk * M * N * sizeof(float) : 0;
+  if (act == 1 || (K + 63) / 64 < 8) return 0;
+  size_t per = (size_t)M * N * sizeof(float);
+  int sk = 32;
+  while (sk > 1 && ((size_t)sk * per > TF_SPLITK_WS_CAP || (K + 63) / 64 / sk < 4)) sk >>= 1;
+  return sk > 1 ? (size_t)sk * per : 0;
 }
 
 // test hook: force a tile configuration (0 = heuristic)
@@ -576,7 +700,8 @@ static int g_force_bm = 0, g_force_bn = 0, g_force_split = 0;
 
 extern "C" {
 
-int tf_gemm_debug(int flags) { g_dbg = flags; return TF_OK; }
+int tf_gemm_debug(int flags) { g_dbg = flags & 7; g_force_wide = (flags & 16) ? 1 : (flags & 8) ? 0 : -1; return TF_OK; }
+int tf_gemm_autotune(int on) { g_autotune = on != 0; if (!on) g_tuned.clear(); return TF_OK; }
 int tf_gemm_force_config(int bm, int bn, int splitk) { g_force_bm = bm; g_force_bn = bn; g_force_split = splitk; return TF_OK; }
 
 int tf_prof_enable(int on) {

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tinyfusers_amd.storage.tensor as T
 from tinyfusers_amd.native import hip, lib
 from tools.gemm_bench import time_call, st
-lib.tf_gemm_debug.argtypes = [ctypes.c_int]
+
 
 def run(n, h, w, cin, cout, k, bm, bn, sk, label):
     pad = k // 2
@@ -29,3 +29,12 @@ run(2, 64, 64, 320, 320, 3, 128, 160, 1, "conv3x3 320@64")
 run(2, 32, 32, 640, 640, 3, 128, 160, 4, "conv3x3 640@32")
 run(2, 32, 32, 640, 640, 1, 64, 64, 1, "conv1x1 640@32")
 run(2, 16, 16, 1280, 1280, 3, 128, 160, 8, "conv3x3 1280@16")
+print("--- small-K shapes")
+run(2, 64, 64, 320, 2560, 1, 128, 128, 1, "geglu 320->2560@64")
+run(2, 64, 64, 320, 2560, 1, 64, 128, 1, "geglu 320->2560@64")
+run(2, 64, 64, 320, 2560, 1, 128, 160, 1, "geglu 320->2560@64")
+run(2, 64, 64, 320, 960, 1, 128, 160, 1, "qkv 320->960@64")
+run(2, 64, 64, 320, 960, 1, 64, 160, 1, "qkv 320->960@64")
+run(2, 64, 64, 1280, 320, 1, 64, 160, 1, "ff2 1280->320@64")
+run(2, 32, 32, 640, 640, 1, 64, 128, 1, "lin 640@32")
+run(2, 16, 16, 1280, 1280, 1, 64, 64, 1, "lin 1280@16")

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tinyfusers_amd.storage.tensor as T
 from tinyfusers_amd.native import hip, lib
 from tools.gemm_bench import time_call, st
-lib.tf_gemm_debug.argtypes = [ctypes.c_int]
+
 x = T.DeviceArray.from_numpy(np.random.randn(8192, 320).astype(np.float16))
 y = T.DeviceArray.empty((8192, 320))
 print("silu 64 elems      : %.2f us" % time_call(lambda: hip.tf_silu_f16(y.ptr, x.ptr, 64, st.handle), 200))
