@@ -10,6 +10,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtinyfusers_hip.so")
 SOURCES = ["runtime.hip", "elementwise.hip", "norm.hip", "gemm.hip", "sdpa.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-ffp-contract=fast"]
+# sdpa.hip: keep the MFMA accumulators in VGPRs (the softmax reads every score: no v_accvgpr_read traffic) and drop
+# the NaN-canonicalising v_max in front of every fmaxf on MFMA outputs (scores are never NaN; -inf masks still work)
+EXTRA = {"sdpa.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}
 
 
 def _hipcc():
@@ -36,7 +39,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + EXTRA.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -124,15 +124,15 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
 
     // ---- S^T = K Q^T : st[kt][qt], key(kt, row) = 32 (kt>>1) + 8 (row>>2) + 4 (kt&1) + (row&3)
     f4 st[4][2];
+    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      st[kt][0] = (f4){0, 0, 0, 0}; st[kt][1] = (f4){0, 0, 0, 0};
       int krow = 32 * (kt >> 1) + 8 * (lr >> 2) + 4 * (kt & 1) + (lr & 3);
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         h8 kf = *reinterpret_cast<const h8*>(ks_ + krow * KS + ks * 32 + lg * 8);
-        st[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], st[kt][0], 0, 0, 0);
-        st[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], st[kt][1], 0, 0, 0);
+        st[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], ks == 0 ? zero4 : st[kt][0], 0, 0, 0);
+        st[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], ks == 0 ? zero4 : st[kt][1], 0, 0, 0);
       }
     }
     // ---- masks: this lane's keys are t*64 + 32 (kt>>1) + 8 lg + 4 (kt&1) + reg
