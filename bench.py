@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of the HIP-graph replay")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--tune-cache", default="", help="file to load/save the GEMM autotuner's per-shape choices (optional)")
     return ap.parse_args()
 
 
@@ -137,7 +138,11 @@ def main():
     ac = sd.alphas_cumprod
     alphas = ac[timesteps]
     alphas_prev = np.concatenate((np.array([1.0]), alphas[:-1])).astype(np.float32)
+    if args.tune_cache:
+        hip.tf_gemm_tune_load(args.tune_cache.encode())
     sd.compile(unc, ctx, lat)
+    if args.tune_cache and rank == 0:
+        hip.tf_gemm_tune_save(args.tune_cache.encode())
 
     def run(n, eager):
         for s in range(n):

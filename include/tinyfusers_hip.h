@@ -88,7 +88,9 @@ int tf_prof_dump(const char* csv_path);   /* per-shape table: M,N,K,taps,tile,sp
 int tf_gemm_force_config(int bm, int bn, int splitk);
 /* per-shape autotuning of (tile, split-K, ring variant) on the first eager call of a shape (default on) */
 int tf_gemm_autotune(int on);
-/* diagnostic builds of tools/: bit 0 no stores, 1 no MFMA, 2 no staging, 3 force deep ring, 4 force wide ring */
+int tf_gemm_tune_save(const char* path);
+int tf_gemm_tune_load(const char* path);
+/* diagnostic builds of tools/: bit 0 no stores, 1 no MFMA, 2 no staging, 3/4 force deep/wide ring, 5/6 force n-fastest/m-fastest order */
 int tf_gemm_debug(int flags);
 
 /* ---- layout / dtype converters (the API edge: the reference's arrays are fp32 NCHW) ----------- */

@@ -31,6 +31,7 @@ struct GemmP {
   int ktiles, ktiles_per_split, splitk;
   int act;              // 0 none, 1 GEGLU
   int ntm, ntn;         // tile counts
+  int order;            // block -> tile order inside an XCD's run: 0 = n fastest (share activation rows), 1 = m fastest (share the weight tile)
   unsigned dv_howo_mul, dv_howo_shr, dv_wo_mul, dv_wo_shr;   // magic numbers: n / HoWo, n / Wo without a divide
   int dbg;              // diagnostic builds only (tools/gemm_bench.py): 1 no stores, 2 no MFMA, 4 no staging
 };
@@ -175,17 +176,23 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wid >= 4;
   const int w4 = wid & 3;
-  // XCD-aware tile order: blocks b and b+8 share an XCD's L2; give every XCD a contiguous run of tiles
-  // (n fastest, so a run re-uses the same activation rows and sweeps the weight tiles).
-  const int nblk = p.ntm * p.ntn;
+  // XCD-aware work order: blocks b and b+8 share an XCD (and its L2), so every XCD gets a contiguous run of work items
+  // (bijective remap).  Inside a run either n is fastest (neighbours re-use the same activation rows and sweep the
+  // weight tiles) or m is fastest (neighbours share one weight tile: each weight byte leaves HBM / Infinity Cache once);
+  // the host picks the order per shape (it is one of the autotuned knobs).  Speed only: any order is correct.
+  const int ntiles = p.ntm * p.ntn;
+  const int nblk = ntiles * p.splitk;
   int bid = blockIdx.x;
   {
     int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tile_m = bid / p.ntn, tile_n = bid - tile_m * p.ntn;
+  const int split = bid / ntiles;
+  const int tid_ = bid - split * ntiles;
+  int tile_m, tile_n;
+  if (p.order == 0) { tile_m = tid_ / p.ntn; tile_n = tid_ - tile_m * p.ntn; }
+  else { tile_n = tid_ / p.ntm; tile_m = tid_ - tile_n * p.ntm; }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int split = blockIdx.y;
   const int kt_begin = split * p.ktiles_per_split;
   const int kt_end = min(p.ktiles, kt_begin + p.ktiles_per_split);
 
@@ -512,7 +519,7 @@ struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, taps, bm, bn, split
 static std::map<std::array<int, 7>, std::pair<long long, double>> g_prof_shapes;
 static std::vector<ProfRec> g_prof_pending;
 
-static int g_dbg = 0, g_force_wide = -1;
+static int g_dbg = 0, g_force_wide = -1, g_force_order = -1;
 struct TileCfg { int bm, bn, splitk; };
 
 // Cost model (microseconds) calibrated on MI355X with tools/gemm_bench.py: a K tile costs the larger of its LDS-DMA
@@ -555,7 +562,7 @@ static int launch_cfg3(const GemmP& p, hipStream_t st) {
     TF_HIP(hipFuncSetAttribute((const void*)k_igemm<BM, BN, GENERIC, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_igemm<BM, BN, GENERIC, WIDE>), dim3(p.ntm * p.ntn, p.splitk), dim3(512), smem, st, p);
+  hipLaunchKernelGGL((k_igemm<BM, BN, GENERIC, WIDE>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
@@ -567,8 +574,9 @@ static int launch_cfg(const GemmP& p, hipStream_t st, bool wide) {
 }
 
 // one fully specified launch (tile, split-K, ring variant) of the kernel family (+ the split-K reduce)
-static int launch_one(GemmP p, TileCfg c, bool wide, void* workspace, hipStream_t st) {
+static int launch_one(GemmP p, TileCfg c, bool wide, int order, void* workspace, hipStream_t st) {
   int rc = 0;
+  p.order = order;
   p.ktiles_per_split = (p.ktiles + c.splitk - 1) / c.splitk;
   p.splitk = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
   p.partial = (float*)workspace;
@@ -599,7 +607,7 @@ static int launch_one(GemmP p, TileCfg c, bool wide, void* workspace, hipStream_
 // inside a stream capture (a captured shape that was never seen eagerly falls back to the cost model).
 #define TF_SPLITK_WS_CAP ((size_t)64 << 20)
 static bool g_autotune = true;
-struct TunedCfg { TileCfg c; bool wide; };
+struct TunedCfg { TileCfg c; bool wide; int order; };
 static std::map<std::array<int, 10>, TunedCfg> g_tuned;
 
 static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hipStream_t st, TunedCfg* out) {
@@ -607,7 +615,7 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
   hipEvent_t a, b;
   TF_HIP(hipEventCreate(&a)); TF_HIP(hipEventCreate(&b));
   float best = 1e30f;
-  TunedCfg bc = {choose_tiles(p.M, p.N, p.K, p.act, true), false};
+  TunedCfg bc = {choose_tiles(p.M, p.N, p.K, p.act, true), false, 0};
   for (int ci = 0; ci < 6; ++ci) {
     int bm = cand[ci][0], bn = cand[ci][1];
     if (p.act == 1 && (bn % 64) != 0) continue;
@@ -621,15 +629,18 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
         if (wide && (bm == 128 && bn == 160)) continue;
         if (wide && blocks <= 256) continue;               // two blocks per CU need more blocks than CUs
         TileCfg c = {bm, bn, sk};
-        int rc = launch_one(p, c, wide != 0, workspace, st);   // warm-up
-        if (rc) return rc;
-        TF_HIP(hipEventRecord(a, st));
-        for (int r = 0; r < 8; ++r) { rc = launch_one(p, c, wide != 0, workspace, st); if (rc) return rc; }
-        TF_HIP(hipEventRecord(b, st));
-        TF_HIP(hipEventSynchronize(b));
-        float ms = 0.f;
-        TF_HIP(hipEventElapsedTime(&ms, a, b));
-        if (ms < best) { best = ms; bc = {c, wide != 0}; }
+        for (int order = 0; order < 2; ++order) {
+          if (order == 1 && (p.M + bm - 1) / bm == 1) continue;   // a single m tile: both orders coincide
+          int rc = launch_one(p, c, wide != 0, order, workspace, st);   // warm-up
+          if (rc) return rc;
+          TF_HIP(hipEventRecord(a, st));
+          for (int r = 0; r < 8; ++r) { rc = launch_one(p, c, wide != 0, order, workspace, st); if (rc) return rc; }
+          TF_HIP(hipEventRecord(b, st));
+          TF_HIP(hipEventSynchronize(b));
+          float ms = 0.f;
+          TF_HIP(hipEventElapsedTime(&ms, a, b));
+          if (ms < best) { best = ms; bc = {c, wide != 0, order}; }
+        }
       }
     }
   }
@@ -643,10 +654,11 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
   p.dbg = g_dbg;
   fast_div_magic((unsigned)p.HoWo, &p.dv_howo_mul, &p.dv_howo_shr);
   fast_div_magic((unsigned)p.Wo, &p.dv_wo_mul, &p.dv_wo_shr);
-  TunedCfg t = {choose_tiles(p.M, p.N, p.K, p.act, true), false};
+  TunedCfg t = {choose_tiles(p.M, p.N, p.K, p.act, true), false, 0};
   bool tuned = false;
   if (force_bm) {
     t.c = {force_bm, force_bn, force_split > 0 ? force_split : 1};
+    t.order = g_force_order > 0 ? 1 : 0;
   } else if (g_autotune && !g_dbg) {
     std::array<int, 10> key = {p.M, p.N, p.K, p.C1, p.C2, p.S, p.stride, p.ups, p.act, (p.bias ? 1 : 0) | (p.residual ? 2 : 0) | (p.bias_nc ? 4 : 0)};
     auto it = g_tuned.find(key);
@@ -680,7 +692,8 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.taps = p.K / p.C; rec.bm = t.c.bm; rec.bn = t.c.bn; rec.splitk = t.c.splitk * (wide ? -1 : 1);
     TF_HIP(hipEventRecord(rec.a, st));
   }
-  int rc = launch_one(p, t.c, wide, workspace, st);
+  if (g_force_order >= 0) t.order = g_force_order;
+  int rc = launch_one(p, t.c, wide, t.order, workspace, st);
   if (rc) return rc;
   if (g_prof) { TF_HIP(hipEventRecord(rec.b, st)); g_prof_pending.push_back(rec); }
   return TF_OK;
@@ -700,8 +713,41 @@ static int g_force_bm = 0, g_force_bn = 0, g_force_split = 0;
 
 extern "C" {
 
-int tf_gemm_debug(int flags) { g_dbg = flags & 7; g_force_wide = (flags & 16) ? 1 : (flags & 8) ? 0 : -1; return TF_OK; }
+int tf_gemm_debug(int flags) {
+  g_dbg = flags & 7;
+  g_force_wide = (flags & 16) ? 1 : (flags & 8) ? 0 : -1;
+  g_force_order = (flags & 64) ? 1 : (flags & 32) ? 0 : -1;
+  return TF_OK;
+}
 int tf_gemm_autotune(int on) { g_autotune = on != 0; if (!on) g_tuned.clear(); return TF_OK; }
+// persist / restore the tuner's choices (one line per shape) so that profiled or repeated runs skip the tuning launches
+int tf_gemm_tune_save(const char* path) {
+  TF_REQUIRE(path, "tf_gemm_tune_save: null path");
+  FILE* f = fopen(path, "w");
+  TF_REQUIRE(f, "tf_gemm_tune_save: cannot open %s", path);
+  for (auto& kv : g_tuned) {
+    for (int i = 0; i < 10; ++i) fprintf(f, "%d ", kv.first[i]);
+    fprintf(f, "%d %d %d %d %d\n", kv.second.c.bm, kv.second.c.bn, kv.second.c.splitk, kv.second.wide ? 1 : 0, kv.second.order);
+  }
+  fclose(f);
+  return TF_OK;
+}
+int tf_gemm_tune_load(const char* path) {
+  TF_REQUIRE(path, "tf_gemm_tune_load: null path");
+  FILE* f = fopen(path, "r");
+  if (!f) return TF_OK;                                  // no cache yet: tune on first use
+  std::array<int, 10> k; int bm, bn, sk, wide, order;
+  for (;;) {
+    int n = 0;
+    for (int i = 0; i < 10; ++i) n += fscanf(f, "%d", &k[i]);
+    n += fscanf(f, "%d %d %d %d %d", &bm, &bn, &sk, &wide, &order);
+    if (n != 15) break;
+    bool ok = (bm == 64 || bm == 128) && (bn == 64 || bn == 128 || bn == 160) && sk >= 1 && sk <= 32;
+    if (ok) g_tuned[k] = {{bm, bn, sk}, wide != 0, order != 0 ? 1 : 0};
+  }
+  fclose(f);
+  return TF_OK;
+}
 int tf_gemm_force_config(int bm, int bn, int splitk) { g_force_bm = bm; g_force_bn = bn; g_force_split = splitk; return TF_OK; }
 
 int tf_prof_enable(int on) {

@@ -252,10 +252,11 @@ int tf_layer_norm_f16(void* y, const void* x, const void* gamma, const void* bet
 #define LN_LAUNCH(LPR_)                                                                                                            \
   hipLaunchKernelGGL(k_layer_norm<LPR_>, dim3(ceil_div(rows, 4 * (64 / LPR_))), dim3(256), 0, tf_hs(s), (half_t*)y, (const half_t*)x, \
                      (const half_t*)gamma, (const half_t*)beta, rows, C, eps)
-  if (cv <= 8 * LN_MAXV) LN_LAUNCH(8);
+  // few rows: one wave per row (most waves in flight); many rows: several rows per wave (more loads per lane)
+  if (rows < 8192 || cv > 32 * LN_MAXV) LN_LAUNCH(64);
+  else if (cv <= 8 * LN_MAXV) LN_LAUNCH(8);
   else if (cv <= 16 * LN_MAXV) LN_LAUNCH(16);
-  else if (cv <= 32 * LN_MAXV) LN_LAUNCH(32);
-  else LN_LAUNCH(64);
+  else LN_LAUNCH(32);
 #undef LN_LAUNCH
   TF_LAUNCH_CHECK();
   return TF_OK;
