@@ -184,8 +184,17 @@ def main():
         hip.tf_prof_read(ctypes.byref(gms), ctypes.byref(gfl), ctypes.byref(gl))
         lib.tf_prof_enable(0)
         ach = gfl.value / (gms.value * 1e-3) / 1e12 if gms.value > 0 else 0.0
+        # HBM bytes per launch of this kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the
+        # gfx950 correction + WRITE_SIZE, separate runs of this same command; tools/pmc_summary.py): cannot be sampled live
+        traffic = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = round(pj["k_igemm"]["hbm_bytes_per_launch"])
+        except Exception:
+            pass
         roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4),
-                    "traffic": None, "kernel": "k_igemm<BM,BN> (implicit-GEMM conv2d + linear)",
+                    "traffic": traffic, "traffic_unit": "HBM bytes per launch (profiles/r01_pmc_traffic.json)",
+                    "kernel": "k_igemm<BM,BN> (implicit-GEMM conv2d + linear)",
                     "launches_per_step": gl.value / n_inst, "avg_launch_us": round(gms.value * 1e3 / max(1, gl.value), 2),
                     "gemm_ms_per_step": round(gms.value / n_inst, 4), "gemm_flop_per_step": gfl.value / n_inst}
 

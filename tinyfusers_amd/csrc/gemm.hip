@@ -60,7 +60,18 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-constexpr int NSTAGE = 4;
+// counted wait with a runtime stage count: leaves k * LPS of this wave's loads in flight (k clamped to [0, MAXK])
+template <int LPS, int MAXK>
+__device__ __forceinline__ void wait_stages(int k) {
+  if constexpr (MAXK == 0) { wait_vm<0>(); }
+  else {
+    if (k >= MAXK) wait_vm<(MAXK * LPS > 63 ? 63 : MAXK * LPS)>();
+    else wait_stages<LPS, MAXK - 1>(k);
+  }
+}
+
+// deep-variant ring depth: as many slots as 160 KiB of LDS hold (<= 8): LDS-DMA ingest is latency x bytes-in-flight bound
+constexpr int ring_slots(int bm, int bn) { int s = 163840 / ((bm + bn) * 128); return s > 8 ? 8 : s; }
 
 // GENERIC = false: every channel count is a multiple of 64, so a 64-wide K tile lies inside one filter tap and one
 // concat source and (tap, channel) advance as wave-uniform scalars; GENERIC = true recomputes them per lane.
@@ -168,7 +179,9 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   constexpr int NG = (BM + BN) / 8;                       // 8-row staging groups: activation rows first, then weight rows
   constexpr int LPS = NG / 4;                             // LDS-DMA pieces per loader wave per stage
   constexpr int STAGE = (BM + BN) * 128;
+  constexpr int NS = WIDE ? 2 : ring_slots(BM, BN);      // ring slots
   static_assert(NG % 4 == 0 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
+  static_assert((NS - 2) * LPS <= 63 || WIDE, "vmcnt immediate is 6 bits");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -290,27 +303,20 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
         if (it + 1 < nt) stage((it + 1) & 1, kt_begin + it + 1);
       }
     } else {
-      // Ring protocol (4 slots, tile t lives in slot t % 4).  Barrier P hands tile 0 to the consumers; barrier(it)
+      // Ring protocol (NS slots, tile t lives in slot t % NS).  Barrier P hands tile 0 to the consumers; barrier(it)
       // guarantees tile it+1 has landed (the consumers prefetch its fragments while multiplying tile it) and hands
-      // slot it % 4 back (the consumers drained their reads of tile it before arriving).  Three tiles stay in flight.
-      static_assert(NSTAGE == 4, "wait ladder below is written for a 4-slot ring");
+      // slot it % NS back (the consumers drained their reads of tile it before arriving).  NS-1 tiles stay in flight.
 #pragma unroll
-      for (int s_ = 0; s_ < NSTAGE; ++s_)
+      for (int s_ = 0; s_ < NS; ++s_)
         if (s_ < nt) stage(s_, kt_begin + s_);
-      {
-        const int newer = nt - 1;                          // stages issued after tile 0
-        if (newer >= 3) wait_vm<3 * LPS>(); else if (newer == 2) wait_vm<2 * LPS>(); else if (newer == 1) wait_vm<LPS>(); else wait_vm<0>();
-      }
+      wait_stages<LPS, NS - 1>(nt - 1);                    // tile 0 landed; up to NS-1 newer stages in flight
       __builtin_amdgcn_s_barrier();                       // barrier P
       asm volatile("" ::: "memory");
       for (int it = 0; it < nt; ++it) {
-        if (it + 1 < nt) {
-          const int newer = min(nt - 2 - it, 2);           // stages issued after tile it+1 (ring holds up to it+3 here)
-          if (newer >= 2) wait_vm<2 * LPS>(); else if (newer == 1) wait_vm<LPS>(); else wait_vm<0>();
-        }
+        if (it + 1 < nt) wait_stages<LPS, NS - 2>(nt - 2 - it);   // tile it+1 landed (ring holds up to tile it+NS-1 here)
         __builtin_amdgcn_s_barrier();                     // barrier(it)
         asm volatile("" ::: "memory");
-        if (it + NSTAGE < nt) stage(it % NSTAGE, kt_begin + it + NSTAGE);
+        if (it + NS < nt) stage(it % NS, kt_begin + it + NS);
       }
     }
     __builtin_amdgcn_s_barrier();                         // barrier X: matches the consumers' "ring is free" barrier
@@ -408,7 +414,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // fragments of tile it are in registers: its slot may be refilled
     __builtin_amdgcn_s_barrier();                         // barrier(it): tile it+1 landed
     asm volatile("" ::: "memory");
-    if (it + 1 < nt) read_frags((it + 1) % NSTAGE, wfB, xfB);
+    if (it + 1 < nt) read_frags((it + 1) % NS, wfB, xfB);
     __builtin_amdgcn_sched_barrier(0);
     mma(wfA, xfA);
     __builtin_amdgcn_sched_barrier(0);
@@ -416,7 +422,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                         // barrier(it+1)
     asm volatile("" ::: "memory");
-    if (it + 2 < nt) read_frags((it + 2) % NSTAGE, wfA, xfA);
+    if (it + 2 < nt) read_frags((it + 2) % NS, wfA, xfA);
     __builtin_amdgcn_sched_barrier(0);
     mma(wfB, xfB);
     __builtin_amdgcn_sched_barrier(0);
@@ -554,7 +560,7 @@ static TileCfg choose_tiles(int M, int N, int K, int act, bool allow_split) {
 template <int BM, int BN, bool GENERIC, bool WIDE>
 static int launch_cfg3(const GemmP& p, hipStream_t st) {
   constexpr int TM = BM / 2, TN = BN / 2;
-  constexpr int ring = (WIDE ? 2 : NSTAGE) * (BM + BN) * 128;
+  constexpr int ring = (WIDE ? 2 : ring_slots(BM, BN)) * (BM + BN) * 128;
   constexpr int scratch = 4 * TM * (TN + 4) * 4;         // epilogue transpose scratch overlays the ring
   constexpr int smem = ring > scratch ? ring : scratch;
   static bool attr_set = false;
@@ -750,9 +756,23 @@ int tf_gemm_tune_load(const char* path) {
 }
 int tf_gemm_force_config(int bm, int bn, int splitk) { g_force_bm = bm; g_force_bn = bn; g_force_split = splitk; return TF_OK; }
 
+static float g_prof_overhead_ms = 0.f;   // what an empty [record a][record b] interval reads on this stream
 int tf_prof_enable(int on) {
   g_prof = on != 0;
-  if (on) { g_prof_ms = 0.0; g_prof_flops = 0.0; g_prof_launches = 0; g_prof_pending.clear(); g_prof_shapes.clear(); }
+  if (on) {
+    g_prof_ms = 0.0; g_prof_flops = 0.0; g_prof_launches = 0; g_prof_pending.clear(); g_prof_shapes.clear();
+    // calibrate the event pair itself (median of 16 empty intervals on the NULL stream) and subtract it per launch
+    hipEvent_t a, b;
+    TF_HIP(hipEventCreate(&a)); TF_HIP(hipEventCreate(&b));
+    float v[16];
+    for (int i = 0; i < 16; ++i) {
+      TF_HIP(hipEventRecord(a, 0)); TF_HIP(hipEventRecord(b, 0)); TF_HIP(hipEventSynchronize(b));
+      TF_HIP(hipEventElapsedTime(&v[i], a, b));
+    }
+    for (int i = 0; i < 16; ++i) for (int j = i + 1; j < 16; ++j) if (v[j] < v[i]) { float t = v[i]; v[i] = v[j]; v[j] = t; }
+    g_prof_overhead_ms = v[8];
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  }
   return TF_OK;
 }
 int tf_prof_read(double* ms, double* flops, long long* launches) {
@@ -760,6 +780,8 @@ int tf_prof_read(double* ms, double* flops, long long* launches) {
     float t = 0.f;
     TF_HIP(hipEventSynchronize(r.b));
     TF_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    t -= g_prof_overhead_ms;
+    if (t < 0.f) t = 0.f;
     g_prof_ms += t; g_prof_flops += r.flops; g_prof_launches += 1;
     auto& e = g_prof_shapes[{r.M, r.N, r.K, r.taps, r.bm, r.bn, r.splitk}];
     e.first += 1; e.second += t;
