@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Sampler driver -- mirrors example/sd1.py:54-79 of the reference (timesteps = range(1,1000,1000//steps), reversed loop,
+decode at the end) on synthetic weights / contexts (no checkpoint, vocab or CLIP exists offline).
+BASELINE config 3: full 50-step sampler, batch 1, end-to-end img/s.
+
+    python -m example.sd1 --steps 50 [--out rendered.npy]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser(description="Run the SD-1.x sampler on MI355X (synthetic weights)")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--guidance", type=float, default=7.5)
+    ap.add_argument("--images", type=int, default=3, help="images to time after the first (compile + warm-up) one")
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+
+    import oracle  # only for the parameter-shape enumerator of the VAE (names); no oracle compute is used
+    import tinyfusers_amd.storage.tensor as T
+    from tinyfusers_amd.storage.state import unet_param_shapes, update_state
+    from tinyfusers_amd.storage.synth import synth_normal, synth_state_dict
+    from tinyfusers_amd.variants.sd import StableDiffusion
+
+    T.ensure_init(0)
+    model = StableDiffusion()
+    t0 = time.time()
+    shapes = {"model.diffusion_model." + k: v for k, v in unet_param_shapes(model.model.diffusion_model).items()}
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        update_state(model, {**synth_state_dict(shapes, 0), **synth_state_dict(oracle.vae_decoder_param_shapes(), 0)}, "")
+    print(f"weights installed in {time.time() - t0:.1f}s")
+    context = T.DeviceArray.from_numpy(synth_normal(args.seed, "sd.context", (1, 77, 768)))
+    unconditional_context = T.DeviceArray.from_numpy(synth_normal(args.seed, "sd.uncond", (1, 77, 768)))
+    timesteps = list(range(1, 1000, 1000 // args.steps))
+    alphas = model.alphas_cumprod[timesteps]
+    alphas_prev = np.concatenate((np.array([1.0]), alphas[:-1])).astype(np.float32)
+    latent = model.latent_from_numpy(synth_normal(args.seed, "sd.latent", (1, 4, 64, 64)))
+    model.compile(unconditional_context, context, latent)
+    times = []
+    for n in range(args.images + 1):
+        T.hip.tf_memcpy(latent.ptr, np.ascontiguousarray(synth_normal(args.seed + n, "sd.latent", (1, 4, 64, 64))).ctypes.data, latent.nbytes, 1)
+        t0 = time.perf_counter()
+        for index, timestep in list(enumerate(timesteps))[::-1]:
+            model.step(timestep, alphas[index], alphas_prev[index], args.guidance)
+        model.synchronize()
+        t1 = time.perf_counter()
+        with T.use_stream(model._stream):
+            x = model.decode(latent)
+        t2 = time.perf_counter()
+        times.append((t1 - t0, t2 - t1))
+        print(f"image {n}: {args.steps} steps {1e3 * (t1 - t0):.1f} ms ({args.steps / (t1 - t0):.1f} steps/s), decode {1e3 * (t2 - t1):.1f} ms, image {x.shape} mean {x.mean():.1f}")
+    s, d = np.median([t[0] for t in times[1:]]), np.median([t[1] for t in times[1:]])
+    print(f"end-to-end (sampler + VAE decode, batch 1): {1.0 / (s + d):.3f} img/s  [{args.steps} steps {1e3 * s:.1f} ms + decode {1e3 * d:.1f} ms]")
+    if args.out:
+        np.save(args.out, x)

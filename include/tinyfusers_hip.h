@@ -98,6 +98,12 @@ int tf_nchw_f32_to_nhwc_f16(void* dst, const void* src, int N, int C, int H, int
 int tf_nhwc_f16_to_nchw_f32(void* dst, const void* src, int N, int C, int H, int W, tfStream_t s);
 int tf_cast_f32_to_f16(void* dst, const void* src, long long n, tfStream_t s);
 int tf_cast_f16_to_f32(void* dst, const void* src, long long n, tfStream_t s);
+int tf_scale_cast_f32_to_f16(void* dst, const void* src, float scale, long long n, tfStream_t s);  /* 1/0.18215 * x (variants/sd.py:49) */
+/* fp16 re-layouts for the VAE AttnBlock, which the reference runs on NCHW q/k/v (attention/attention.py:19-24) */
+int tf_nhwc_to_nchw_f16(void* dst, const void* src, int N, int C, int H, int W, tfStream_t s);
+int tf_nchw_to_nhwc_f16(void* dst, const void* src, int N, int C, int H, int W, tfStream_t s);
+/* decode tail (variants/sd.py:51-53): (x+1)/2 -> clip -> *255 -> uint8; x (H,W,C) f16 -> out (H,W,C) u8 */
+int tf_image_to_u8(void* out, const void* x, long long n, tfStream_t s);
 
 /* ---- conv2d / linear: one implicit-GEMM MFMA kernel family ------------------------------------
  * tf_conv2d_f16 replaces conv_2d + Conv2d.__call__ (vision/conv2d.py:9-28, :48-58: cuDNN conv_fprop graph

@@ -1,0 +1,84 @@
+"""CPU restatement of the reference's VAE decode side: post_quant_conv + Decoder + image tail.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Weight names are the LDM keys the reference's update_state walk
+produces from the StableDiffusion root (``first_stage_model.decoder...``)."""
+import numpy as np
+import torch
+
+from . import ops
+
+__all__ = ["vae_decoder_param_shapes", "resnet_block", "attn_block", "vae_decoder", "sd_decode"]
+
+_SZ = [(128, 256), (256, 512), (512, 512), (512, 512)]
+
+
+def vae_decoder_param_shapes(prefix="first_stage_model."):
+    """vae/vae.py:10, vae/decoder.py:9-20, vae/mid.py:6-9, attention/attention.py:11-16, vision/resnet.py:34-39."""
+    P = {}
+
+    def conv(p, i, o, k):
+        P[p + ".weight"] = (o, i, k, k); P[p + ".bias"] = (o,)
+
+    def norm(p, c):
+        P[p + ".weight"] = (c,); P[p + ".bias"] = (c,)
+
+    def res(p, i, o):
+        norm(p + ".norm1", i); conv(p + ".conv1", i, o, 3); norm(p + ".norm2", o); conv(p + ".conv2", o, o, 3)
+        if i != o:
+            conv(p + ".nin_shortcut", i, o, 1)
+    d = prefix + "decoder"
+    conv(prefix + "post_quant_conv", 4, 4, 1)
+    conv(d + ".conv_in", 4, 512, 3)
+    res(d + ".mid.block_1", 512, 512)
+    norm(d + ".mid.attn_1.norm", 512)
+    for n in ("q", "k", "v", "proj_out"):
+        conv(d + ".mid.attn_1." + n, 512, 512, 1)
+    res(d + ".mid.block_2", 512, 512)
+    for i, s in enumerate(_SZ):
+        res(f"{d}.up.{i}.block.0", s[1], s[0]); res(f"{d}.up.{i}.block.1", s[0], s[0]); res(f"{d}.up.{i}.block.2", s[0], s[0])
+        if i != 0:
+            conv(f"{d}.up.{i}.upsample.conv", s[0], s[0], 3)
+    norm(d + ".norm_out", 128); conv(d + ".conv_out", 128, 3, 3)
+    return P
+
+
+def resnet_block(x, W, p):
+    """vision/resnet.py:41-45 -- ResnetBlock.__call__."""
+    h = ops.conv2d_bias(ops.silu(ops.group_norm_affine(x, 32, W[p + ".norm1.weight"], W[p + ".norm1.bias"])), W[p + ".conv1.weight"], W[p + ".conv1.bias"], (1, 1))
+    h = ops.conv2d_bias(ops.silu(ops.group_norm_affine(h, 32, W[p + ".norm2.weight"], W[p + ".norm2.bias"])), W[p + ".conv2.weight"], W[p + ".conv2.bias"], (1, 1))
+    if p + ".nin_shortcut.weight" in W:
+        x = ops.conv2d_bias(x, W[p + ".nin_shortcut.weight"], W[p + ".nin_shortcut.bias"])
+    return x + h
+
+
+def attn_block(x, W, p):
+    """attention/attention.py:19-24 -- AttnBlock.__call__.  q/k/v stay NCHW and go straight into
+    scaled_dot_product_attention, which therefore reads them as (B, NH, T, HS) = (b, c, h, w) (reference-exact)."""
+    h_ = ops.group_norm_affine(x, 32, W[p + ".norm.weight"], W[p + ".norm.bias"])
+    q, k, v = [ops.conv2d_bias(h_, W[f"{p}.{n}.weight"], W[f"{p}.{n}.bias"]) for n in ("q", "k", "v")]
+    h_tf = ops.scaled_dot_product_attention(q, k, v)
+    return x + ops.conv2d_bias(h_tf, W[p + ".proj_out.weight"], W[p + ".proj_out.bias"])
+
+
+def vae_decoder(x, W, d="first_stage_model.decoder"):
+    """vae/decoder.py:22-34 -- Decoder.__call__."""
+    x = ops.conv2d_bias(x, W[d + ".conv_in.weight"], W[d + ".conv_in.bias"], (1, 1))
+    x = resnet_block(x, W, d + ".mid.block_1"); x = attn_block(x, W, d + ".mid.attn_1"); x = resnet_block(x, W, d + ".mid.block_2")
+    for i in reversed(range(4)):
+        for j in range(3):
+            x = resnet_block(x, W, f"{d}.up.{i}.block.{j}")
+        if i != 0:
+            x = ops.conv2d_bias(ops.upsample_nearest2x(x), W[f"{d}.up.{i}.upsample.conv.weight"], W[f"{d}.up.{i}.upsample.conv.bias"], (1, 1))
+    x = ops.silu(ops.group_norm_affine(x, 32, W[d + ".norm_out.weight"], W[d + ".norm_out.bias"]))
+    return ops.conv2d_bias(x, W[d + ".conv_out.weight"], W[d + ".conv_out.bias"], (1, 1))
+
+
+def sd_decode(latent, W, prefix="first_stage_model."):
+    """variants/sd.py:48-54 -- decode: returns (float image in [-..], uint8 HWC image)."""
+    W = {k: ops.as_t(v) for k, v in W.items()}
+    x = ops.conv2d_bias(1 / 0.18215 * ops.as_t(latent), W[prefix + "post_quant_conv.weight"], W[prefix + "post_quant_conv.bias"])
+    x = vae_decoder(x, W, prefix + "decoder")
+    img = (x + 1.0) / 2.0
+    h, w = img.shape[2], img.shape[3]
+    u8 = (torch.clip(img.reshape(3, h, w).permute(1, 2, 0), 0, 1) * 255).numpy().astype(np.uint8)
+    return x, u8

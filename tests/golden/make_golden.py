@@ -291,9 +291,40 @@ def gen_unet():
     print("unet_sd15.npz written (inputs: synth seed 1234 by name; weights: synth seed 0)")
 
 
+def gen_vae():
+    """StableDiffusion.decode (variants/sd.py:48-54) through the reference's Decoder / AttnBlock / ResnetBlock."""
+    from types import SimpleNamespace
+    from tinyfusers.vae.decoder import Decoder
+    from tinyfusers.vision.conv2d import Conv2d
+    from tinyfusers.variants.sd import StableDiffusion
+    from oracle.vae import vae_decoder_param_shapes
+    W = synth(vae_decoder_param_shapes(), seed=0)
+    fsm = SimpleNamespace(decoder=Decoder(), post_quant_conv=Conv2d(4, 4, kernel_size=[1, 1]))
+    install(fsm, W, "first_stage_model")
+    sd = StableDiffusion.__new__(StableDiffusion)
+    sd.first_stage_model = fsm
+    latent = rnd("vae.latent", (1, 4, 64, 64), 0.18215 * 0.8, seed=1234)
+    t0 = time.time()
+    import io, contextlib
+    taps = {}
+    dec = fsm.decoder
+    orig = dec.__class__.__call__
+    def tapped(self, x):
+        y = orig(self, x); taps["pre"] = np.array(y); return y
+    dec.__class__.__call__ = tapped
+    with contextlib.redirect_stdout(io.StringIO()):
+        img = sd.decode(latent)
+    dec.__class__.__call__ = orig
+    print("decode %.1fs" % (time.time() - t0), img.shape, img.dtype, float(img.mean()))
+    np.savez_compressed(os.path.join(HERE, "vae_sd15.npz"), pre_sub=taps["pre"][:, :, ::4, ::4].astype(np.float32),
+                        img_sub=np.asarray(img)[::4, ::4].astype(np.uint8), pre_mean=np.float32(taps["pre"].mean()), pre_std=np.float32(taps["pre"].std()))
+    print("vae_sd15.npz written")
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["ops", "blocks"]
     import_reference()
     if "ops" in what: gen_ops()
     if "blocks" in what: gen_blocks()
     if "unet" in what: gen_unet()
+    if "vae" in what: gen_vae()

@@ -116,3 +116,18 @@ def test_unet_full_sd15(golden):
     x = oracle.sd_step(unc, ctx, latent, np.array([ts[49]]), al[49:50], ap[49:50], np.array([7.5]), Wt)
     err = float((x - torch.from_numpy(g["x_after_step0"])).abs().max())
     assert err < 2e-4, err
+
+
+@pytest.mark.slow
+def test_vae_decode_sd15(golden):
+    """decode() of the reference (VAE decoder incl. its per-channel AttnBlock) on the golden latent (~40 s on 8 cores)."""
+    import os
+    p = os.path.join(os.path.dirname(__file__), "golden", "vae_sd15.npz")
+    if not os.path.exists(p):
+        pytest.skip("vae_sd15.npz not generated")
+    g = np.load(p)
+    W = {k: v.astype(np.float32) for k, v in synth_state_dict(oracle.vae_decoder_param_shapes(), 0).items()}
+    latent = synth_normal(1234, "vae.latent", (1, 4, 64, 64), 0.18215 * 0.8)
+    pre, u8 = oracle.sd_decode(latent, W)
+    np.testing.assert_allclose(pre.numpy()[:, :, ::4, ::4], g["pre_sub"], rtol=1e-4, atol=2e-4)
+    assert int(np.abs(u8[::4, ::4].astype(np.int32) - g["img_sub"].astype(np.int32)).max()) <= 1

@@ -31,6 +31,40 @@ def _concat_rows(ws):
     return out
 
 
+class AttnBlock:
+    """attention/attention.py:10-24 (VAE mid block).  The reference hands the NCHW q/k/v straight to
+    scaled_dot_product_attention, which reads them as (B, NH, T, HS) = (b, c, h, w): one 'head' per channel attending
+    over the h x w matrix of that channel (not the LDM (b, hw, c) single-head attention).  config.head_merge ==
+    'reference_exact' reproduces exactly that (NHWC -> NCHW re-layout around the fused SDPA kernel); 'intended'
+    runs the LDM form."""
+
+    def __init__(self, in_channels, init=True):
+        self.norm = GroupNorm(32, in_channels, init=init)
+        self.q = Conv2d(in_channels, in_channels, kernel_size=[1, 1], init=init)
+        self.k = Conv2d(in_channels, in_channels, kernel_size=[1, 1], init=init)
+        self.v = Conv2d(in_channels, in_channels, kernel_size=[1, 1], init=init)
+        self.proj_out = Conv2d(in_channels, in_channels, kernel_size=[1, 1], init=init)
+
+    def __call__(self, x):
+        b, c, h, w = x.shape
+        h_ = self.norm(x)
+        q, k, v = self.q(h_), self.k(h_), self.v(h_)
+        if config.head_merge == "reference_exact":
+            def nchw(t):
+                o = DeviceArray.empty((b, c, h, w), np.float16, "row")
+                hip.tf_nhwc_to_nchw_f16(o.ptr, t.ptr, b, c, h, w, _sh())
+                return o
+            qn, kn, vn = nchw(q), nchw(k), nchw(v)
+            on = DeviceArray.empty((b, c, h, w), np.float16, "row")
+            st = (c * h * w, h * w, w)
+            sdpa_strided(on, qn, kn, vn, b, c, h, h, w, st, st, st, st)
+            o = DeviceArray.empty((b, c, h, w), np.float16, "nhwc")
+            hip.tf_nchw_to_nhwc_f16(o.ptr, on.ptr, b, c, h, w, _sh())
+        else:
+            raise NotImplementedError("AttnBlock: the LDM single-head form (head size = channels) is not built yet")
+        return self.proj_out(o, residual=x)
+
+
 class CrossAttention:
     def __init__(self, query_dim, context_dim, n_heads, d_head, init=True):
         self.to_q = Linear(query_dim, n_heads * d_head, bias=False, init=init)

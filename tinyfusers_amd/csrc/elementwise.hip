@@ -136,6 +136,10 @@ __global__ void __launch_bounds__(EW_BLOCK) k_im2col(half_t* __restrict__ y, con
   }
 }
 
+__global__ void __launch_bounds__(EW_BLOCK) k_scale_cast_f32_f16(half_t* __restrict__ y, const float* __restrict__ x, float sc, long long n) {
+  long long gs = (long long)gridDim.x * EW_BLOCK;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += gs) y[i] = (half_t)(x[i] * sc);
+}
 __global__ void __launch_bounds__(EW_BLOCK) k_cast_f32_f16(half_t* __restrict__ y, const float* __restrict__ x, long long n) {
   long long gs = (long long)gridDim.x * EW_BLOCK;
   for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += gs) y[i] = (half_t)x[i];
@@ -172,6 +176,22 @@ __global__ void __launch_bounds__(256) k_nhwc_to_nchw(float* __restrict__ dst, c
   for (int j = ty; j < 32; j += 8) {
     int c = c0 + j, p = p0 + tx;
     if (c < C && p < HW) dst[((long long)n * C + c) * HW + p] = tile[tx][j];
+  }
+}
+
+// f16 <-> f16 re-layout through a 32x32 LDS tile: (N, A, B) -> (N, B, A)
+__global__ void __launch_bounds__(256) k_transpose_f16(half_t* __restrict__ dst, const half_t* __restrict__ src, int A, int B) {
+  __shared__ half_t tile[32][34];
+  int n = blockIdx.z, a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    int a = a0 + j, b = b0 + tx;
+    tile[j][tx] = (a < A && b < B) ? src[((long long)n * A + a) * B + b] : (half_t)0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int b = b0 + j, a = a0 + tx;
+    if (a < A && b < B) dst[((long long)n * B + b) * A + a] = tile[tx][j];
   }
 }
 
@@ -336,6 +356,13 @@ int tf_cast_f32_to_f16(void* dst, const void* src, long long n, tfStream_t s) {
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
+int tf_scale_cast_f32_to_f16(void* dst, const void* src, float scale, long long n, tfStream_t s) {
+  TF_REQUIRE(dst && src && n >= 0, "tf_scale_cast_f32_to_f16: bad arguments");
+  if (n == 0) return TF_OK;
+  hipLaunchKernelGGL(k_scale_cast_f32_f16, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)dst, (const float*)src, scale, n);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
 int tf_cast_f16_to_f32(void* dst, const void* src, long long n, tfStream_t s) {
   TF_REQUIRE(dst && src && n >= 0, "tf_cast_f16_to_f32: bad arguments");
   if (n == 0) return TF_OK;
@@ -356,6 +383,38 @@ int tf_nhwc_f16_to_nchw_f32(void* dst, const void* src, int N, int C, int H, int
   int HW = H * W;
   if ((long long)N * HW == 0) return TF_OK;
   hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(ceil_div(HW, 32), ceil_div(C, 32), N), dim3(256), 0, tf_hs(s), (float*)dst, (const half_t*)src, C, HW);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_nhwc_to_nchw_f16(void* dst, const void* src, int N, int C, int H, int W, tfStream_t s) {
+  TF_REQUIRE(dst && src && N >= 0 && N <= 65535 && C > 0, "tf_nhwc_to_nchw_f16: bad arguments");
+  int HW = H * W;
+  if ((long long)N * HW == 0) return TF_OK;
+  hipLaunchKernelGGL(k_transpose_f16, dim3(ceil_div(C, 32), ceil_div(HW, 32), N), dim3(256), 0, tf_hs(s), (half_t*)dst, (const half_t*)src, HW, C);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_nchw_to_nhwc_f16(void* dst, const void* src, int N, int C, int H, int W, tfStream_t s) {
+  TF_REQUIRE(dst && src && N >= 0 && N <= 65535 && C > 0, "tf_nchw_to_nhwc_f16: bad arguments");
+  int HW = H * W;
+  if ((long long)N * HW == 0) return TF_OK;
+  hipLaunchKernelGGL(k_transpose_f16, dim3(ceil_div(HW, 32), ceil_div(C, 32), N), dim3(256), 0, tf_hs(s), (half_t*)dst, (const half_t*)src, C, HW);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+// decode tail (variants/sd.py:51-53): (x + 1) / 2 -> clip [0,1] -> * 255 -> uint8, NHWC f16 -> HWC u8
+__global__ void __launch_bounds__(EW_BLOCK) k_to_u8(unsigned char* __restrict__ out, const half_t* __restrict__ x, long long n) {
+  long long gs = (long long)gridDim.x * EW_BLOCK;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += gs) {
+    float v = ((float)x[i] + 1.0f) * 0.5f;
+    v = fminf(fmaxf(v, 0.f), 1.f) * 255.f;
+    out[i] = (unsigned char)v;
+  }
+}
+int tf_image_to_u8(void* out, const void* x, long long n, tfStream_t s) {
+  TF_REQUIRE(out && x && n >= 0, "tf_image_to_u8: bad arguments");
+  if (n == 0) return TF_OK;
+  hipLaunchKernelGGL(k_to_u8, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (unsigned char*)out, (const half_t*)x, n);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }

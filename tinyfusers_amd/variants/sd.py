@@ -34,7 +34,8 @@ class StableDiffusion:
     def __init__(self, cfg=SD15, init=False):
         self.alphas_cumprod = get_alphas_cumprod()
         self.model = namedtuple("DiffusionModel", ["diffusion_model"])(diffusion_model=UNetModel(cfg, init=init))
-        self.first_stage_model = None    # AutoencoderKL: SURVEY 8(f1), not on the per-step path
+        from ..vae.vae import AutoencoderKL
+        self.first_stage_model = AutoencoderKL(init=init) if cfg is SD15 else None   # decode side only
         self.cond_stage_model = None     # CLIPTextTransformer: SURVEY 8(f2)
         self._params = None
         self._graph = None
@@ -68,6 +69,24 @@ class StableDiffusion:
         hip.tf_memcpy_async(x_prev.ptr, latent.ptr, latent.nbytes, 3, _sh())
         hip.tf_cfg_ddim_step_f32(x_prev.ptr, out.ptr, sp.dev.ptr, b, c, h, w, _sh())
         return x_prev
+
+    def decode(self, x):
+        """variants/sd.py:48-54: post_quant_conv(x / 0.18215) -> Decoder -> (x+1)/2 -> clip -> uint8 (H, W, 3).
+        x: fp32 NCHW latent (1,4,h,w) on the device.  Returns a host uint8 array."""
+        b, c, h, w = x.shape
+        assert b == 1, "decode: batch 1 (the reference reshapes to (3,512,512), variants/sd.py:52)"
+        z16 = DeviceArray.empty((b, c, h, w), np.float16, "row")
+        hip.tf_scale_cast_f32_to_f16(z16.ptr, x.ptr, 1.0 / 0.18215, x.size, _sh())
+        z = DeviceArray.empty((b, c, h, w), np.float16, "nhwc")
+        hip.tf_nchw_to_nhwc_f16(z.ptr, z16.ptr, b, c, h, w, _sh())
+        y = self.first_stage_model.decoder(self.first_stage_model.post_quant_conv(z))      # (1,3,8h,8w) NHWC
+        n = y.size
+        out = DeviceArray.empty((n,), np.uint8, "row")
+        hip.tf_image_to_u8(out.ptr, y.ptr, n, _sh())
+        hip.tf_stream_sync(_sh())
+        host = np.empty((y.shape[2], y.shape[3], y.shape[1]), dtype=np.uint8)
+        hip.tf_memcpy(host.ctypes.data, out.ptr, n, 2)
+        return host
 
     # -- helpers ---------------------------------------------------------------------------------
     def _step_params(self):
