@@ -131,6 +131,16 @@ size_t tf_conv2d_workspace(int N, int H, int W, int C1, int C2, int Cout, int R,
 int tf_linear_f16(void* y, const void* x, const void* w, const void* bias, const void* residual, int M, int N, int K,
                   int act, void* workspace, size_t workspace_bytes, tfStream_t s);
 size_t tf_linear_workspace(int M, int N, int K, int act);
+/* LayerNorm folded into the Linear that consumes it (ff/layer_norm.py:34-49 followed by ff/linear.py:112-121, the
+ * norm1->to_q/k/v, norm2->to_q, norm3->GEGLU pairs of attention/attention.py:52-56):
+ *   Linear(LN(x)) = rstd[m] * ( x . w'^T - mean[m] * colsum[n] ) + bias'[n],   w' = w * gamma, colsum = rowsum(w'),
+ *   bias' = w . beta + bias.  tf_ln_fold_weights_f16 prepares (w', bias', colsum) once per weight set; the GEMM then runs
+ *   on the RAW x and gets mean / rstd of every row from the activation fragments it streams anyway (no LayerNorm
+ *   launch, no normalised tensor in HBM).  act as in tf_linear_f16 (for GEGLU fold first, then pack). */
+int tf_ln_fold_weights_f16(void* w_out, void* bias_out, void* colsum_out_f32, const void* w, const void* bias, const void* gamma,
+                           const void* beta, int N, int K, tfStream_t s);
+int tf_linear_ln_f16(void* y, const void* x, const void* w_folded, const void* bias_folded, const void* colsum_f32, const void* residual,
+                     int M, int N, int K, int act, float eps, tfStream_t s);
 /* M == 1..8 weight-streaming GEMV with optional SiLU on the input (the time-embedding MLP and the 22
  * ResBlock emb_layers, vision/unet.py:53-54, vision/resnet.py:27): y(M,N) = silu?(x)(M,K) . w(N,K)^T + b */
 int tf_gemv_f16(void* y, const void* x, const void* w, const void* bias, int M, int N, int K, int silu_input, tfStream_t s);

@@ -241,3 +241,27 @@ def test_softmax_rows_and_own_runtime_kernels(tf):
         (d.transpose4d if len(shape) == 4 else d.transpose)(dst, src, axes)
         out = dst.to("cpu").data.reshape([shape[i] for i in axes])
         close(out, np.transpose(a, axes), atol=0, rtol=0)
+
+
+@pytest.mark.parametrize("m,n,k,act", [(8192, 960, 320, 0), (2048, 640, 640, 0), (512, 1280, 1280, 0), (300, 128, 64, 0), (8192, 1280, 320, 1), (154, 64, 128, 1)])
+def test_linear_with_folded_layer_norm(tf, m, n, k, act):
+    """Linear(LayerNorm(x)) as one GEMM on the raw x (tf_linear_ln_f16) vs the oracle's LN followed by Linear / GEGLU."""
+    from oracle import ops as O
+    from tinyfusers_amd.ff.layer_norm import LayerNorm
+    from tinyfusers_amd.ff.linear import fold_layer_norm, linear_ln_f16
+    from tinyfusers_amd.ff.nn import GEGLU
+    x = rnd("lnf.x", (m, k), 1.5) + 0.7          # non-zero mean: exercises the mean * colsum cancellation
+    g, b = 1 + rnd("lnf.g", (k,), 0.1), rnd("lnf.b", (k,), 0.1)
+    ln = LayerNorm(k); ln.weight = dev(tf, g); ln.bias = dev(tf, b)
+    xn = O.layer_norm(x, g, b)
+    if act == 0:
+        w, bias = rnd("lnf.w", (n, k), k ** -0.5), rnd("lnf.bias", (n,), 0.1)
+        r = rnd("lnf.r", (m, n))
+        got = linear_ln_f16(dev(tf, x), fold_layer_norm(dev(tf, w), dev(tf, bias), ln), ln.eps, residual=dev(tf, r)).numpy()
+        close(got, (O.linear(xn, w, bias) + torch.from_numpy(r)).numpy())
+        got = linear_ln_f16(dev(tf, x), fold_layer_norm(dev(tf, w), None, ln), ln.eps).numpy()
+        close(got, O.linear(xn, w).numpy())
+    else:
+        w, bias = rnd("lnf.w", (2 * n, k), k ** -0.5), rnd("lnf.bias", (2 * n,), 0.1)
+        ge = GEGLU(k, n, init=False); ge.proj.weight = dev(tf, w); ge.proj.bias = dev(tf, bias)
+        close(ge(dev(tf, x), ln=ln).numpy(), O.geglu(xn, w, bias).numpy())

@@ -12,7 +12,7 @@ import numpy as np
 from .. import config
 from ..ff.group_norm import GroupNorm
 from ..ff.layer_norm import LayerNorm
-from ..ff.linear import Linear, linear_f16
+from ..ff.linear import Linear, fold_layer_norm, linear_f16, linear_ln_f16
 from ..ff.nn import FeedForward
 from ..native import hip
 from ..storage.tensor import DeviceArray, _sh
@@ -82,20 +82,32 @@ class CrossAttention:
             self._fused = (key, _concat_rows(ws))
         return self._fused[1]
 
+    def _folded(self, ln, self_attn):
+        """LayerNorm folded into the fused q|k|v weight (self-attention) or into to_q (cross-attention)."""
+        w = self._fused_weights(True) if self_attn else self.to_q.weight
+        key = (w.ptr, ln.weight.ptr, ln.bias.ptr)
+        if getattr(self, "_ln_fold", None) is None or self._ln_fold[0] != key:
+            self._ln_fold = (key, fold_layer_norm(w, None, ln))
+        return self._ln_fold[1]
+
     def project_kv(self, context):
         """(b, tk, 2C) fused K|V projection of the context (computed once per UNet call by the model)."""
         return linear_f16(context, self._fused_weights(False))
 
-    def __call__(self, x, context=None, residual=None, kv=None):
+    def __call__(self, x, context=None, residual=None, kv=None, ln=None):
+        """ln: a LayerNorm to apply to x first, folded into the q (or q|k|v) projection (x is then the RAW input)."""
         b, t, _ = x.shape
         nh, hs = self.num_heads, self.head_size
         c = nh * hs
         if context is None and kv is None:
-            qkv = linear_f16(x, self._fused_weights(True))            # (b, t, 3C): q | k | v
+            if ln is not None:
+                qkv = linear_ln_f16(x, self._folded(ln, True), ln.eps)
+            else:
+                qkv = linear_f16(x, self._fused_weights(True))        # (b, t, 3C): q | k | v
             q, k, v = qkv, qkv.view((b, t, 3 * c), "row", c), qkv.view((b, t, 3 * c), "row", 2 * c)
             tk, qs, ks = t, (t * 3 * c, hs, 3 * c), (t * 3 * c, hs, 3 * c)
         else:
-            q = linear_f16(x, self.to_q.weight)
+            q = linear_ln_f16(x, self._folded(ln, False), ln.eps) if ln is not None else linear_f16(x, self.to_q.weight)
             if kv is None:
                 kv = self.project_kv(context)
             if hasattr(kv, "ld"):                          # column slice of the UNet's step-level K|V GEMM
@@ -125,6 +137,11 @@ class BasicTransformerBlock:
         self.norm3 = LayerNorm(dim, init=init)
 
     def __call__(self, x, context=None, kv=None):
+        if config.fuse_layer_norm and x.shape[-1] % 64 == 0:
+            x = self.attn1(x, residual=x, ln=self.norm1)
+            x = self.attn2(x, context=context, residual=x, kv=kv, ln=self.norm2)
+            x = self.ff(x, residual=x, ln=self.norm3)
+            return x
         x = self.attn1(self.norm1(x), residual=x)
         x = self.attn2(self.norm2(x), context=context, residual=x, kv=kv)
         x = self.ff(self.norm3(x), residual=x)

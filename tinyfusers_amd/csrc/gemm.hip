@@ -23,6 +23,8 @@ struct GemmP {
   const half_t* x; const half_t* x2; const half_t* w; half_t* y;
   const half_t* bias; const half_t* bias_nc; const half_t* residual; float* partial;
   long long bias_nc_stride;
+  const float* ln_colsum;   // LayerNorm folded into this GEMM (see tf_linear_ln_f16): colsum[n] = sum_k w'[n,k]; NULL = off
+  float ln_eps;
   unsigned x_bytes, x2_bytes, w_bytes;
   int M, N, K;          // N = rows of w (2x the output width for GEGLU)
   int C1, C2, C;
@@ -78,10 +80,32 @@ constexpr int ring_slots(int bm, int bn) { int s = 163840 / ((bm + bn) * 128); r
 // ---- epilogue (consumer waves): write the wave's TM x TN fp32 tile through a per-wave row-major LDS scratch so
 // that global stores / residual loads are 16-B coalesced row segments instead of MFMA-layout 8-B fragments.
 template <int BM, int BN>
-__device__ __forceinline__ void igemm_scratch_write(f4 (&acc)[BN / 32][BM / 32], char* smem, int w4, int lane) {
+__device__ __forceinline__ void igemm_scratch_write(const GemmP& p, f4 (&acc)[BN / 32][BM / 32], float (&rs)[BM / 32], float (&rq)[BM / 32], char* smem,
+                                                    int n0, int w4, int lane) {
   constexpr int TM = BM / 2, TN = BN / 2, MJ = TM / 16, NI = TN / 16;
   constexpr int RS = TN + 4;                               // row stride (floats) keeps the f4 writes ~conflict-free
   const int lr = lane & 15, lg = lane >> 4;
+  if (p.ln_colsum) {
+    // LayerNorm fold: y = rstd[m] * (x . w'^T - mean[m] * colsum[n]); the row statistics were accumulated from the
+    // activation fragments in the K loop (each lane group saw a quarter of K: finish with two xor-shuffles)
+    const float invK = 1.0f / (float)p.K;
+    const int wave_n = w4 >> 1;
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+      float s_ = rs[j], q_ = rq[j];
+      s_ += __shfl_xor(s_, 16, 64); s_ += __shfl_xor(s_, 32, 64);
+      q_ += __shfl_xor(q_, 16, 64); q_ += __shfl_xor(q_, 32, 64);
+      float mean = s_ * invK;
+      float var = fmaxf(q_ * invK - mean * mean, 0.f);
+      float rstd = rsqrtf(var + p.ln_eps);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        int n = n0 + wave_n * TN + i * 16 + lg * 4;
+        f4 cs = n + 3 < p.N ? *reinterpret_cast<const f4*>(p.ln_colsum + n) : (f4){0.f, 0.f, 0.f, 0.f};
+        acc[i][j] = rstd * (acc[i][j] - mean * cs);
+      }
+    }
+  }
   float* sc = reinterpret_cast<float*>(smem) + (size_t)w4 * (TM * RS);
 #pragma unroll
   for (int i = 0; i < NI; ++i)
@@ -336,6 +360,21 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < MJ; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+  // LayerNorm fold: per-lane partial sum / sum of squares of this lane's slice of every activation row (v_dot2)
+  float rs[MJ], rq[MJ];
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) { rs[j] = 0.f; rq[j] = 0.f; }
+  auto ln_accum = [&](const h8& x, float& s_, float& q_) {
+    typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+    const hh2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hh2 v = {x[2 * e], x[2 * e + 1]};
+      s_ = __builtin_amdgcn_fdot2(v, one2, s_, false);
+      q_ = __builtin_amdgcn_fdot2(v, v, q_, false);
+    }
+  };
+  const bool ln_on = p.ln_colsum != nullptr;
   // fragment addresses inside a stage (swizzled chunk for k-step 0; k-step 1 is chunk ^ 4)
   int wa[NI], xa[MJ];
 #pragma unroll
@@ -372,6 +411,10 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
         for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        if (ln_on) {
+#pragma unroll
+          for (int j = 0; j < MJ; ++j) ln_accum(xf[j], rs[j], rq[j]);
+        }
       }
     }
   } else {
@@ -406,6 +449,12 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[k2][i], xf[k2][j], acc[i][j], 0, 0, 0);
+    if (ln_on) {
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) ln_accum(xf[k2][j], rs[j], rq[j]);
+    }
   };
   __builtin_amdgcn_s_barrier();                           // barrier P: tile 0 landed
   asm volatile("" ::: "memory");
@@ -437,7 +486,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
       for (int j = 0; j < MJ; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-  igemm_scratch_write<BM, BN>(acc, smem, w4, lane);
+  igemm_scratch_write<BM, BN>(p, acc, rs, rq, smem, n0, w4, lane);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                           // barrier Y
   asm volatile("" ::: "memory");
@@ -512,6 +561,28 @@ __global__ void __launch_bounds__(256) k_gemv(half_t* __restrict__ y, const half
       if (l == 0) y[(long long)m * N + n] = (half_t)(v + (bias ? (float)bias[n] : 0.f));
     }
   }
+}
+
+// LayerNorm fold of a Linear weight (one wave per output row n):
+//   w'[n,k] = fp16(w[n,k] * gamma[k]);  colsum[n] = sum_k float(w'[n,k]);  bias'[n] = sum_k beta[k] * w[n,k] + bias[n]
+__global__ void __launch_bounds__(256) k_ln_fold(half_t* __restrict__ wo, half_t* __restrict__ bo, float* __restrict__ colsum, const half_t* __restrict__ w,
+                                                 const half_t* __restrict__ bias, const half_t* __restrict__ gamma, const half_t* __restrict__ beta, int N, int K) {
+  int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+  int n = blockIdx.x * 4 + wv;
+  if (n >= N) return;
+  float cs = 0.f, bs = 0.f;
+  for (int k = l * 8; k < K; k += 512) {
+    h8 v = *reinterpret_cast<const h8*>(w + (long long)n * K + k), g = *reinterpret_cast<const h8*>(gamma + k), b = *reinterpret_cast<const h8*>(beta + k), o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      o[j] = (half_t)((float)v[j] * (float)g[j]);
+      cs += (float)o[j];
+      bs += (float)b[j] * (float)v[j];
+    }
+    *reinterpret_cast<h8*>(wo + (long long)n * K + k) = o;
+  }
+  cs = wave_sum(cs); bs = wave_sum(bs);
+  if (l == 0) { colsum[n] = cs; bo[n] = (half_t)(bs + (bias ? (float)bias[n] : 0.f)); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -628,7 +699,7 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
     if (bm == 128 && p.M <= 64) continue;
     if (bn >= 128 && p.N <= 64 && ci != 5) continue;
     for (int sk = 1; sk <= 32; sk *= 2) {
-      if (sk > 1 && (p.act == 1 || p.ktiles / sk < 4 || !workspace || (size_t)sk * p.M * p.N * 4 > workspace_bytes)) break;
+      if (sk > 1 && (p.act == 1 || p.ln_colsum || p.ktiles / sk < 4 || !workspace || (size_t)sk * p.M * p.N * 4 > workspace_bytes)) break;
       long long blocks = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * sk;
       if (sk > 1 && blocks > 1024) break;
       for (int wide = 0; wide < 2; ++wide) {
@@ -666,7 +737,7 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     t.c = {force_bm, force_bn, force_split > 0 ? force_split : 1};
     t.order = g_force_order > 0 ? 1 : 0;
   } else if (g_autotune && !g_dbg) {
-    std::array<int, 10> key = {p.M, p.N, p.K, p.C1, p.C2, p.S, p.stride, p.ups, p.act, (p.bias ? 1 : 0) | (p.residual ? 2 : 0) | (p.bias_nc ? 4 : 0)};
+    std::array<int, 10> key = {p.M, p.N, p.K, p.C1, p.C2, p.S, p.stride, p.ups, p.act, (p.bias ? 1 : 0) | (p.residual ? 2 : 0) | (p.bias_nc ? 4 : 0) | (p.ln_colsum ? 8 : 0)};
     auto it = g_tuned.find(key);
     if (it != g_tuned.end()) { t = it->second; tuned = true; }
     else {
@@ -680,6 +751,7 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
       }
     }
   }
+  if (p.ln_colsum) t.c.splitk = 1;                       // row statistics need the whole K range in one block
   if (t.c.splitk > 1) {
     size_t need = (size_t)t.c.splitk * p.M * p.N * sizeof(float);
     if (!workspace || workspace_bytes < need) t.c.splitk = 1;   // degrade gracefully: correctness does not depend on split-K
@@ -869,6 +941,35 @@ int tf_linear_f16(void* y, const void* x, const void* w, const void* bias, const
     p.x_bytes = (unsigned)xb; p.x2_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
   }
   return run_gemm(p, workspace, workspace_bytes, g_force_bm, g_force_bn, g_force_split, tf_hs(s));
+}
+
+int tf_ln_fold_weights_f16(void* w_out, void* bias_out, void* colsum_out, const void* w, const void* bias, const void* gamma, const void* beta,
+                           int N, int K, tfStream_t s) {
+  TF_REQUIRE(w_out && bias_out && colsum_out && w && gamma && beta && N >= 1 && K % 8 == 0, "tf_ln_fold_weights_f16: bad arguments (K=%d)", K);
+  hipLaunchKernelGGL(k_ln_fold, dim3(ceil_div(N, 4)), dim3(256), 0, tf_hs(s), (half_t*)w_out, (half_t*)bias_out, (float*)colsum_out, (const half_t*)w,
+                     (const half_t*)bias, (const half_t*)gamma, (const half_t*)beta, N, K);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+
+int tf_linear_ln_f16(void* y, const void* x, const void* w_folded, const void* bias_folded, const void* colsum, const void* residual, int M, int N,
+                     int K, int act, float eps, tfStream_t s) {
+  TF_REQUIRE(y && x && w_folded && bias_folded && colsum, "tf_linear_ln_f16: null tensor");
+  TF_REQUIRE(M >= 0 && N >= 1 && K >= 64 && K % 64 == 0, "tf_linear_ln_f16: K=%d must be a positive multiple of 64", K);
+  TF_REQUIRE(act == 0 || act == 1, "tf_linear_ln_f16: act=%d", act);
+  TF_REQUIRE((act == 1 ? N % 16 == 0 : N % 4 == 0), "tf_linear_ln_f16: N=%d must be a multiple of 4 (16 for GEGLU)", N);
+  if (M == 0) return TF_OK;
+  GemmP p = {};
+  p.x = (const half_t*)x; p.w = (const half_t*)w_folded; p.y = (half_t*)y; p.bias = (const half_t*)bias_folded; p.residual = (const half_t*)residual;
+  p.ln_colsum = (const float*)colsum; p.ln_eps = eps;
+  p.M = M; p.N = act == 1 ? 2 * N : N; p.K = K; p.C1 = K; p.C2 = 0; p.C = K;
+  p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.HoWo = M; p.S = 1; p.stride = 1; p.pad = 0; p.ups = 0; p.act = act;
+  {
+    long long xb = (long long)M * K * 2, wb = (long long)p.N * K * 2;
+    TF_REQUIRE(xb < (1LL << 31) && wb < (1LL << 31), "tf_linear_ln_f16: tensors must be < 2 GiB each");
+    p.x_bytes = (unsigned)xb; p.x2_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+  }
+  return run_gemm(p, nullptr, 0, g_force_bm, g_force_bn, g_force_split, tf_hs(s));
 }
 
 int tf_gemv_f16(void* y, const void* x, const void* w, const void* bias, int M, int N, int K, int silu_input, tfStream_t s) {

@@ -32,6 +32,28 @@ def gemv_f16(x, w, b=None, silu_input=False):
     return y
 
 
+def fold_layer_norm(w, b, ln):
+    """(w', bias', colsum) of Linear(LayerNorm(.)) for tf_linear_ln_f16; w (N,K), b (N,) or None, ln a LayerNorm."""
+    n, k = w.shape
+    wf = DeviceArray.empty((n, k), np.float16, "row")
+    bf = DeviceArray.empty((n,), np.float16, "row")
+    cs = DeviceArray.empty((n,), np.float32, "row")
+    hip.tf_ln_fold_weights_f16(wf.ptr, bf.ptr, cs.ptr, w.ptr, b.ptr if b is not None else None, ln.weight.ptr, ln.bias.ptr, n, k, _sh())
+    return wf, bf, cs
+
+
+def linear_ln_f16(x, folded, eps, residual=None, act=0, out_features=None):
+    """y = act(Linear(LayerNorm(x))) + residual in one launch; ``folded`` from fold_layer_norm."""
+    wf, bf, cs = folded
+    K = x.shape[-1]
+    rows = x.size // K
+    n_out = out_features if out_features is not None else wf.shape[0]
+    y = DeviceArray.empty(x.shape[:-1] + (n_out,), np.float16, "row")
+    hip.tf_linear_ln_f16(y.ptr, x.ptr, wf.ptr, bf.ptr, cs.ptr, residual.ptr if residual is not None else None, rows, n_out, K, act,
+                         float(np.asarray(eps).reshape(-1)[0]), _sh())
+    return y
+
+
 class Linear:
     def __init__(self, in_features, out_features, bias=True, init=True):
         self.in_features, self.out_features = in_features, out_features

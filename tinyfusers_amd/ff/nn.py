@@ -5,7 +5,7 @@ import numpy as np
 
 from ..native import hip
 from ..storage.tensor import DeviceArray, Tensor, _sh
-from .linear import Linear, linear_f16
+from .linear import Linear, fold_layer_norm, linear_f16, linear_ln_f16
 
 
 def pack_geglu(weight, bias):
@@ -35,7 +35,22 @@ class GEGLU:
             self._packed = (key,) + pack_geglu(self.proj.weight, self.proj.bias)
         return self._packed[1], self._packed[2]
 
-    def __call__(self, x):
+    def _pack_ln(self, ln):
+        key = (self.proj.weight.ptr, self.proj.bias.ptr, ln.weight.ptr, ln.bias.ptr)
+        if getattr(self, "_packed_ln", None) is None or self._packed_ln[0] != key:
+            wf, bf, cs = fold_layer_norm(self.proj.weight, self.proj.bias, ln)       # fold first ...
+            wp, bp = pack_geglu(wf, bf)                                            # ... then interleave value | gate blocks
+            n = self.dim_out
+            csp = DeviceArray.empty((2 * n,), np.float32, "row")
+            hip.tf_memcpy_2d_async(csp.ptr, 128, cs.ptr, 64, 64, n // 16, _sh())
+            hip.tf_memcpy_2d_async(csp.ptr + 64, 128, cs.ptr + n * 4, 64, 64, n // 16, _sh())
+            self._packed_ln = (key, (wp, bp, csp))
+        return self._packed_ln[1]
+
+    def __call__(self, x, ln=None):
+        if ln is not None:
+            assert self.dim_out % 16 == 0 and self.proj.bias is not None and x.shape[-1] % 64 == 0
+            return linear_ln_f16(x, self._pack_ln(ln), ln.eps, act=1, out_features=self.dim_out)
         if self.dim_out % 16 == 0 and self.proj.bias is not None:
             wp, bp = self._pack()
             return linear_f16(x, wp, bp, None, act=1, out_features=self.dim_out)
@@ -53,8 +68,8 @@ class FeedForward:
             Linear(dim * mult, dim, init=init),
         ]
 
-    def __call__(self, x, residual=None):
-        h = self.net[0](x)
+    def __call__(self, x, residual=None, ln=None):
+        h = self.net[0](x, ln=ln) if ln is not None else self.net[0](x)
         return self.net[2](h, residual=residual)
 
 
