@@ -80,30 +80,21 @@ constexpr int ring_slots(int bm, int bn) { int s = 163840 / ((bm + bn) * 128); r
 // ---- epilogue (consumer waves): write the wave's TM x TN fp32 tile through a per-wave row-major LDS scratch so
 // that global stores / residual loads are 16-B coalesced row segments instead of MFMA-layout 8-B fragments.
 template <int BM, int BN>
-__device__ __forceinline__ void igemm_scratch_write(const GemmP& p, f4 (&acc)[BN / 32][BM / 32], float (&rs)[BM / 32], float (&rq)[BM / 32], char* smem,
-                                                    int n0, int w4, int lane) {
+__device__ __forceinline__ void igemm_scratch_write(const GemmP& p, f4 (&acc)[BN / 32][BM / 32], const f4 (&csum)[BN / 32], char* smem, int w4, int lane) {
   constexpr int TM = BM / 2, TN = BN / 2, MJ = TM / 16, NI = TN / 16;
   constexpr int RS = TN + 4;                               // row stride (floats) keeps the f4 writes ~conflict-free
   const int lr = lane & 15, lg = lane >> 4;
   if (p.ln_colsum) {
-    // LayerNorm fold: y = rstd[m] * (x . w'^T - mean[m] * colsum[n]); the row statistics were accumulated from the
-    // activation fragments in the K loop (each lane group saw a quarter of K: finish with two xor-shuffles)
-    const float invK = 1.0f / (float)p.K;
-    const int wave_n = w4 >> 1;
+    // LayerNorm fold: y = rstd[m] * (x . w'^T - mean[m] * colsum[n]); (mean, rstd) of every row of the block were
+    // produced by the loader waves from the activation tiles they staged (LDS table behind the transpose scratch)
+    const f2* stats = reinterpret_cast<const f2*>(smem + 4 * TM * RS * 4);
+    const int wave_m = w4 & 1;
 #pragma unroll
     for (int j = 0; j < MJ; ++j) {
-      float s_ = rs[j], q_ = rq[j];
-      s_ += __shfl_xor(s_, 16, 64); s_ += __shfl_xor(s_, 32, 64);
-      q_ += __shfl_xor(q_, 16, 64); q_ += __shfl_xor(q_, 32, 64);
-      float mean = s_ * invK;
-      float var = fmaxf(q_ * invK - mean * mean, 0.f);
-      float rstd = rsqrtf(var + p.ln_eps);
+      f2 st_ = stats[wave_m * TM + j * 16 + lr];
+      float mean = st_[0], rstd = st_[1];
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        int n = n0 + wave_n * TN + i * 16 + lg * 4;
-        f4 cs = n + 3 < p.N ? *reinterpret_cast<const f4*>(p.ln_colsum + n) : (f4){0.f, 0.f, 0.f, 0.f};
-        acc[i][j] = rstd * (acc[i][j] - mean * cs);
-      }
+      for (int i = 0; i < NI; ++i) acc[i][j] = rstd * (acc[i][j] - mean * csum[i]);
     }
   }
   float* sc = reinterpret_cast<float*>(smem) + (size_t)w4 * (TM * RS);
@@ -263,6 +254,30 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
       }
     }
     const int Hl = p.H << p.ups, Wl = p.W << p.ups;        // logical (post-upsample) input extent
+    // LayerNorm fold: this wave also sums (x, x^2) over the activation rows it staged (it reads back its own LDS-DMA
+    // pieces once they have landed: idle VALU of the loaders, nothing added to the consumers' MFMA stream)
+    const bool ln_on = p.ln_colsum != nullptr;
+    float ls[LPS], lq[LPS];
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) { ls[i] = 0.f; lq[i] = 0.f; }
+    auto ln_tile = [&](int slot) {
+      typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+      const hh2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
+      const char* base = smem + slot * STAGE;
+#pragma unroll
+      for (int i = 0; i < LPS; ++i) {
+        const int g = w4 + 4 * i;
+        if (g * 8 < BM) {
+          h8 x = *reinterpret_cast<const h8*>(base + g * 1024 + lane * 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            hh2 v = {x[2 * e], x[2 * e + 1]};
+            ls[i] = __builtin_amdgcn_fdot2(v, one2, ls[i], false);
+            lq[i] = __builtin_amdgcn_fdot2(v, v, lq[i], false);
+          }
+        }
+      }
+    };
     int st_r, st_s, st_c;                                  // wave-uniform (tap, channel) of the next tile to stage
     {
       int kg0 = kt_begin * 64;
@@ -325,6 +340,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
         __builtin_amdgcn_s_barrier();                     // barrier(it)
         asm volatile("" ::: "memory");
         if (it + 1 < nt) stage((it + 1) & 1, kt_begin + it + 1);
+        if (ln_on) ln_tile(it & 1);                       // off the barrier's critical path; slot refilled after barrier(it+1)
       }
     } else {
       // Ring protocol (NS slots, tile t lives in slot t % NS).  Barrier P hands tile 0 to the consumers; barrier(it)
@@ -335,17 +351,45 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
         if (s_ < nt) stage(s_, kt_begin + s_);
       wait_stages<LPS, NS - 1>(nt - 1);                    // tile 0 landed; up to NS-1 newer stages in flight
       __builtin_amdgcn_s_barrier();                       // barrier P
+      if (ln_on && nt > 0) ln_tile(0);                    // slot 0 is refilled only after barrier(0)
       asm volatile("" ::: "memory");
       for (int it = 0; it < nt; ++it) {
         if (it + 1 < nt) wait_stages<LPS, NS - 2>(nt - 2 - it);   // tile it+1 landed (ring holds up to tile it+NS-1 here)
         __builtin_amdgcn_s_barrier();                     // barrier(it)
         asm volatile("" ::: "memory");
         if (it + NS < nt) stage(it % NS, kt_begin + it + NS);
+        if (ln_on && it + 1 < nt) ln_tile((it + 1) % NS);  // tile it+1 stays in its slot until barrier(it+1)
+      }
+    }
+    // LayerNorm fold: finish (mean, rstd) of the rows this wave staged while the consumers drain their last MFMAs
+    f2 lstat[LPS];
+    if (ln_on) {
+      const float invK = 1.0f / (float)p.K;
+#pragma unroll
+      for (int i = 0; i < LPS; ++i) {
+        float s_ = ls[i], q_ = lq[i];
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { s_ += __shfl_xor(s_, o, 64); q_ += __shfl_xor(q_, o, 64); }
+        float mean = s_ * invK;
+        float var = fmaxf(q_ * invK - mean * mean, 0.f);
+        lstat[i] = (f2){mean, rsqrtf(var + p.ln_eps)};
       }
     }
     __builtin_amdgcn_s_barrier();                         // barrier X: matches the consumers' "ring is free" barrier
     asm volatile("" ::: "memory");
     if (p.dbg & 1) return;
+    if (ln_on) {
+      constexpr int TMl = BM / 2, TNl = BN / 2;
+      f2* stats = reinterpret_cast<f2*>(smem + 4 * TMl * (TNl + 4) * 4);
+#pragma unroll
+      for (int i = 0; i < LPS; ++i) {
+        const int g = w4 + 4 * i;
+        if (g * 8 < BM && (lane & 7) == 0) stats[8 * g + sub] = lstat[i];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                       // barrier Z
+      asm volatile("" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                         // barrier Y: the consumers' tiles are in the LDS scratch
     asm volatile("" ::: "memory");
     igemm_epilogue<BM, BN>(p, smem, m0, n0, split, w4, 1, lane);
@@ -360,21 +404,13 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < MJ; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
-  // LayerNorm fold: per-lane partial sum / sum of squares of this lane's slice of every activation row (v_dot2)
-  float rs[MJ], rq[MJ];
+  // LayerNorm fold: this lane's colsum values, fetched now so their latency hides under the K loop
+  f4 csum[NI];
 #pragma unroll
-  for (int j = 0; j < MJ; ++j) { rs[j] = 0.f; rq[j] = 0.f; }
-  auto ln_accum = [&](const h8& x, float& s_, float& q_) {
-    typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
-    const hh2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      hh2 v = {x[2 * e], x[2 * e + 1]};
-      s_ = __builtin_amdgcn_fdot2(v, one2, s_, false);
-      q_ = __builtin_amdgcn_fdot2(v, v, q_, false);
-    }
-  };
-  const bool ln_on = p.ln_colsum != nullptr;
+  for (int i = 0; i < NI; ++i) {
+    int n = n0 + wave_n * TN + i * 16 + lg * 4;
+    csum[i] = (p.ln_colsum && n + 3 < p.N) ? *reinterpret_cast<const f4*>(p.ln_colsum + n) : (f4){0.f, 0.f, 0.f, 0.f};
+  }
   // fragment addresses inside a stage (swizzled chunk for k-step 0; k-step 1 is chunk ^ 4)
   int wa[NI], xa[MJ];
 #pragma unroll
@@ -411,10 +447,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
         for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-        if (ln_on) {
-#pragma unroll
-          for (int j = 0; j < MJ; ++j) ln_accum(xf[j], rs[j], rq[j]);
-        }
+
       }
     }
   } else {
@@ -449,12 +482,6 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[k2][i], xf[k2][j], acc[i][j], 0, 0, 0);
-    if (ln_on) {
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-        for (int j = 0; j < MJ; ++j) ln_accum(xf[k2][j], rs[j], rq[j]);
-    }
   };
   __builtin_amdgcn_s_barrier();                           // barrier P: tile 0 landed
   asm volatile("" ::: "memory");
@@ -486,7 +513,11 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
       for (int j = 0; j < MJ; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-  igemm_scratch_write<BM, BN>(p, acc, rs, rq, smem, n0, w4, lane);
+  if (p.ln_colsum) {
+    __builtin_amdgcn_s_barrier();                         // barrier Z: the loaders' (mean, rstd) table is in LDS
+    asm volatile("" ::: "memory");
+  }
+  igemm_scratch_write<BM, BN>(p, acc, csum, smem, w4, lane);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                           // barrier Y
   asm volatile("" ::: "memory");
@@ -633,7 +664,7 @@ static int launch_cfg3(const GemmP& p, hipStream_t st) {
   constexpr int TM = BM / 2, TN = BN / 2;
   constexpr int ring = (WIDE ? 2 : ring_slots(BM, BN)) * (BM + BN) * 128;
   constexpr int scratch = 4 * TM * (TN + 4) * 4;         // epilogue transpose scratch overlays the ring
-  constexpr int smem = ring > scratch ? ring : scratch;
+  constexpr int smem = ring > scratch + BM * 8 ? ring : scratch + BM * 8;   // + the LayerNorm (mean, rstd) table behind the scratch
   static bool attr_set = false;
   if (!attr_set) {
     TF_HIP(hipFuncSetAttribute((const void*)k_igemm<BM, BN, GENERIC, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
