@@ -81,3 +81,9 @@ class _Hip:
 
 
 hip = _Hip()
+
+# per-shape GEMM configurations measured on MI355X for the SD-1.x step (tools/tune_best.sh); shapes that are not in the
+# table are autotuned on their first eager call
+_TUNE = os.path.join(os.path.dirname(_HERE), "gemm_tune_gfx950.txt")
+if os.path.exists(_TUNE):
+    lib.tf_gemm_tune_load(_TUNE.encode())
