@@ -6,7 +6,11 @@
 // prefetch, two LDS stages).  Per wave and tile:
 //   S^T (64 keys x 32 queries) = K_tile . Q^T      -- K rows are the MFMA A operand (ds_read_b128),
 //                                                     Q fragments stay in registers for the whole kernel;
-//   softmax along keys is lane-local (query = lane & 15) plus two xor-shuffles across the 4 lane groups;
+//   softmax along keys is lane-local (query = lane & 15) plus two xor-shuffles across the 4 lane groups.  The loop is
+//   VALU-issue bound at d = 40 (v_exp 8 cycles, everything else 4), so the softmax is cut to max3 + exp2 + cvt per
+//   score: Q is pre-scaled by log2(e)/sqrt(d), the running reference maximum enters as the INITIAL ACCUMULATOR of
+//   the QK^T chain (S' = K Q^T - m needs no subtract), and the row sums come out of the PV product itself through
+//   a column of ones in the padding of the V tile (column DV-1 >= HS), rescaled together with O for free;
 //   O^T (d x 32 queries) += V^T . P^T              -- P^T is already in B-operand layout (accumulator ->
 //                                                     operand, keys permuted so each lane group owns 8
 //                                                     consecutive keys), V^T comes from the row-major V
@@ -31,7 +35,7 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
   constexpr int KS = DQK + 8;                 // K row stride (halves); 16-B multiple
   constexpr int VS = DV + 8;                  // V row stride (halves); 16-B multiple
   constexpr int NKS = DQK / 32;               // k-steps of QK^T
-  constexpr int NDT = DV / 16;                // d tiles of PV
+  constexpr int NDT = DV / 16;                // d tiles of PV (the last one holds the ones column: DV > HS)
   constexpr int CPR = DV / 8;                 // 16-B chunks per staged row (covers HS <= DV)
   constexpr int NCH = (64 * CPR + 255) / 256; // staging rounds per tensor
   constexpr int STAGE_H = 64 * KS + 64 * VS;  // halves per stage
@@ -57,14 +61,17 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       int d0 = ks * 32 + lg * 8;
-      qf[qt][ks] = (qi < p.Tq && d0 < p.HS) ? *reinterpret_cast<const h8*>(qb + qi * p.q_st + d0) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+      h8 qv = (qi < p.Tq && d0 < p.HS) ? *reinterpret_cast<const h8*>(qb + qi * p.q_st + d0) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qv[j] = (half_t)((float)qv[j] * p.scale_log2e);
+      qf[qt][ks] = qv;
     }
   }
 
   f4 ot[NDT][2];
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) { ot[dt][0] = (f4){0, 0, 0, 0}; ot[dt][1] = (f4){0, 0, 0, 0}; }
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  float m_run[2] = {0.f, 0.f};    // reference maximum (log2 units); set from the first tile, then only raised
 
   int ntiles = (p.Tk + 63) / 64;
   if (p.causal) {   // keys beyond the block's last query are never needed
@@ -114,6 +121,7 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
   load_tile(0);
   __syncthreads();           // zero-fill complete before the first tile lands on top of it
   store_tile(0);
+  if (tid < 128) smem[(tid >> 6) * STAGE_H + 64 * KS + (tid & 63) * VS + DV - 1] = (half_t)1.0f;   // ones column -> row sums
   __syncthreads();
 
   for (int t = 0; t < ntiles; ++t) {
@@ -124,15 +132,15 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
 
     // ---- S^T = K Q^T : st[kt][qt], key(kt, row) = 32 (kt>>1) + 8 (row>>2) + 4 (kt&1) + (row&3)
     f4 st[4][2];
-    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f4 init4[2] = {{-m_run[0], -m_run[0], -m_run[0], -m_run[0]}, {-m_run[1], -m_run[1], -m_run[1], -m_run[1]}};
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       int krow = 32 * (kt >> 1) + 8 * (lr >> 2) + 4 * (kt & 1) + (lr & 3);
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         h8 kf = *reinterpret_cast<const h8*>(ks_ + krow * KS + ks * 32 + lg * 8);
-        st[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], ks == 0 ? zero4 : st[kt][0], 0, 0, 0);
-        st[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], ks == 0 ? zero4 : st[kt][1], 0, 0, 0);
+        st[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], ks == 0 ? init4[0] : st[kt][0], 0, 0, 0);
+        st[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], ks == 0 ? init4[1] : st[kt][1], 0, 0, 0);
       }
     }
     // ---- masks: this lane's keys are t*64 + 32 (kt>>1) + 8 lg + 4 (kt&1) + reg
@@ -150,46 +158,48 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
           }
         }
     }
-    // ---- online softmax (per query column) in log2 units, P^T fragments.  The running reference max only moves when
-    // some query's tile max exceeds it by more than RESCALE_THR (then every accumulator of the wave is rescaled once),
-    // so P <= 2^RESCALE_THR: harmless in fp16 (fp32 accumulation), and the O-wide multiply leaves the steady state.
+    // ---- online softmax (per query column) in log2 units, P^T fragments.  st already holds s - m_run.  The reference
+    // max is set by the first tile and afterwards only moves when some query's tile max exceeds it by more than
+    // RESCALE_THR (then every accumulator of the wave is rescaled once), so P <= 2^RESCALE_THR: harmless in fp16 (fp32
+    // accumulation), and the O-wide multiply leaves the steady state.
     constexpr float RESCALE_THR = 6.0f;
     float mx[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       float m0_ = fmaxf(fmaxf(st[0][qt][0], st[0][qt][1]), fmaxf(st[0][qt][2], st[0][qt][3]));
 #pragma unroll
-      for (int kt = 1; kt < 4; ++kt) m0_ = fmaxf(fmaxf(m0_, fmaxf(st[kt][qt][0], st[kt][qt][1])), fmaxf(st[kt][qt][2], st[kt][qt][3]));
+      for (int kt = 1; kt < 4; ++kt) {
+        m0_ = fmaxf(fmaxf(m0_, st[kt][qt][0]), st[kt][qt][1]);
+        m0_ = fmaxf(fmaxf(m0_, st[kt][qt][2]), st[kt][qt][3]);
+      }
       m0_ = fmaxf(m0_, __shfl_xor(m0_, 16, 64));
       m0_ = fmaxf(m0_, __shfl_xor(m0_, 32, 64));
-      mx[qt] = m0_ * p.scale_log2e;
+      mx[qt] = m0_;
     }
-    if (__any((mx[0] > m_run[0] + RESCALE_THR) || (mx[1] > m_run[1] + RESCALE_THR))) {
+    if (t == 0 || __any((mx[0] > RESCALE_THR) || (mx[1] > RESCALE_THR))) {
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
-        float m_new = fmaxf(m_run[qt], mx[qt]);
-        float alpha = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f(m_run[qt] - m_new);   // m_run = -inf -> 0
-        l_run[qt] *= alpha;
-        m_run[qt] = m_new;
+        // first tile: adopt its max whatever the sign (O is still zero, nothing to rescale); later: raise only
+        float delta = mx[qt] == -INFINITY ? 0.f : (t == 0 ? mx[qt] : fmaxf(mx[qt], 0.f));
+        m_run[qt] += delta;
+        if (t != 0) {
+          float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) ot[dt][qt] *= alpha;
+          for (int dt = 0; dt < NDT; ++dt) ot[dt][qt] *= alpha;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) st[kt][qt][e] -= delta;
       }
     }
     h8 pf[2][2];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      const float mc = m_run[qt] == -INFINITY ? 0.f : m_run[qt];
-      float sum = 0.f;
+    for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float pv = __builtin_amdgcn_exp2f(st[kt][qt][e] * p.scale_log2e - mc);
-          sum += pv;
-          pf[kt >> 1][qt][(kt & 1) * 4 + e] = (half_t)pv;
-        }
-      l_run[qt] += sum;
-    }
+        for (int e = 0; e < 4; ++e) pf[kt >> 1][qt][(kt & 1) * 4 + e] = (half_t)__builtin_amdgcn_exp2f(st[kt][qt][e]);
     // ---- O^T += V^T P^T
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
@@ -211,9 +221,8 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
   half_t* ob = p.o + b * p.o_sb + h * p.o_sh;
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    float l = l_run[qt];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    // row sum = O^T row DV-1 (the ones column of V): last accumulator tile, lane group 3, register 3
+    float l = __shfl(ot[NDT - 1][qt][3], lr + 48, 64);
     float inv = l > 0.f ? 1.0f / l : 0.f;
     int qi = qblk + qt * 16 + lr;
     if (qi < p.Tq) {
@@ -263,11 +272,14 @@ extern "C" int tf_sdpa_f16(void* o, const void* q, const void* k, const void* v,
   p.scale_log2e = (1.0f / sqrtf((float)HS)) * 1.4426950408889634f;
   p.causal = causal;
   hipStream_t st = tf_hs(s);
-  if (HS <= 32) return launch_sdpa<32, 32>(p, st);
-  if (HS <= 48) return launch_sdpa<64, 48>(p, st);
-  if (HS <= 64) return launch_sdpa<64, 64>(p, st);
-  if (HS <= 80) return launch_sdpa<96, 80>(p, st);
-  if (HS <= 96) return launch_sdpa<96, 96>(p, st);
-  if (HS <= 128) return launch_sdpa<128, 128>(p, st);
-  return launch_sdpa<160, 160>(p, st);
+  // (DQK, DV) = (HS rounded up to 32, HS + 1 rounded up to 16): the V tile always has room for the ones column
+  if (HS <= 32) return launch_sdpa<32, 48>(p, st);
+  if (HS <= 40) return launch_sdpa<64, 48>(p, st);
+  if (HS <= 56) return launch_sdpa<64, 64>(p, st);
+  if (HS <= 64) return launch_sdpa<64, 80>(p, st);
+  if (HS <= 88) return launch_sdpa<96, 96>(p, st);
+  if (HS <= 96) return launch_sdpa<96, 112>(p, st);
+  if (HS <= 120) return launch_sdpa<128, 128>(p, st);
+  if (HS <= 128) return launch_sdpa<128, 144>(p, st);
+  return launch_sdpa<160, 176>(p, st);
 }
