@@ -196,6 +196,8 @@ def test_conv2d_concat_and_upsample(tf, c1, c2, cout, hw, k):
 SDPA_CASES = [  # b, nh, tq, tk, hs
     (2, 2, 16, 16, 8), (2, 2, 16, 5, 8), (1, 3, 100, 77, 40), (2, 8, 256, 256, 160), (2, 8, 64, 77, 160), (2, 8, 1024, 1024, 80),
     (2, 8, 4096, 77, 40), (1, 2, 4096, 4096, 40), (2, 2, 130, 130, 32), (1, 12, 77, 77, 64), (1, 1, 200, 333, 128), (1, 2, 70, 70, 96),
+    (1, 2, 200, 200, 40), (1, 2, 130, 130, 80), (1, 1, 192, 192, 64), (1, 1, 256, 256, 128), (1, 1, 129, 65, 160), (1, 1, 1, 1, 40),
+    (1, 2, 250, 250, 56), (1, 1, 64, 300, 48),
 ]
 
 
@@ -222,6 +224,26 @@ def test_sdpa_online_softmax_rescale(tf):
     k[0, 0, 70] = q[0, 0, 33] * 4.0
     got = scaled_dot_product_attention(dev(tf, q, "row"), dev(tf, k, "row"), dev(tf, v, "row")).numpy()
     close(got, O.scaled_dot_product_attention(q, k, v).numpy())
+
+
+@pytest.mark.parametrize("hs", [40, 96])
+def test_sdpa_first_tile_far_below_zero(tf, hs):
+    """Every score of the first key tile is hugely negative (and later tiles huge positive): the reference maximum is
+    adopted from the first tile whatever its sign, then raised; nothing may underflow to an all-zero row."""
+    from oracle import ops as O
+    from tinyfusers_amd.attention.sdpa import scaled_dot_product_attention
+    b, nh, t = 1, 2, 192
+    q = rnd("ft.q", (b, nh, t, hs), 1.0)
+    k = rnd("ft.k", (b, nh, t, hs), 0.05)
+    v = rnd("ft.v", (b, nh, t, hs))
+    k[:, :, :64] -= 3.0 * np.sign(q.mean(axis=2, keepdims=True)) * np.abs(q).mean()   # push tile 0 scores down
+    q = q + 2.0 * np.sign(q.mean(axis=2, keepdims=True))                              # common direction for all queries
+    k[:, :, 128:] += 1.5 * np.sign(q.mean(axis=2, keepdims=True))                     # tile 2 far above tile 0
+    q, k = q.astype(np.float16).astype(np.float32), k.astype(np.float16).astype(np.float32)
+    got = scaled_dot_product_attention(dev(tf, q, "row"), dev(tf, k, "row"), dev(tf, v, "row")).numpy()
+    ref = O.scaled_dot_product_attention(q, k, v).numpy()
+    assert np.isfinite(got).all()
+    close(got, ref)
 
 
 def test_softmax_rows_and_own_runtime_kernels(tf):

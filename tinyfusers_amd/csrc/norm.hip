@@ -67,6 +67,7 @@ __global__ void k_gn_stats(float* __restrict__ partial, const half_t* __restrict
 // partials of its image into (mean, rstd) per group (8 lanes per group strided over the chunks + xor-shuffles, fp64,
 // fixed order -> every block gets the same bits) -- cheaper than a separate finalize launch; then many small blocks
 // stream the tensor (the kernel is latency-bound otherwise).
+#define GN_APPLY_PPT 4
 __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ x2, const half_t* __restrict__ gamma,
                            const half_t* __restrict__ beta, const float* __restrict__ partial, int HW, int C1, int C2, int G, float eps,
                            int do_silu, int chunks, int pix_per_block, int CV, int RPB) {
@@ -74,6 +75,27 @@ __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x,
   int n = blockIdx.y;
   int C = C1 + C2, cpg = C / G;
   int t = threadIdx.x;
+  // this thread's slice of the tensor: issue its first loads (and gamma / beta) BEFORE the statistics fold, so the three
+  // dependent global round trips (partials -> gamma/beta -> x) of a latency-bound launch collapse into one
+  const int cv = t % CV, rr = t / CV;
+  const bool active = rr < RPB;
+  const int c = cv * 8;
+  const half_t* base = x;
+  int ld = C1;
+  if (active) {
+    if (c < C1) { base = x + (long long)n * HW * C1 + c; ld = C1; }
+    else { base = x2 + (long long)n * HW * C2 + (c - C1); ld = C2; }
+  }
+  const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+  h8 gm, bt, v[GN_APPLY_PPT];                            // pix_per_block == GN_APPLY_PPT * RPB (gn_geometry)
+  if (active) {
+    if (gamma) { gm = *reinterpret_cast<const h8*>(gamma + c); bt = *reinterpret_cast<const h8*>(beta + c); }
+#pragma unroll
+    for (int i = 0; i < GN_APPLY_PPT; ++i) {
+      int p = p0 + rr + i * RPB;
+      if (p < p1) v[i] = *reinterpret_cast<const h8*>(base + (long long)p * ld);
+    }
+  }
   {
     const int sub = t & 7;
     const int gstep = blockDim.x >> 3;               // blockDim.x is a multiple of 8 (CV*RPB threads, padded below)
@@ -81,8 +103,8 @@ __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x,
       int g = g0 + (t >> 3);
       double S = 0.0, SS = 0.0;
       if (g < G) {
-        const float* p = partial + (long long)n * chunks * G * 2 + g * 2;
-        for (int k = sub; k < chunks; k += 8) { S += (double)p[(long long)k * G * 2]; SS += (double)p[(long long)k * G * 2 + 1]; }
+        const float* pp = partial + (long long)n * chunks * G * 2 + g * 2;
+        for (int k = sub; k < chunks; k += 8) { S += (double)pp[(long long)k * G * 2]; SS += (double)pp[(long long)k * G * 2 + 1]; }
       }
 #pragma unroll
       for (int o = 1; o < 8; o <<= 1) { S += __shfl_xor(S, o, 64); SS += __shfl_xor(SS, o, 64); }
@@ -97,13 +119,9 @@ __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x,
     }
   }
   __syncthreads();
-  int cv = t % CV, rr = t / CV;
-  if (rr >= RPB) return;
-  int c = cv * 8;
+  if (!active) return;
   float a[8], b[8];
   {
-    h8 gm, bt;
-    if (gamma) { gm = *reinterpret_cast<const h8*>(gamma + c); bt = *reinterpret_cast<const h8*>(beta + c); }
     int g = c / cpg, gend = (g + 1) * cpg;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -114,24 +132,15 @@ __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x,
       b[j] = btj - mean * a[j];
     }
   }
-  const half_t* base;
-  int ld;
-  if (c < C1) { base = x + (long long)n * HW * C1 + c; ld = C1; }
-  else { base = x2 + (long long)n * HW * C2 + (c - C1); ld = C2; }
   half_t* yo = y + (long long)n * HW * C + c;
-  int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
-  for (int p = p0 + rr; p < p1; p += 2 * RPB) {          // two independent loads in flight per thread
-    int q = p + RPB;
-    h8 v0 = *reinterpret_cast<const h8*>(base + (long long)p * ld), v1;
-    if (q < p1) v1 = *reinterpret_cast<const h8*>(base + (long long)q * ld);
-    h8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { float f = (float)v0[j] * a[j] + b[j]; o[j] = (half_t)(do_silu ? silu_f(f) : f); }
-    *reinterpret_cast<h8*>(yo + (long long)p * C) = o;
-    if (q < p1) {
+  for (int i = 0; i < GN_APPLY_PPT; ++i) {
+    int p = p0 + rr + i * RPB;
+    if (p < p1) {
+      h8 o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { float f = (float)v1[j] * a[j] + b[j]; o[j] = (half_t)(do_silu ? silu_f(f) : f); }
-      *reinterpret_cast<h8*>(yo + (long long)q * C) = o;
+      for (int j = 0; j < 8; ++j) { float f = (float)v[i][j] * a[j] + b[j]; o[j] = (half_t)(do_silu ? silu_f(f) : f); }
+      *reinterpret_cast<h8*>(yo + (long long)p * C) = o;
     }
   }
 }
@@ -205,8 +214,8 @@ static void gn_geometry(int HW, int C, int N, int* CV, int* RPB, int* threads, i
   int c = (HW + p - 1) / p;
   if (c > GN_MAX_CHUNKS) { c = GN_MAX_CHUNKS; p = (HW + c - 1) / c; p = ((p + *RPB - 1) / *RPB) * *RPB; c = (HW + p - 1) / p; }
   *ppc = p; *chunks = c;
-  // apply: 4 pixels per thread
-  int q = *RPB * 4;
+  // apply: GN_APPLY_PPT pixels per thread, all loaded up front
+  int q = *RPB * GN_APPLY_PPT;
   *appb = q; *ablocks = (HW + q - 1) / q;
 }
 

@@ -30,6 +30,23 @@ __device__ __forceinline__ s4v lds_tr16(const half_t* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)p);
 }
 
+// 1-D grid, XCD-aware: blocks i and i+8 share an XCD (and its L2).  Every XCD gets a contiguous run of work items with
+// the query block fastest, so all query blocks of one (batch, head) sit on one XCD and its K/V stream through that
+// L2 once instead of through all eight (bijective remap, any grid size).
+struct SdpaBlk { int qb, h, b; };
+__device__ __forceinline__ SdpaBlk sdpa_block(const SdpaP& p) {
+  const int nqb = (p.Tq + 127) / 128, nblk = nqb * p.NH * p.B;
+  int bid = blockIdx.x;
+  int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+  bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  SdpaBlk o;
+  int bh = bid / nqb;
+  o.qb = bid - bh * nqb;
+  o.b = bh / p.NH;
+  o.h = bh - o.b * p.NH;
+  return o;
+}
+
 template <int DQK, int DV>
 __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
   constexpr int KS = DQK + 8;                 // K row stride (halves); 16-B multiple
@@ -44,8 +61,9 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int qblk = blockIdx.x * 128 + wid * 32;
+  const SdpaBlk blk = sdpa_block(p);
+  const int b = blk.b, h = blk.h;
+  const int qblk = blk.qb * 128 + wid * 32;
   const half_t* qb = p.q + b * p.q_sb + h * p.q_sh;
   const half_t* kb = p.k + b * p.k_sb + h * p.k_sh;
   const half_t* vb = p.v + b * p.v_sb + h * p.v_sh;
@@ -75,7 +93,7 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
 
   int ntiles = (p.Tk + 63) / 64;
   if (p.causal) {   // keys beyond the block's last query are never needed
-    int last_q = min(p.Tq, blockIdx.x * 128 + 128) - 1;
+    int last_q = min(p.Tq, blk.qb * 128 + 128) - 1;
     ntiles = min(ntiles, last_q / 64 + 1);
   }
 
@@ -240,6 +258,271 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant for the head sizes of the SD UNets (40 / 80 / 160, plus 64 / 128).  In k_sdpa above a third of the
+// time at d = 40 goes to moving K/V tiles global -> VGPR -> LDS (buffer loads, ds_writes, the vmcnt stall in front of
+// them).  Here the tiles go global -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction, no
+// registers) into a ring of S stages, S-1 tiles in flight, one s_barrier per tile behind a counted vmcnt.
+//   K image: row r = 16 kt + lr holds key 32 (kt>>1) + 8 (lr>>2) + 4 (kt&1) + (lr&3) (the key each MFMA A-row needs, so
+//            a 16-lane read walks 16 consecutive rows); pitch = an odd number of 16-B chunks -> conflict-free b128 reads.
+//   V image: natural key order, pitch chosen so the 4 rows x 32 B of a transposed read fall in distinct banks.
+//   Pad chunks are fetched "out of range" (zeros).  Columns >= HS read by the 32-deep QK^T steps hold finite data of
+//   the neighbouring row and meet zero Q columns; the LDS is zeroed once so no stale NaN pattern can be there.
+//   Row sums: one extra MFMA per (key half, query tile) against an all-ones A fragment.
+typedef int i4v __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor in SGPRs (base, no stride, num_records in bytes, 32-bit raw format word of gfx9)
+__device__ __forceinline__ i4v sdpa_rsrc(const void* base, unsigned bytes) {
+  unsigned long long a = (unsigned long long)base;
+  i4v r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+
+// LDS-DMA issued from inline asm: the compiler does not see an LDS write, so it puts no vmcnt(0) in front of the
+// ds_read_tr of the tile being consumed (it cannot tell the ring stages apart); ordering is the kernel's own
+// counted s_waitcnt vmcnt + s_barrier.  16 B per lane, LDS destination = M0 + lane * 16, out-of-range lanes write 0.
+__device__ __forceinline__ void sdpa_dma16(i4v rsrc, unsigned voffset_bytes, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(__builtin_amdgcn_readfirstlane((int)lds_base)), "v"(voffset_bytes), "s"(rsrc) : "memory");   // M0 has no other user in k_sdpa_dma (gfx9 DS ops do not read it)
+}
+
+constexpr bool sdpa_v_pitch_ok(int vpc) {
+  for (int i = 0; i < 4; ++i)
+    for (int j = i + 1; j < 4; ++j) {
+      int d = ((i - j) * vpc * 16 % 256 + 256) % 256;
+      if (d < 32 || d > 224) return false;
+    }
+  return true;
+}
+constexpr int sdpa_v_pitch(int ck) { int v = ck; while (!sdpa_v_pitch_ok(v)) ++v; return v; }
+
+template <int HS>
+struct SdpaDma {
+  static constexpr int DQK = (HS + 31) / 32 * 32, NKS = DQK / 32, NDT = (HS + 15) / 16, CK = HS / 8;
+  static constexpr int KPC = CK | 1, VPC = sdpa_v_pitch(CK);      // pitches in 16-B chunks
+  static constexpr int KP = KPC * 8, VP = VPC * 8;                // pitches in halves
+  static constexpr int K_BYTES = 64 * KPC * 16, STAGE_B = 64 * (KPC + VPC) * 16;
+  static constexpr int S = (144 * 1024 / STAGE_B) >= 4 ? 4 : (144 * 1024 / STAGE_B);
+  static constexpr int NI = KPC + VPC, LPW = (NI + 3) / 4;        // 1-KiB pieces per tile / per wave
+  static_assert(S >= 2, "ring needs two stages");
+};
+
+template <int HS>
+__global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
+  using C = SdpaDma<HS>;
+  constexpr int NKS = C::NKS, NDT = C::NDT, CK = C::CK, KPC = C::KPC, VPC = C::VPC, KP = C::KP, VP = C::VP;
+  constexpr int S = C::S, NI = C::NI, LPW = C::LPW, STAGE_B = C::STAGE_B;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const SdpaBlk blk = sdpa_block(p);
+  const int b = blk.b, h = blk.h;
+  const int qblk = blk.qb * 128 + wid * 32;
+  const half_t* qb = p.q + b * p.q_sb + h * p.q_sh;
+  const half_t* kb = p.k + b * p.k_sb + h * p.k_sh;
+  const half_t* vb = p.v + b * p.v_sb + h * p.v_sh;
+
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  for (int i = tid; i < S * STAGE_B / 16; i += 256) reinterpret_cast<u4*>(smem_raw)[i] = (u4){0, 0, 0, 0};
+
+  h8 qf[2][NKS];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    int qi = qblk + qt * 16 + lr;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      int d0 = ks * 32 + lg * 8;
+      h8 qv = (qi < p.Tq && d0 < HS) ? *reinterpret_cast<const h8*>(qb + qi * p.q_st + d0) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qv[j] = (half_t)((float)qv[j] * p.scale_log2e);
+      qf[qt][ks] = qv;
+    }
+  }
+
+  int ntiles = (p.Tk + 63) / 64;
+  if (p.causal) {
+    int last_q = min(p.Tq, blk.qb * 128 + 128) - 1;
+    ntiles = min(ntiles, last_q / 64 + 1);
+  }
+
+  // this wave's 1-KiB pieces of a tile: piece j = wid + 4 i (clamped: the spare slots of the last round repeat piece
+  // NI-1, same bytes to the same place); j < KPC -> K image, else V image
+  const i4v rs_k = sdpa_rsrc(kb, (unsigned)(((long long)(p.Tk - 1) * p.k_st + HS) * 2));
+  const i4v rs_v = sdpa_rsrc(vb, (unsigned)(((long long)(p.Tk - 1) * p.v_st + HS) * 2));
+  unsigned voff[LPW];
+  const unsigned k_adv = 64u * (unsigned)p.k_st * 2u, v_adv = 64u * (unsigned)p.v_st * 2u;
+#pragma unroll
+  for (int i = 0; i < LPW; ++i) {
+    int j = min(wid + 4 * i, NI - 1);
+    if (j < KPC) {
+      int x = 64 * j + lane, r = x / KPC, cc = x - r * KPC;
+      int kt = r >> 4, rr = r & 15;
+      int key = 32 * (kt >> 1) + 8 * (rr >> 2) + 4 * (kt & 1) + (rr & 3);
+      voff[i] = cc < CK ? (unsigned)(key * (int)p.k_st + cc * 8) * 2u : 0x80000000u;
+    } else {
+      int x = 64 * (j - KPC) + lane, r = x / VPC, cc = x - r * VPC;
+      voff[i] = cc < CK ? (unsigned)(r * (int)p.v_st + cc * 8) * 2u : 0x80000000u;
+    }
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
+  auto issue = [&](int tt) {
+    const unsigned base = lds0 + (unsigned)(tt % S) * STAGE_B;
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+      int j = min(wid + 4 * i, NI - 1);
+      if (j < KPC) sdpa_dma16(rs_k, voff[i] + (unsigned)tt * k_adv, base + j * 1024);
+      else sdpa_dma16(rs_v, voff[i] + (unsigned)tt * v_adv, base + j * 1024);
+    }
+  };
+
+  f4 ot[NDT][2], lt[2];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) { ot[dt][0] = (f4){0, 0, 0, 0}; ot[dt][1] = (f4){0, 0, 0, 0}; }
+  lt[0] = (f4){0, 0, 0, 0}; lt[1] = (f4){0, 0, 0, 0};
+  float m_run[2] = {0.f, 0.f};
+  const h8 ones = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
+
+  __syncthreads();                       // zero fill done (and drained) before the first DMA lands
+#pragma unroll
+  for (int tt = 0; tt < S - 1; ++tt)
+    if (tt < ntiles) issue(tt);
+
+  for (int t = 0; t < ntiles; ++t) {
+    // tile t landed (this wave's pieces), leaving the younger tiles in flight; the barrier extends that to every wave
+    // and tells that all of them are done reading tile t-1, whose slot the next issue refills
+    {
+      int younger = min(S - 2, ntiles - 1 - t);
+      if (younger >= 2 && S >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW > 63 ? 63 : 2 * LPW) : "memory");
+      else if (younger >= 1 && S >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW > 63 ? 63 : LPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (t + S - 1 < ntiles) issue(t + S - 1);
+
+    const half_t* ks_ = reinterpret_cast<const half_t*>(smem_raw + (t % S) * STAGE_B);
+    const half_t* vs_ = ks_ + 64 * KP;
+
+    f4 st[4][2];
+    const f4 init4[2] = {{-m_run[0], -m_run[0], -m_run[0], -m_run[0]}, {-m_run[1], -m_run[1], -m_run[1], -m_run[1]}};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        h8 kf = *reinterpret_cast<const h8*>(ks_ + (16 * kt + lr) * KP + ks * 32 + lg * 8);
+        st[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], ks == 0 ? init4[0] : st[kt][0], 0, 0, 0);
+        st[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], ks == 0 ? init4[1] : st[kt][1], 0, 0, 0);
+      }
+    }
+    const int kbase = t * 64 + 8 * lg;
+    if (t * 64 + 64 > p.Tk || p.causal) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int key = kbase + 32 * (kt >> 1) + 4 * (kt & 1) + e;
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) {
+            int qi = qblk + qt * 16 + lr;
+            if (key >= p.Tk || (p.causal && key > qi)) st[kt][qt][e] = -INFINITY;
+          }
+        }
+    }
+    constexpr float RESCALE_THR = 6.0f;
+    float mx[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float m0_ = fmaxf(fmaxf(st[0][qt][0], st[0][qt][1]), fmaxf(st[0][qt][2], st[0][qt][3]));
+#pragma unroll
+      for (int kt = 1; kt < 4; ++kt) {
+        m0_ = fmaxf(fmaxf(m0_, st[kt][qt][0]), st[kt][qt][1]);
+        m0_ = fmaxf(fmaxf(m0_, st[kt][qt][2]), st[kt][qt][3]);
+      }
+      m0_ = fmaxf(m0_, __shfl_xor(m0_, 16, 64));
+      m0_ = fmaxf(m0_, __shfl_xor(m0_, 32, 64));
+      mx[qt] = m0_;
+    }
+    if (t == 0 || __any((mx[0] > RESCALE_THR) || (mx[1] > RESCALE_THR))) {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        float delta = mx[qt] == -INFINITY ? 0.f : (t == 0 ? mx[qt] : fmaxf(mx[qt], 0.f));
+        m_run[qt] += delta;
+        if (t != 0) {
+          float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) ot[dt][qt] *= alpha;
+          lt[qt] *= alpha;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) st[kt][qt][e] -= delta;
+      }
+    }
+    h8 pf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pf[kt >> 1][qt][(kt & 1) * 4 + e] = (half_t)__builtin_amdgcn_exp2f(st[kt][qt][e]);
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      lt[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[kc][0], lt[0], 0, 0, 0);
+      lt[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[kc][1], lt[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        const half_t* va = vs_ + (32 * kc + 8 * lg + (lr >> 2)) * VP + dt * 16 + 4 * (lr & 3);
+        s4v v0 = lds_tr16(va), v1 = lds_tr16(va + 4 * VP);
+        union { struct { s4v a, b; } s; h8 h; } u;
+        u.s.a = v0; u.s.b = v1;
+        ot[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.h, pf[kc][0], ot[dt][0], 0, 0, 0);
+        ot[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.h, pf[kc][1], ot[dt][1], 0, 0, 0);
+      }
+    }
+  }
+
+  half_t* ob = p.o + b * p.o_sb + h * p.o_sh;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float l = lt[qt][0];
+    float inv = l > 0.f ? 1.0f / l : 0.f;
+    int qi = qblk + qt * 16 + lr;
+    if (qi < p.Tq) {
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        int d = dt * 16 + lg * 4;
+        if (d < HS) {
+          h4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[dt][qt][e] * inv);
+          *reinterpret_cast<h4*>(ob + qi * p.o_st + d) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int HS>
+static int launch_sdpa_dma(const SdpaP& p, hipStream_t st) {
+  constexpr int smem = SdpaDma<HS>::S * SdpaDma<HS>::STAGE_B;
+  static bool attr_set = false;
+  if (!attr_set) {
+    TF_HIP(hipFuncSetAttribute((const void*)k_sdpa_dma<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_sdpa_dma<HS>), dim3((unsigned)((p.Tq + 127) / 128 * p.NH * p.B)), dim3(256), smem, st, p);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+
 template <int DQK, int DV>
 static int launch_sdpa(const SdpaP& p, hipStream_t st) {
   constexpr int smem = 2 * (64 * (DQK + 8) + 64 * (DV + 8)) * 2;
@@ -248,10 +531,12 @@ static int launch_sdpa(const SdpaP& p, hipStream_t st) {
     TF_HIP(hipFuncSetAttribute((const void*)k_sdpa<DQK, DV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_sdpa<DQK, DV>), dim3((p.Tq + 127) / 128, p.NH, p.B), dim3(256), smem, st, p);
+  hipLaunchKernelGGL((k_sdpa<DQK, DV>), dim3((unsigned)((p.Tq + 127) / 128 * p.NH * p.B)), dim3(256), smem, st, p);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
+
+static bool g_sdpa_generic = getenv("TF_SDPA_GENERIC") != nullptr;   // debugging: force the register-staged kernel
 
 extern "C" int tf_sdpa_f16(void* o, const void* q, const void* k, const void* v, int B, int NH, int Tq, int Tk, int HS, long long q_sb,
                            long long q_sh, long long q_st, long long k_sb, long long k_sh, long long k_st, long long v_sb, long long v_sh,
@@ -259,7 +544,7 @@ extern "C" int tf_sdpa_f16(void* o, const void* q, const void* k, const void* v,
   TF_REQUIRE(o && q && k && v, "tf_sdpa_f16: null tensor");
   TF_REQUIRE(B >= 0 && NH >= 1 && Tq >= 0 && Tk >= 1, "tf_sdpa_f16: bad sizes B=%d NH=%d Tq=%d Tk=%d", B, NH, Tq, Tk);
   TF_REQUIRE(HS >= 8 && HS % 8 == 0 && HS <= 160, "tf_sdpa_f16: head size %d must be a multiple of 8 in [8, 160]", HS);
-  TF_REQUIRE(NH <= 65535 && B <= 65535, "tf_sdpa_f16: NH / B exceed grid limits");
+  TF_REQUIRE((long long)((Tq + 127) / 128) * NH * B < (1ll << 31), "tf_sdpa_f16: too many (query block, head, batch) work items");
   const long long str[] = {q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st};
   for (int i = 0; i < 9; ++i) TF_REQUIRE(str[i] % 8 == 0, "tf_sdpa_f16: q/k/v strides must be multiples of 8 elements (16-B rows)");
   TF_REQUIRE(o_sb % 4 == 0 && o_sh % 4 == 0 && o_st % 4 == 0, "tf_sdpa_f16: output strides must be multiples of 4 elements");
@@ -272,6 +557,15 @@ extern "C" int tf_sdpa_f16(void* o, const void* q, const void* k, const void* v,
   p.scale_log2e = (1.0f / sqrtf((float)HS)) * 1.4426950408889634f;
   p.causal = causal;
   hipStream_t st = tf_hs(s);
+  // K/V offsets inside a (batch, head) slice must fit the 32-bit buffer offsets of the DMA kernels
+  const bool small = ((long long)Tk * k_st + HS) * 2 < (1ll << 31) && ((long long)Tk * v_st + HS) * 2 < (1ll << 31);
+  if (small && !g_sdpa_generic) {
+    if (HS == 40) return launch_sdpa_dma<40>(p, st);
+    if (HS == 64) return launch_sdpa_dma<64>(p, st);
+    if (HS == 80) return launch_sdpa_dma<80>(p, st);
+    if (HS == 128) return launch_sdpa_dma<128>(p, st);
+    if (HS == 160) return launch_sdpa_dma<160>(p, st);
+  }
   // (DQK, DV) = (HS rounded up to 32, HS + 1 rounded up to 16): the V tile always has room for the ones column
   if (HS <= 32) return launch_sdpa<32, 48>(p, st);
   if (HS <= 40) return launch_sdpa<64, 48>(p, st);
