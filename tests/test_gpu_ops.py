@@ -193,6 +193,50 @@ def test_conv2d_concat_and_upsample(tf, c1, c2, cout, hw, k):
     close(up(dev(tf, a)).numpy(), O.conv2d_bias(O.upsample_nearest2x(a), wu, up.conv.bias.numpy(), (1, 1)).numpy())
 
 
+GN_FUSED_CASES = [  # n, cin, hw, cout, k, groups, forced (bm, bn, splitk) or None
+    (2, 64, 16, 320, 3, 32, (64, 160, 1)), (2, 64, 16, 320, 3, 32, (64, 128, 1)), (2, 64, 16, 320, 3, 32, (64, 64, 1)),
+    (2, 64, 16, 320, 3, 32, (128, 160, 1)), (2, 64, 16, 320, 3, 32, (128, 128, 1)), (2, 128, 16, 640, 3, 32, (128, 64, 1)),
+    (2, 320, 16, 1280, 3, 32, (64, 160, 4)), (2, 640, 8, 1280, 3, 32, (64, 64, 8)), (2, 320, 32, 640, 1, 32, (64, 128, 2)),
+    (2, 64, 8, 64, 3, 32, None), (1, 64, 16, 96, 1, 8, (64, 64, 1)), (2, 320, 16, 320, 3, 32, None), (2, 1280, 8, 1280, 3, 32, None),
+    (2, 64, 8, 128, 3, 32, (128, 64, 1)),      # tile straddles two images: statistics cannot ride along (chunks = 0)
+    (1, 64, 16, 2560, 1, 32, (64, 160, 1)),    # groups of 80 channels: too wide for the epilogue fold (chunks = 0)
+]
+
+
+@pytest.mark.parametrize("n,cin,hw,cout,k,groups,force", GN_FUSED_CASES)
+def test_conv2d_emits_group_norm_statistics(tf, n, cin, hw, cout, k, groups, force):
+    """conv -> GroupNorm(+SiLU) with the statistics produced by the conv's epilogue / split-K reduce (tf_conv2d_gn_f16 +
+    tf_group_norm_apply_f16) against the oracle's conv followed by its own group_norm (vision/resnet.py:11,17-18), and
+    bit-identical to the unfused two-kernel GroupNorm on the same conv output."""
+    from oracle import ops as O
+    from tinyfusers_amd.native import lib
+    from tinyfusers_amd.ff.group_norm import GroupNorm
+    from tinyfusers_amd.vision.conv2d import Conv2d
+    x = rnd("gf.x", (n, cin, hw, hw)); wt = rnd("gf.w", (cout, cin, k, k), (cin * k * k) ** -0.5); b = rnd("gf.b", (cout,), 0.1)
+    e = rnd("gf.e", (n, cout), 0.5); r = rnd("gf.r", (n, cout, hw, hw))
+    gam = 1.0 + rnd("gf.g", (cout,), 0.1); bet = rnd("gf.bt", (cout,), 0.1)
+    m = Conv2d(cin, cout, [k, k], padding=[k // 2, k // 2], init=False); m.weight = dev(tf, wt); m.bias = dev(tf, b)
+    g = GroupNorm(groups, cout, init=False); g.weight = dev(tf, gam, "row"); g.bias = dev(tf, bet, "row")
+    if force:
+        lib.tf_gemm_force_config(*force)
+    try:
+        y = m(dev(tf, x), bias_nc=dev(tf, e), residual=dev(tf, r), gn=groups)
+    finally:
+        lib.tf_gemm_force_config(0, 0, 0)
+    expect_fused = cout // groups <= 64 and not (force and hw * hw % force[0] != 0)
+    if force:
+        assert (y.gn is not None) == expect_fused
+    fused = g(y, silu=True).numpy()
+    want_y = O.conv2d_bias(x, wt, b, (k // 2, k // 2)) + torch.from_numpy(e)[:, :, None, None] + torch.from_numpy(r)
+    close(y.numpy(), want_y.numpy())
+    yq = torch.from_numpy(y.numpy())                       # GroupNorm of the fp16 tensor the device holds
+    want = O.silu(O.group_norm_affine(yq, groups, gam, bet, 1e-5)).numpy()
+    close(fused, want)
+    y.gn = None
+    plain = g(y, silu=True).numpy()                        # stand-alone statistics pass on the same tensor
+    np.testing.assert_allclose(fused, plain, atol=2e-3, rtol=2e-3)
+
+
 SDPA_CASES = [  # b, nh, tq, tk, hs
     (2, 2, 16, 16, 8), (2, 2, 16, 5, 8), (1, 3, 100, 77, 40), (2, 8, 256, 256, 160), (2, 8, 64, 77, 160), (2, 8, 1024, 1024, 80),
     (2, 8, 4096, 77, 40), (1, 2, 4096, 4096, 40), (2, 2, 130, 130, 32), (1, 12, 77, 77, 64), (1, 1, 200, 333, 128), (1, 2, 70, 70, 96),

@@ -156,7 +156,7 @@ class SpatialTransformer:
         self.transformer_blocks = [BasicTransformerBlock(channels, context_dim, n_heads, d_head, init=init)]
         self.proj_out = Conv2d(n_heads * d_head, channels, kernel_size=[1, 1], init=init)
 
-    def __call__(self, x, context=None, kv=None):
+    def __call__(self, x, context=None, kv=None, out_gn=0):
         b, c, h, w = x.shape
         x_in = x
         x = self.norm(x)
@@ -165,4 +165,4 @@ class SpatialTransformer:
         for block in self.transformer_blocks:
             x = block(x, context=context, kv=kv)
         x = x.image(b, c, h, w)                          # attention.py:74
-        return self.proj_out(x, residual=x_in)           # + x_in fused (attention.py:75)
+        return self.proj_out(x, residual=x_in, gn=out_gn)   # + x_in fused (attention.py:75)

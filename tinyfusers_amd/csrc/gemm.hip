@@ -36,6 +36,10 @@ struct GemmP {
   int order;            // block -> tile order inside an XCD's run: 0 = n fastest (share activation rows), 1 = m fastest (share the weight tile)
   unsigned dv_howo_mul, dv_howo_shr, dv_wo_mul, dv_wo_shr;   // magic numbers: n / HoWo, n / Wo without a divide
   int dbg;              // diagnostic builds only (tools/gemm_bench.py): 1 no stores, 2 no MFMA, 4 no staging
+  // GroupNorm statistics of the OUTPUT emitted by the epilogue (tf_conv2d_gn_f16): per (image, chunk, group) partial
+  // (sum, sum of squares) of the fp16-rounded outputs, in the layout k_gn_apply folds; NULL = off
+  float* gn_part;
+  int gn_G, gn_cpg, gn_chunks;
 };
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;   // 128-bit buffer resource
@@ -107,11 +111,11 @@ __device__ __forceinline__ void igemm_scratch_write(const GemmP& p, f4 (&acc)[BN
 
 // all 8 waves: wave (w4, half) stores rows [half*TM/2, (half+1)*TM/2) of consumer w4's tile
 template <int BM, int BN>
-__device__ __forceinline__ void igemm_epilogue(const GemmP& p, const char* smem, int m0, int n0, int split, int w4, int half, int lane) {
+__device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m0, int n0, int split, int w4, int half, int lane) {
   constexpr int TM = BM / 2, TN = BN / 2;
   const int wave_m = w4 & 1, wave_n = w4 >> 1;
   constexpr int RS = TN + 4, ROWS = TM / 2;
-  const float* sc = reinterpret_cast<const float*>(smem) + (size_t)w4 * (TM * RS) + (size_t)half * ROWS * RS;
+  float* sc = reinterpret_cast<float*>(smem) + (size_t)w4 * (TM * RS) + (size_t)half * ROWS * RS;
   const int mb = m0 + wave_m * TM + half * ROWS;
   const int nb = n0 + wave_n * TN;                       // first (packed) column
   if (p.act == 1) {
@@ -167,6 +171,11 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, const char* smem,
       h8 out;
       for (int e = 0; e < 4; ++e) { out[e] = (half_t)v0[e]; out[4 + e] = (half_t)v1[e]; }
       *reinterpret_cast<h8*>(p.y + o) = out;
+      if (p.gn_part) {   // the statistics pass below sums what the consumer will read: the fp16-rounded outputs
+        float* rw = sc + row * RS + c8 * 8;
+        for (int e = 0; e < 4; ++e) { v0[e] = (float)out[e]; v1[e] = (float)out[4 + e]; }
+        *reinterpret_cast<f4*>(rw) = v0; *reinterpret_cast<f4*>(rw + 4) = v1;
+      }
     } else {
       for (int e = 0; e < 8 && n + e < p.N; ++e) {
         float f = e < 4 ? v0[e] : v1[e - 4];
@@ -176,6 +185,57 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, const char* smem,
         p.y[o + e] = (half_t)f;
       }
     }
+  }
+}
+
+// ---- GroupNorm statistics of the block's output tile (all 8 waves, after igemm_epilogue left the rounded outputs in
+// the scratch).  Fixed summation order everywhere -> bitwise reproducible:
+//   1. every wave sums its ROWS x TN region by columns (lane = column: conflict-free ds_read_b32 down the rows);
+//   2. the per-(row stripe, channel) sums meet in an LDS table; one barrier;
+//   3. one lane per group touched by the tile adds its channels over the 4 row stripes and writes the partial for
+//      (image, chunk = 2 * m-tile + piece, group).  A group that straddles two n-tiles (cpg <= 64 <= BN: at most two)
+//      gets piece 0 from the tile holding its first channel and piece 1 from the next; a tile that holds a whole
+//      group writes piece 1 = 0 itself, so every slot has exactly one writer and no zero-fill is needed.
+template <int BM, int BN>
+__device__ __forceinline__ void igemm_gn_stats(const GemmP& p, char* smem, int m0, int n0, int w4, int half, int lane) {
+  constexpr int TM = BM / 2, TN = BN / 2, RS = TN + 4, ROWS = TM / 2;
+  const int wave_m = w4 & 1, wave_n = w4 >> 1;
+  const float* sc = reinterpret_cast<const float*>(smem) + (size_t)w4 * (TM * RS) + (size_t)half * ROWS * RS;
+  f2* cs = reinterpret_cast<f2*>(smem + 4 * TM * RS * 4 + BM * 8);       // [4 stripes][BN]
+  const int stripe = wave_m * 2 + half;
+  const int ncols = min(p.N - n0, BN);
+  for (int c = lane; c < TN; c += 64) {
+    float s_ = 0.f, q_ = 0.f;
+    if (wave_n * TN + c < ncols) {
+#pragma unroll 8
+      for (int r = 0; r < ROWS; ++r) { float v = sc[r * RS + c]; s_ += v; q_ += v * v; }
+    }
+    cs[stripe * BN + wave_n * TN + c] = (f2){s_, q_};
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                           // barrier W: the column sums of all 8 waves are in LDS
+  asm volatile("" ::: "memory");
+  if (w4 != 0 || half != 0) return;
+  const int cpg = p.gn_cpg;
+  const int g_lo = n0 / cpg, g_hi = (n0 + ncols - 1) / cpg;
+  const int g = g_lo + lane;
+  if (g > g_hi) return;
+  const int cb = max(g * cpg, n0) - n0, ce = min((g + 1) * cpg, n0 + ncols) - n0;
+  float S = 0.f, Q = 0.f;
+  for (int st_ = 0; st_ < 4; ++st_)
+    for (int c = cb; c < ce; ++c) { f2 v = cs[st_ * BN + c]; S += v[0]; Q += v[1]; }
+  const int img = m0 / p.HoWo, mt = (m0 - img * p.HoWo) / BM;
+  if (BN % cpg == 0) {                                    // groups never straddle n-tiles: one chunk per m-tile
+    *reinterpret_cast<f2*>(p.gn_part + ((long long)(img * p.gn_chunks + mt) * p.gn_G + g) * 2) = (f2){S, Q};
+    return;
+  }
+  float* dst = p.gn_part + ((long long)(img * p.gn_chunks + 2 * mt) * p.gn_G + g) * 2;
+  const bool starts = g * cpg >= n0, ends = (g + 1) * cpg <= n0 + ncols;
+  if (starts) {
+    *reinterpret_cast<f2*>(dst) = (f2){S, Q};
+    if (ends) *reinterpret_cast<f2*>(dst + p.gn_G * 2) = (f2){0.f, 0.f};
+  } else {
+    *reinterpret_cast<f2*>(dst + p.gn_G * 2) = (f2){S, Q};
   }
 }
 
@@ -393,6 +453,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
     __builtin_amdgcn_s_barrier();                         // barrier Y: the consumers' tiles are in the LDS scratch
     asm volatile("" ::: "memory");
     igemm_epilogue<BM, BN>(p, smem, m0, n0, split, w4, 1, lane);
+    if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 1, lane);
     return;
   }
 
@@ -522,6 +583,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   __builtin_amdgcn_s_barrier();                           // barrier Y
   asm volatile("" ::: "memory");
   igemm_epilogue<BM, BN>(p, smem, m0, n0, split, w4, 0, lane);
+  if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 0, lane);
 }
 
 // split-K reduce + epilogue: y[m,n] = sum_z partial[z,m,n] + bias + bias_nc + residual   (N % 4 == 0 fast path)
@@ -535,10 +597,13 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(half_t* __restrict__ y, c
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += gs) {
       long long e0 = i << 2;
       int m = (int)(e0 / N), n = (int)(e0 - (long long)m * N);
-      f4 v = *reinterpret_cast<const f4*>(partial + e0);
-      for (int z = 1; z < splitk; ++z) {
-        f4 u = *reinterpret_cast<const f4*>(partial + (long long)z * total + e0);
-        v += u;
+      f4 v = {0.f, 0.f, 0.f, 0.f};
+      for (int z0 = 0; z0 < splitk; z0 += 8) {           // 8 independent loads in flight, added in split order
+        f4 u[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = z0 + i < splitk ? *reinterpret_cast<const f4*>(partial + (long long)(z0 + i) * total + e0) : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v += u[i];
       }
       if (bias) { h4 b = *reinterpret_cast<const h4*>(bias + n); for (int e = 0; e < 4; ++e) v[e] += (float)b[e]; }
       if (bias_nc) { h4 b = *reinterpret_cast<const h4*>(bias_nc + (long long)(m / HoWo) * bnc_stride + n); for (int e = 0; e < 4; ++e) v[e] += (float)b[e]; }
@@ -557,6 +622,60 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(half_t* __restrict__ y, c
       if (residual) v += (float)residual[i];
       y[i] = (half_t)v;
     }
+  }
+}
+
+// split-K reduce + epilogue + GroupNorm statistics of the output (tf_conv2d_gn_f16 on a split-K shape): a block owns R
+// whole output rows (R = HoWo / chunks); thread t owns column quad t % nq and the rows r = t / nq (mod RL), so the
+// per-channel sums stay in its registers; row lanes and channels -> groups meet through LDS in a fixed order.
+// The split partials of an element are fetched 8 at a time (independent loads) and added in split order.
+__global__ void __launch_bounds__(1024) k_splitk_reduce_gn(half_t* __restrict__ y, const float* __restrict__ partial, const half_t* __restrict__ bias,
+                                                           const half_t* __restrict__ bias_nc, const half_t* __restrict__ residual, int M, int N,
+                                                           int HoWo, int splitk, long long bnc_stride, float* __restrict__ gn_part, int G, int cpg,
+                                                           int chunks, int R, int RL) {
+  extern __shared__ float chan[];                        // [RL][N][2]
+  const long long total = (long long)M * N;
+  const int m_first = blockIdx.x * R;
+  const int nq = N >> 2;
+  const int rl = threadIdx.x / nq, q0 = threadIdx.x - rl * nq;
+  if (rl < RL) {
+    const int n = q0 << 2;
+    f4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
+    f4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) { h4 b = *reinterpret_cast<const h4*>(bias + n); for (int e = 0; e < 4; ++e) bv[e] = (float)b[e]; }
+    for (int r = rl; r < R; r += RL) {
+      const int m = m_first + r;
+      const long long e0 = (long long)m * N + n;
+      h4 bnc = {0, 0, 0, 0}, res = {0, 0, 0, 0};
+      if (bias_nc) bnc = *reinterpret_cast<const h4*>(bias_nc + (long long)(m / HoWo) * bnc_stride + n);
+      if (residual) res = *reinterpret_cast<const h4*>(residual + e0);
+      f4 v = {0.f, 0.f, 0.f, 0.f};
+      for (int z0 = 0; z0 < splitk; z0 += 8) {
+        f4 u[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = z0 + i < splitk ? *reinterpret_cast<const f4*>(partial + (long long)(z0 + i) * total + e0) : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v += u[i];
+      }
+      v += bv;
+      for (int e = 0; e < 4; ++e) v[e] += (float)bnc[e];
+      for (int e = 0; e < 4; ++e) v[e] += (float)res[e];
+      h4 o;
+      for (int e = 0; e < 4; ++e) { o[e] = (half_t)v[e]; float f = (float)o[e]; cs[e] += f; cq[e] += f * f; }
+      *reinterpret_cast<h4*>(y + e0) = o;
+    }
+    float* ch = chan + (long long)rl * N * 2;
+    for (int e = 0; e < 4; ++e) { ch[2 * (n + e)] = cs[e]; ch[2 * (n + e) + 1] = cq[e]; }
+  }
+  __syncthreads();
+  const int g = threadIdx.x;
+  if (g < G) {
+    float S = 0.f, Q = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c)
+      for (int l = 0; l < RL; ++l) { S += chan[((long long)l * N + c) * 2]; Q += chan[((long long)l * N + c) * 2 + 1]; }
+    const int img = m_first / HoWo, slot = (m_first - img * HoWo) / R;
+    float* dst = gn_part + ((long long)(img * chunks + slot) * G + g) * 2;
+    dst[0] = S; dst[1] = Q;
   }
 }
 
@@ -659,12 +778,22 @@ static TileCfg choose_tiles(int M, int N, int K, int act, bool allow_split) {
   return best;
 }
 
+// GroupNorm statistics from the producing conv: limits shared by the host entry, the tuner and the launches
+#define TF_GN_MAX_CHUNKS 128
+static int gn_reduce_chunks(int HoWo) { int R = (HoWo + TF_GN_MAX_CHUNKS - 1) / TF_GN_MAX_CHUNKS; while (HoWo % R) ++R; return HoWo / R; }
+static int gn_pieces(const GemmP& p, int bn) { return bn % p.gn_cpg == 0 ? 1 : 2; }   // chunks per m-tile (igemm_gn_stats)
+static int gn_chunks_for(const GemmP& p, TileCfg c, int splitk) {
+  return splitk > 1 ? gn_reduce_chunks(p.HoWo) : gn_pieces(p, c.bn) * (p.HoWo / c.bm);
+}
+static bool gn_tile_ok(const GemmP& p, int bm, int bn) { return p.HoWo % bm == 0 && gn_pieces(p, bn) * (p.HoWo / bm) <= TF_GN_MAX_CHUNKS; }
+
 template <int BM, int BN, bool GENERIC, bool WIDE>
 static int launch_cfg3(const GemmP& p, hipStream_t st) {
   constexpr int TM = BM / 2, TN = BN / 2;
   constexpr int ring = (WIDE ? 2 : ring_slots(BM, BN)) * (BM + BN) * 128;
   constexpr int scratch = 4 * TM * (TN + 4) * 4;         // epilogue transpose scratch overlays the ring
-  constexpr int smem = ring > scratch + BM * 8 ? ring : scratch + BM * 8;   // + the LayerNorm (mean, rstd) table behind the scratch
+  constexpr int tail = BM * 8 + 4 * BN * 8;              // LayerNorm (mean, rstd) table + GroupNorm column-sum table behind the scratch
+  constexpr int smem = ring > scratch + tail ? ring : scratch + tail;
   static bool attr_set = false;
   if (!attr_set) {
     TF_HIP(hipFuncSetAttribute((const void*)k_igemm<BM, BN, GENERIC, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -690,6 +819,12 @@ static int launch_one(GemmP p, TileCfg c, bool wide, int order, void* workspace,
   p.partial = (float*)workspace;
   p.ntm = (p.M + c.bm - 1) / c.bm;
   p.ntn = (p.N + c.bn - 1) / c.bn;
+  float* gn_part = p.gn_part;
+  if (gn_part) {
+    // chunk geometry of the statistics partials: in-kernel (2 pieces per m-tile) or in the split-K reduce (row stripes)
+    if (p.splitk > 1) { p.gn_chunks = gn_reduce_chunks(p.HoWo); p.gn_part = nullptr; }
+    else p.gn_chunks = gn_pieces(p, c.bn) * (p.HoWo / c.bm);
+  }
   if (c.bm == 128 && c.bn == 160) rc = launch_cfg<128, 160, false>(p, st, wide);     // scratch 86 KB: one block per CU only
   else if (c.bm == 64 && c.bn == 160) rc = launch_cfg<64, 160, true>(p, st, wide);
   else if (c.bm == 128 && c.bn == 128) rc = launch_cfg<128, 128, true>(p, st, wide);
@@ -698,7 +833,17 @@ static int launch_one(GemmP p, TileCfg c, bool wide, int order, void* workspace,
   else if (c.bm == 64 && c.bn == 64) rc = launch_cfg<64, 64, true>(p, st, wide);
   else { tf_set_error("run_gemm: no kernel for tile %dx%d", c.bm, c.bn); return TF_E_UNSUPPORTED; }
   if (rc) return rc;
-  if (p.splitk > 1) {
+  p.gn_part = gn_part;
+  if (p.splitk > 1 && p.gn_part) {
+    const int R = p.HoWo / p.gn_chunks, nq = p.N >> 2;
+    int RL = 1024 / nq;
+    if (RL > R) RL = R;
+    int threads = (RL * nq + 63) & ~63;
+    if (threads < ((p.gn_G + 63) & ~63)) threads = (p.gn_G + 63) & ~63;   // one thread per group in the final fold
+    hipLaunchKernelGGL(k_splitk_reduce_gn, dim3(p.M / R), dim3(threads), (size_t)RL * p.N * 2 * sizeof(float), st, p.y, (const float*)p.partial,
+                       p.bias, p.bias_nc, p.residual, p.M, p.N, p.HoWo, p.splitk, p.bias_nc_stride, p.gn_part, p.gn_G, p.gn_cpg, p.gn_chunks, R, RL);
+    TF_LAUNCH_CHECK();
+  } else if (p.splitk > 1) {
     long long nv = ((long long)p.M * p.N) >> 2;
     int grid = (int)((nv + 255) / 256);
     if (grid > 2048) grid = 2048;
@@ -742,7 +887,9 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
         TileCfg c = {bm, bn, sk};
         for (int order = 0; order < 2; ++order) {
           if (order == 1 && (p.M + bm - 1) / bm == 1) continue;   // a single m tile: both orders coincide
-          int rc = launch_one(p, c, wide != 0, order, workspace, st);   // warm-up
+          GemmP q = p;
+          if (q.gn_part && sk == 1 && !gn_tile_ok(q, bm, bn)) q.gn_part = nullptr;
+          int rc = launch_one(q, c, wide != 0, order, workspace, st);   // warm-up
           if (rc) return rc;
           // In the real step every layer's weights come from HBM (1.7 GB of weights per step never stay cached), so each
           // timed launch is preceded by a cache flush (a 384 MiB memset, outside the timed interval): median of 5.
@@ -750,7 +897,7 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
           for (int r = 0; r < 5; ++r) {
             TF_HIP(hipMemsetAsync(g_flush, r, TF_FLUSH_BYTES, st));
             TF_HIP(hipEventRecord(a, st));
-            rc = launch_one(p, c, wide != 0, order, workspace, st);
+            rc = launch_one(q, c, wide != 0, order, workspace, st);
             if (rc) return rc;
             TF_HIP(hipEventRecord(b, st));
             TF_HIP(hipEventSynchronize(b));
@@ -768,7 +915,7 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
   return TF_OK;
 }
 
-static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_bm, int force_bn, int force_split, hipStream_t st) {
+static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_bm, int force_bn, int force_split, hipStream_t st, int* gn_chunks = nullptr) {
   p.ktiles = (p.K + 63) / 64;
   p.dbg = g_dbg;
   fast_div_magic((unsigned)p.HoWo, &p.dv_howo_mul, &p.dv_howo_shr);
@@ -813,6 +960,13 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     TF_HIP(hipEventRecord(rec.a, st));
   }
   if (g_force_order >= 0) t.order = g_force_order;
+  if (p.gn_part) {
+    // statistics ride along only when the chosen tiling maps m-tiles onto whole images; otherwise the caller is told
+    // (chunks = 0) and runs the stand-alone statistics pass
+    int kps = (p.ktiles + t.c.splitk - 1) / t.c.splitk, eff = (p.ktiles + kps - 1) / kps;
+    if (eff == 1 && !gn_tile_ok(p, t.c.bm, t.c.bn)) p.gn_part = nullptr;
+    if (gn_chunks) *gn_chunks = p.gn_part ? gn_chunks_for(p, t.c, eff) : 0;
+  }
   int rc = launch_one(p, t.c, wide, t.order, workspace, st);
   if (rc) return rc;
   if (g_prof) { TF_HIP(hipEventRecord(rec.b, st)); g_prof_pending.push_back(rec); }
@@ -932,15 +1086,19 @@ static int conv_geometry(int H, int W, int R, int S, int stride, int pad, int up
   return (*Ho > 0 && *Wo > 0) ? 0 : 1;
 }
 
+size_t tf_conv2d_gn_partial_bytes(int N, int groups) { return (size_t)(N > 0 ? N : 0) * TF_GN_MAX_CHUNKS * (groups > 0 ? groups : 0) * 2 * sizeof(float); }
+
 size_t tf_conv2d_workspace(int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample) {
   int Ho, Wo;
   if (stride < 1 || conv_geometry(H, W, R, S, stride, pad, upsample ? 1 : 0, &Ho, &Wo)) return 0;
   return gemm_workspace(N * Ho * Wo, Cout, R * S * (C1 + C2), 0);
 }
 
-int tf_conv2d_f16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
-                  const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
-                  void* workspace, size_t workspace_bytes, tfStream_t s) {
+static int conv2d_impl(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
+                       const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
+                       void* workspace, size_t workspace_bytes, float* gn_partial, size_t gn_partial_bytes, int gn_groups, int* gn_chunks,
+                       tfStream_t s) {
+  if (gn_chunks) *gn_chunks = 0;
   TF_REQUIRE(y && x && w, "tf_conv2d_f16: null tensor");
   TF_REQUIRE(C1 > 0 && C2 >= 0 && (C2 == 0 || x2), "tf_conv2d_f16: C1=%d C2=%d x2=%p", C1, C2, x2);
   TF_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0, "tf_conv2d_f16: channel counts must be multiples of 8 (C1=%d C2=%d); use tf_im2col_nhwc_f16 for tiny C", C1, C2);
@@ -961,7 +1119,34 @@ int tf_conv2d_f16(void* y, const void* x, const void* x2, const void* w, const v
     TF_REQUIRE(xb < (1LL << 31) && x2b < (1LL << 31) && wb < (1LL << 31), "tf_conv2d_f16: tensors must be < 2 GiB each");
     p.x_bytes = (unsigned)xb; p.x2_bytes = C2 ? (unsigned)x2b : (unsigned)xb; p.w_bytes = (unsigned)wb;
   }
-  return run_gemm(p, workspace, workspace_bytes, g_force_bm, g_force_bn, g_force_split, tf_hs(s));
+  if (gn_partial) {
+    TF_REQUIRE(gn_chunks, "tf_conv2d_gn_f16: gn_chunks must not be NULL");
+    TF_REQUIRE(gn_groups >= 1 && Cout % gn_groups == 0, "tf_conv2d_gn_f16: Cout=%d not divisible by groups=%d", Cout, gn_groups);
+    TF_REQUIRE(gn_partial_bytes >= tf_conv2d_gn_partial_bytes(N, gn_groups), "tf_conv2d_gn_f16: statistics buffer too small (%zu bytes)", gn_partial_bytes);
+    int cpg = Cout / gn_groups;
+    // group width the epilogue can fold (a group spans at most two n-tiles, one lane per group of a tile); anything else
+    // simply reports chunks = 0 and the caller runs tf_group_norm_f16 as usual
+    if (cpg >= 4 && cpg <= 64 && Cout % 8 == 0 && Cout <= 4096 && gn_groups <= 256) {
+      p.gn_part = gn_partial; p.gn_G = gn_groups; p.gn_cpg = cpg;
+    }
+  }
+  return run_gemm(p, workspace, workspace_bytes, g_force_bm, g_force_bn, g_force_split, tf_hs(s), gn_chunks);
+}
+
+int tf_conv2d_f16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
+                  const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
+                  void* workspace, size_t workspace_bytes, tfStream_t s) {
+  return conv2d_impl(y, x, x2, w, bias, bias_nc, bias_nc_stride, residual, N, H, W, C1, C2, Cout, R, S, stride, pad, upsample, workspace,
+                     workspace_bytes, nullptr, 0, 0, nullptr, s);
+}
+
+int tf_conv2d_gn_f16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
+                     const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
+                     void* workspace, size_t workspace_bytes, void* gn_partial, size_t gn_partial_bytes, int gn_groups, int* gn_chunks,
+                     tfStream_t s) {
+  TF_REQUIRE(gn_partial && gn_chunks, "tf_conv2d_gn_f16: null statistics buffer");
+  return conv2d_impl(y, x, x2, w, bias, bias_nc, bias_nc_stride, residual, N, H, W, C1, C2, Cout, R, S, stride, pad, upsample, workspace,
+                     workspace_bytes, (float*)gn_partial, gn_partial_bytes, gn_groups, gn_chunks, s);
 }
 
 size_t tf_linear_workspace(int M, int N, int K, int act) { return gemm_workspace(M, act == 1 ? 2 * N : N, K, act); }

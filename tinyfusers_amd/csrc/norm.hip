@@ -103,8 +103,18 @@ __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x,
       int g = g0 + (t >> 3);
       double S = 0.0, SS = 0.0;
       if (g < G) {
+        // this lane's chunks k = sub, sub + 8, ...: 8 independent loads in flight per round, summed in k order
         const float* pp = partial + (long long)n * chunks * G * 2 + g * 2;
-        for (int k = sub; k < chunks; k += 8) { S += (double)pp[(long long)k * G * 2]; SS += (double)pp[(long long)k * G * 2 + 1]; }
+        for (int k0 = sub; k0 < chunks; k0 += 64) {
+          f2 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            int k = k0 + 8 * u;
+            v[u] = k < chunks ? *reinterpret_cast<const f2*>(pp + (long long)k * G * 2) : (f2){0.f, 0.f};
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { S += (double)v[u][0]; SS += (double)v[u][1]; }
+        }
       }
 #pragma unroll
       for (int o = 1; o < 8; o <<= 1) { S += __shfl_xor(S, o, 64); SS += __shfl_xor(SS, o, 64); }
@@ -248,6 +258,23 @@ int tf_group_norm_f16(void* y, const void* x, const void* x2, const void* gamma,
   TF_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
                      (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+
+int tf_group_norm_apply_f16(void* y, const void* x, const void* gamma, const void* beta, const void* partial, int chunks, int N, int HW, int C, int G,
+                            float eps, int silu, tfStream_t s) {
+  TF_REQUIRE(y && x && partial, "tf_group_norm_apply_f16: null tensor");
+  TF_REQUIRE((gamma == nullptr) == (beta == nullptr), "tf_group_norm_apply_f16: gamma and beta must both be given or both NULL");
+  TF_REQUIRE(N >= 0 && HW >= 0 && G >= 1 && C > 0 && C % G == 0, "tf_group_norm_apply_f16: C=%d not divisible by G=%d", C, G);
+  TF_REQUIRE(C % 8 == 0 && C / 8 <= 1024 && G <= 1024 && N <= 65535, "tf_group_norm_apply_f16: C=%d G=%d N=%d out of range", C, G, N);
+  TF_REQUIRE(chunks >= 1 && chunks <= 4096, "tf_group_norm_apply_f16: chunks=%d", chunks);
+  if (N == 0 || HW == 0) return TF_OK;
+  int CV, RPB, threads, sc, ppc, ablocks, appb;
+  gn_geometry(HW, C, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
+  int tl = (threads + 7) & ~7;
+  hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)nullptr,
+                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C, 0, G, eps, silu, chunks, appb, CV, RPB);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }

@@ -15,6 +15,11 @@ def _gn(x, num_groups, eps, gamma, beta, silu):
     n, c1, h, w = x.shape
     c2 = x2.shape[1] if x2 is not None else 0
     y = DeviceArray.empty((n, c1 + c2, h, w), np.float16, "nhwc")
+    if x2 is None and x.gn is not None and x.gn[2] == num_groups:
+        part, chunks, _ = x.gn                         # statistics came with x from the conv that produced it
+        hip.tf_group_norm_apply_f16(y.ptr, x.ptr, gamma.ptr if gamma is not None else None, beta.ptr if beta is not None else None,
+                                    part.ptr, chunks, n, h * w, c1, num_groups, float(eps), 1 if silu else 0, _sh())
+        return y
     nb = hip.tf_group_norm_workspace(n, h * w, c1 + c2, num_groups)
     ws = workspace(nb)
     hip.tf_group_norm_f16(y.ptr, x.ptr, x2.ptr if x2 is not None else None, gamma.ptr if gamma is not None else None,

@@ -118,7 +118,7 @@ _NP = {"f16": np.float16, "f32": np.float32}
 
 class DeviceArray:
     """(ptr, logical shape, dtype, layout) handle.  layout: 'nhwc' (4-D, logical NCHW) or 'row'."""
-    __slots__ = ("ptr", "shape", "dtype", "layout", "_base", "_fin", "__weakref__")
+    __slots__ = ("ptr", "shape", "dtype", "layout", "_base", "_fin", "gn", "__weakref__")
 
     def __init__(self, ptr, shape, dtype=np.float16, layout=None, base=None):
         self.ptr = int(ptr)
@@ -127,6 +127,7 @@ class DeviceArray:
         self.layout = layout or ("nhwc" if len(self.shape) == 4 else "row")
         self._base = base
         self._fin = None
+        self.gn = None       # (partials, chunks, groups): GroupNorm statistics emitted by the conv that produced this array
 
     # -- construction
     @staticmethod

@@ -1,6 +1,7 @@
 """conv_2d / Conv2d -- mirrors tinyfusers/vision/conv2d.py:9-58 (cuDNN conv_fprop graph rebuilt per call,
 NHWC->NCHW re-view, separate bias kernel).  Here: one implicit-GEMM MFMA launch on NHWC fp16 with bias, the
 time-embedding add, the residual add, the nearest-2x upsample and the channel concat all folded in."""
+import ctypes
 import functools
 import math
 import operator
@@ -12,7 +13,7 @@ from ..storage.tensor import DeviceArray, _sh, asarray
 from ..ff.linear import workspace, linear_f16
 
 
-def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, upsample=False):
+def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, upsample=False, gn=0):
     x2 = None
     if isinstance(x, (tuple, list)):
         x, x2 = x
@@ -31,9 +32,18 @@ def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, up
     bnc_stride = 0
     if bias_nc is not None:
         bnc_stride = k if bias_nc.size // k > 1 else 0
-    hip.tf_conv2d_f16(y.ptr, x.ptr, x2.ptr if x2 is not None else None, w.ptr, bias.ptr if bias is not None else None,
-                      bias_nc.ptr if bias_nc is not None else None, bnc_stride, residual.ptr if residual is not None else None,
-                      n, h, wd, c1, c2, k, r, s, stride[0], padding[0], up, ws.ptr if ws else None, nb, _sh())
+    args = (y.ptr, x.ptr, x2.ptr if x2 is not None else None, w.ptr, bias.ptr if bias is not None else None,
+            bias_nc.ptr if bias_nc is not None else None, bnc_stride, residual.ptr if residual is not None else None,
+            n, h, wd, c1, c2, k, r, s, stride[0], padding[0], up, ws.ptr if ws else None, nb)
+    if gn:
+        # the GroupNorm(gn) that consumes y next gets its statistics from this conv's epilogue (when the shape allows)
+        pb = hip.tf_conv2d_gn_partial_bytes(n, gn)
+        part, chunks = workspace(pb), ctypes.c_int(0)
+        hip.tf_conv2d_gn_f16(*args, part.ptr, pb, gn, ctypes.byref(chunks), _sh())
+        if chunks.value > 0:
+            y.gn = (part, chunks.value, gn)
+    else:
+        hip.tf_conv2d_f16(*args, _sh())
     return y
 
 
@@ -78,9 +88,10 @@ class Conv2d:
             self.bias = asarray(np.random.uniform(-bound, bound, (out_channels,)).astype(np.float16)) if bias else None
         self._cache = {}
 
-    def __call__(self, x, bias_nc=None, residual=None, upsample=False):
+    def __call__(self, x, bias_nc=None, residual=None, upsample=False, gn=0):
+        """gn = G: also emit the statistics of the output for the GroupNorm(G) that reads it next (y.gn)."""
         cin = (x[0].shape[1] + x[1].shape[1]) if isinstance(x, (tuple, list)) else x.shape[1]
         if cin % 8 != 0:
             assert bias_nc is None and residual is None and not upsample
             return _conv_small_c(x, self.weight, self.bias, self.padding, self.stride, self._cache)
-        return _conv(x, self.weight, self.bias, self.padding, self.stride, self.dilation, bias_nc, residual, upsample)
+        return _conv(x, self.weight, self.bias, self.padding, self.stride, self.dilation, bias_nc, residual, upsample, gn)

@@ -26,15 +26,17 @@ class ResBlock:
         ]
         self.skip_connection = Conv2d(channels, out_channels, kernel_size=[1, 1], init=init) if channels != out_channels else lambda x: x
 
-    def __call__(self, x, emb, emb_out=None):
+    def __call__(self, x, emb, emb_out=None, out_gn=0):
+        """out_gn = G: the block's output is read next by a GroupNorm(G); its statistics ride on the last conv."""
         h = self.in_layers[0](x, silu=True)
         if emb_out is None:
             emb_out = self.emb_layers[1](emb, silu_input=True)         # Linear(SiLU(emb)): (rows, Cout)
-        h = self.in_layers[2](h, bias_nc=emb_out)                      # conv + bias + emb[:, :, None, None]
+        g2 = self.out_layers[0].num_groups
+        h = self.in_layers[2](h, bias_nc=emb_out, gn=g2)               # conv + bias + emb[:, :, None, None] (+ stats for norm2)
         h = self.out_layers[0](h, silu=True)
         skip = self.skip_connection(x)
         assert not isinstance(skip, (tuple, list)), "identity skip needs a single tensor (cin == cout)"
-        return self.out_layers[3](h, residual=skip)
+        return self.out_layers[3](h, residual=skip, gn=out_gn)
 
 
 class ResnetBlock:
@@ -47,6 +49,6 @@ class ResnetBlock:
         self.conv2 = Conv2d(out_channels, out_channels, kernel_size=[3, 3], padding=[1, 1], init=init)
         self.nin_shortcut = Conv2d(in_channels, out_channels, kernel_size=[1, 1], init=init) if in_channels != out_channels else lambda x: x
 
-    def __call__(self, x):
-        h = self.conv1(self.norm1(x, silu=True))
-        return self.conv2(self.norm2(h, silu=True), residual=self.nin_shortcut(x))
+    def __call__(self, x, out_gn=0):
+        h = self.conv1(self.norm1(x, silu=True), gn=self.norm2.num_groups)
+        return self.conv2(self.norm2(h, silu=True), residual=self.nin_shortcut(x), gn=out_gn)

@@ -54,8 +54,8 @@ class Downsample:
     def __init__(self, channels, init=True):
         self.op = Conv2d(channels, channels, stride=[2, 2], kernel_size=[3, 3], padding=[1, 1], init=init)
 
-    def __call__(self, x):
-        return self.op(x)
+    def __call__(self, x, out_gn=0):
+        return self.op(x, gn=out_gn)
 
 
 class StepParams:
@@ -161,26 +161,38 @@ class UNetModel:
         emb_all = gemv_f16(emb, bt["emb_w"], bt["emb_b"], silu_input=True)            # every ResBlock's Linear(SiLU(emb))
         kv_all = linear_f16(context, bt["kv_w"]) if bt["kv_w"] is not None else None  # every attn2's K|V of the context
 
-        def run(x, bb):
+        def run(x, bb, nxt):
+            # nxt = the module that reads this one's output as a single tensor (None across a concat): when it opens
+            # with a GroupNorm, the statistics are produced by this module's last conv
+            gn = nxt.num_groups if isinstance(nxt, GroupNorm) else 32 if isinstance(nxt, (ResBlock, SpatialTransformer)) else 0
             if isinstance(bb, ResBlock):
                 off, n = bt["emb_off"][id(bb)]
-                return bb(x, emb, emb_out=emb_all.view((emb_all.shape[0], n), "row", off))
+                return bb(x, emb, emb_out=emb_all.view((emb_all.shape[0], n), "row", off), out_gn=gn)
             if isinstance(bb, SpatialTransformer):
                 c = bb.proj_in.weight.shape[0]
-                return bb(x, context, kv=KVSlice(kv_all, bt["kv_off"][id(bb)], c, bt["kv_n"]))
+                return bb(x, context, kv=KVSlice(kv_all, bt["kv_off"][id(bb)], c, bt["kv_n"]), out_gn=gn)
+            if isinstance(bb, Downsample):
+                return bb(x, out_gn=gn)
             return bb(x)
 
         saved_inputs = []
+        seq = [bb for b in self.input_blocks for bb in b] + list(self.middle_block)
+        ends = set()                                # indices after which the tensor is also saved for a skip concat
+        i = 0
         for b in self.input_blocks:
-            for bb in b:
-                x = run(x, bb)
-            saved_inputs.append(x)
-        for bb in self.middle_block:
-            x = run(x, bb)
-        for b in self.output_blocks:
+            i += len(b)
+            ends.add(i - 1)
+        for i, bb in enumerate(seq):
+            nxt = seq[i + 1] if i + 1 < len(seq) else None     # the middle block's output enters a concat
+            x = run(x, bb, nxt)
+            if i in ends:
+                saved_inputs.append(x)
+        for bi, b in enumerate(self.output_blocks):
             x = (x, saved_inputs.pop())            # channel concat (unet.py:72), consumed un-materialised
-            for bb in b:
-                x = run(x, bb)
+            for j, bb in enumerate(b):
+                last = bi == len(self.output_blocks) - 1 and j == len(b) - 1
+                nxt = b[j + 1] if j + 1 < len(b) else (self.out[0] if last else None)
+                x = run(x, bb, nxt)
         return self.out[2](self.out[0](x, silu=True))
 
 

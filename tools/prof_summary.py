@@ -2,7 +2,7 @@
 """Summarise a rocprofv3 kernel_stats.csv per step: prof_summary.py <dir> <steps_in_run>"""
 import csv, glob, sys
 d, steps = sys.argv[1], float(sys.argv[2])
-f = glob.glob(d + "/*/*kernel_stats.csv")[0]
+f = (glob.glob(d + "/*/*kernel_stats.csv") + glob.glob(d + "/*kernel_stats.csv"))[0]
 rows = list(csv.DictReader(open(f)))
 tot = 0
 out = []
