@@ -192,7 +192,7 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
 // the scratch).  Fixed summation order everywhere -> bitwise reproducible:
 //   1. every wave sums its ROWS x TN region by columns (lane = column: conflict-free ds_read_b32 down the rows);
 //   2. the per-(row stripe, channel) sums meet in an LDS table; one barrier;
-//   3. one lane per group touched by the tile adds its channels over the 4 row stripes and writes the partial for
+//   3. one wave per group touched by the tile (lane = channel, 4 stripe reads, xor-shuffle tree) writes the partial for
 //      (image, chunk = 2 * m-tile + piece, group).  A group that straddles two n-tiles (cpg <= 64 <= BN: at most two)
 //      gets piece 0 from the tile holding its first channel and piece 1 from the next; a tile that holds a whole
 //      group writes piece 1 = 0 itself, so every slot has exactly one writer and no zero-fill is needed.
@@ -215,27 +215,31 @@ __device__ __forceinline__ void igemm_gn_stats(const GemmP& p, char* smem, int m
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                           // barrier W: the column sums of all 8 waves are in LDS
   asm volatile("" ::: "memory");
-  if (w4 != 0 || half != 0) return;
+  // one WAVE per group (round-robin over the 8 waves): lane = channel of the group, 4 stripe reads, shuffle tree
   const int cpg = p.gn_cpg;
   const int g_lo = n0 / cpg, g_hi = (n0 + ncols - 1) / cpg;
-  const int g = g_lo + lane;
-  if (g > g_hi) return;
-  const int cb = max(g * cpg, n0) - n0, ce = min((g + 1) * cpg, n0 + ncols) - n0;
-  float S = 0.f, Q = 0.f;
-  for (int st_ = 0; st_ < 4; ++st_)
-    for (int c = cb; c < ce; ++c) { f2 v = cs[st_ * BN + c]; S += v[0]; Q += v[1]; }
   const int img = m0 / p.HoWo, mt = (m0 - img * p.HoWo) / BM;
-  if (BN % cpg == 0) {                                    // groups never straddle n-tiles: one chunk per m-tile
-    *reinterpret_cast<f2*>(p.gn_part + ((long long)(img * p.gn_chunks + mt) * p.gn_G + g) * 2) = (f2){S, Q};
-    return;
-  }
-  float* dst = p.gn_part + ((long long)(img * p.gn_chunks + 2 * mt) * p.gn_G + g) * 2;
-  const bool starts = g * cpg >= n0, ends = (g + 1) * cpg <= n0 + ncols;
-  if (starts) {
-    *reinterpret_cast<f2*>(dst) = (f2){S, Q};
-    if (ends) *reinterpret_cast<f2*>(dst + p.gn_G * 2) = (f2){0.f, 0.f};
-  } else {
-    *reinterpret_cast<f2*>(dst + p.gn_G * 2) = (f2){S, Q};
+  for (int g = g_lo + (w4 + 4 * half); g <= g_hi; g += 8) {
+    const int cb = max(g * cpg, n0) - n0, ce = min((g + 1) * cpg, n0 + ncols) - n0;
+    float S = 0.f, Q = 0.f;
+    if (cb + lane < ce) {
+#pragma unroll
+      for (int st_ = 0; st_ < 4; ++st_) { f2 v = cs[st_ * BN + cb + lane]; S += v[0]; Q += v[1]; }
+    }
+    S = wave_sum(S); Q = wave_sum(Q);
+    if (lane != 0) continue;
+    if (BN % cpg == 0) {                                  // groups never straddle n-tiles: one chunk per m-tile
+      *reinterpret_cast<f2*>(p.gn_part + ((long long)(img * p.gn_chunks + mt) * p.gn_G + g) * 2) = (f2){S, Q};
+      continue;
+    }
+    float* dst = p.gn_part + ((long long)(img * p.gn_chunks + 2 * mt) * p.gn_G + g) * 2;
+    const bool starts = g * cpg >= n0, ends = (g + 1) * cpg <= n0 + ncols;
+    if (starts) {
+      *reinterpret_cast<f2*>(dst) = (f2){S, Q};
+      if (ends) *reinterpret_cast<f2*>(dst + p.gn_G * 2) = (f2){0.f, 0.f};
+    } else {
+      *reinterpret_cast<f2*>(dst + p.gn_G * 2) = (f2){S, Q};
+    }
   }
 }
 
@@ -668,14 +672,20 @@ __global__ void __launch_bounds__(1024) k_splitk_reduce_gn(half_t* __restrict__ 
     for (int e = 0; e < 4; ++e) { ch[2 * (n + e)] = cs[e]; ch[2 * (n + e) + 1] = cq[e]; }
   }
   __syncthreads();
-  const int g = threadIdx.x;
-  if (g < G) {
+  // one wave per group (round-robin): lane = channel of the group (cpg <= 64), RL row-lane reads, shuffle tree
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int img = m_first / HoWo, slot = (m_first - img * HoWo) / R;
+  for (int g = wv; g < G; g += nw) {
     float S = 0.f, Q = 0.f;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c)
+    if (lane < cpg) {
+      const int c = g * cpg + lane;
       for (int l = 0; l < RL; ++l) { S += chan[((long long)l * N + c) * 2]; Q += chan[((long long)l * N + c) * 2 + 1]; }
-    const int img = m_first / HoWo, slot = (m_first - img * HoWo) / R;
-    float* dst = gn_part + ((long long)(img * chunks + slot) * G + g) * 2;
-    dst[0] = S; dst[1] = Q;
+    }
+    S = wave_sum(S); Q = wave_sum(Q);
+    if (lane == 0) {
+      float* dst = gn_part + ((long long)(img * chunks + slot) * G + g) * 2;
+      dst[0] = S; dst[1] = Q;
+    }
   }
 }
 
@@ -839,7 +849,6 @@ static int launch_one(GemmP p, TileCfg c, bool wide, int order, void* workspace,
     int RL = 1024 / nq;
     if (RL > R) RL = R;
     int threads = (RL * nq + 63) & ~63;
-    if (threads < ((p.gn_G + 63) & ~63)) threads = (p.gn_G + 63) & ~63;   // one thread per group in the final fold
     hipLaunchKernelGGL(k_splitk_reduce_gn, dim3(p.M / R), dim3(threads), (size_t)RL * p.N * 2 * sizeof(float), st, p.y, (const float*)p.partial,
                        p.bias, p.bias_nc, p.residual, p.M, p.N, p.HoWo, p.splitk, p.bias_nc_stride, p.gn_part, p.gn_G, p.gn_cpg, p.gn_chunks, R, RL);
     TF_LAUNCH_CHECK();
