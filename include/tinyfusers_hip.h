@@ -192,6 +192,10 @@ int tf_silu_f16(void* y, const void* x, long long n, tfStream_t s);
 int tf_sigmoid_f16(void* y, const void* x, long long n, tfStream_t s);
 int tf_gelu_f16(void* y, const void* x, long long n, tfStream_t s);
 int tf_quick_gelu_f16(void* y, const void* x, long long n, tfStream_t s);
+/* Embedding lookup (ff/embedding.py:10-24; the CLIP text encoder's token + position embeddings, vae/encoder.py:68-73):
+ * out(n_tokens, dim) f16 = table[ids[i], :] (+ pos[i % T, :] when pos != NULL).  ids: n_tokens int32 ON THE DEVICE. */
+int tf_embedding_f16(void* out, const void* table, const void* ids, const void* pos, long long n_tokens, int dim, int vocab,
+                     int T, tfStream_t s);
 int tf_geglu_f16(void* y, const void* x, int rows, int C, tfStream_t s);          /* x (rows,2C) -> y (rows,C) */
 int tf_add_f16(void* y, const void* a, const void* b, long long n, tfStream_t s);
 int tf_add_bias_nc_f16(void* y, const void* x, const void* bias_nc, int N, int HW, int C, tfStream_t s);

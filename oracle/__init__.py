@@ -15,3 +15,4 @@ fixtures on every CPU test run.
 from .ops import *  # noqa: F401,F403
 from .unet import *  # noqa: F401,F403
 from .vae import *  # noqa: F401,F403
+from .clip import *  # noqa: F401,F403

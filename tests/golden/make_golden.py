@@ -15,7 +15,7 @@ so it is imported under stand-in modules, exactly as SURVEY 8(c) describes:
   * ``tinyfusers.tensor.tensor`` aliased to ``tinyfusers.storage.tensor`` (D1).
 Nothing from the reference is written anywhere: outputs are numeric arrays only.
 
-Usage:  python tests/golden/make_golden.py [ops] [blocks] [unet]
+Usage:  python tests/golden/make_golden.py [ops] [blocks] [unet] [vae] [clip]
 """
 import os
 import sys
@@ -321,6 +321,28 @@ def gen_vae():
     print("vae_sd15.npz written")
 
 
+def gen_clip():
+    """CLIPEncoder (12 x CLIPEncoderLayer) + final LayerNorm of the reference (vae/encoder.py:39-81) on synthetic hidden
+    states, under the reference's own causal mask.  The embedding front end is NOT taken from the reference: its
+    Embedding is defective; see oracle/clip.py."""
+    from tinyfusers.vae.encoder import CLIPTextTransformer
+    from oracle.clip import clip_param_shapes
+    pre = "cond_stage_model.transformer.text_model."
+    shapes = {k: v for k, v in clip_param_shapes(pre).items() if ".embeddings." not in k}
+    W = synth(shapes, seed=0)
+    t = CLIPTextTransformer()
+    holder = types.SimpleNamespace(encoder=t.encoder, final_layer_norm=t.final_layer_norm)
+    install(holder, W, pre[:-1])
+    h = rnd("clip.hidden", (1, 77, 768), 0.05, seed=1234)
+    mask = np.triu(np.full((1, 1, 77, 77), float("-inf")), k=1).astype(np.float32)       # vae/encoder.py:79
+    t0 = time.time()
+    l0 = t.encoder.layers[0](h, mask)
+    y = t.final_layer_norm(t.encoder(h, mask))
+    print("clip encoder %.1fs" % (time.time() - t0), y.shape, float(np.abs(y).mean()))
+    np.savez_compressed(os.path.join(HERE, "clip_text.npz"), layer0=np.asarray(l0, dtype=np.float32)[:, ::4], out=np.asarray(y, dtype=np.float32))
+    print("clip_text.npz written (hidden: synth 'clip.hidden' seed 1234 std 0.05; weights: synth seed 0)")
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["ops", "blocks"]
     import_reference()
@@ -328,3 +350,4 @@ if __name__ == "__main__":
     if "blocks" in what: gen_blocks()
     if "unet" in what: gen_unet()
     if "vae" in what: gen_vae()
+    if "clip" in what: gen_clip()

@@ -131,3 +131,47 @@ def test_vae_decode_sd15(golden):
     pre, u8 = oracle.sd_decode(latent, W)
     np.testing.assert_allclose(pre.numpy()[:, :, ::4, ::4], g["pre_sub"], rtol=1e-4, atol=2e-4)
     assert int(np.abs(u8[::4, ::4].astype(np.int32) - g["img_sub"].astype(np.int32)).max()) <= 1
+
+
+def _clip_weights(with_embeddings=True, seed=0):
+    shapes = oracle.clip_param_shapes()
+    if not with_embeddings:
+        shapes = {k: v for k, v in shapes.items() if ".embeddings." not in k}
+    return {k: v.astype(np.float32) for k, v in synth_state_dict(shapes, seed).items()}
+
+
+def test_clip_encoder_stack_vs_reference():
+    """12 x CLIPEncoderLayer + final LayerNorm of the reference (vae/encoder.py:39-81) on the golden hidden states."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "clip_text.npz"))
+    pre = "cond_stage_model.transformer.text_model."
+    W = _clip_weights(False)
+    h = synth_normal(1234, "clip.hidden", (1, 77, 768), 0.05)
+    mask = oracle.clip.causal_mask(77)
+    l0 = oracle.clip_encoder_layer(O.as_t(h), W, pre + "encoder.layers.0.", mask, 12)
+    close(l0.numpy()[:, ::4], g["layer0"], rtol=1e-4, atol=1e-4)
+    y = O.layer_norm(oracle.clip_encoder(h, W, pre, mask), W[pre + "final_layer_norm.weight"], W[pre + "final_layer_norm.bias"])
+    close(y.numpy(), g["out"], rtol=2e-4, atol=5e-4)
+
+
+def test_clip_text_transformer_vs_huggingface():
+    """The whole text encoder (embedding gathers included, which the reference gets wrong: SURVEY D7) against
+    transformers.CLIPTextModel carrying the same weights: the class tree of vae/encoder.py:36-81 is a transcription of it."""
+    transformers = pytest.importorskip("transformers")
+    cfg = transformers.CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                                      num_attention_heads=12, max_position_embeddings=77, hidden_act="quick_gelu")
+    model = transformers.CLIPTextModel(cfg).eval()
+    pre = "cond_stage_model.transformer.text_model."
+    W = _clip_weights(True)
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in W.items():
+            name = k[len(pre):]
+            sd["text_model." + name if "text_model." + name in sd else name].copy_(torch.from_numpy(v))
+    rng = np.random.default_rng(5)
+    ids = rng.integers(0, 49408, size=(2, 77))
+    ids[:, 0] = 49406; ids[0, 9:] = 49407; ids[1, 30:] = 49407          # <start> ... <end> padding, as the tokenizer emits
+    with torch.no_grad():
+        want = model(input_ids=torch.from_numpy(ids)).last_hidden_state.numpy()
+    got = oracle.clip_text_transformer(ids, W).numpy()
+    close(got, want, rtol=2e-4, atol=5e-4)

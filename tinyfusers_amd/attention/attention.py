@@ -166,3 +166,47 @@ class SpatialTransformer:
             x = block(x, context=context, kv=kv)
         x = x.image(b, c, h, w)                          # attention.py:74
         return self.proj_out(x, residual=x_in, gn=out_gn)   # + x_in fused (attention.py:75)
+
+
+class CLIPAttention:
+    """attention/attention.py:78-104 -- 12-head causal self-attention of the CLIP text encoder.  q/k/v run as one
+    (3*768, 768) GEMM with the LayerNorm in front folded in; heads are read through strides; unlike CrossAttention
+    the reference merges the heads back WITH the transpose (:100), i.e. the standard (b, t, h*d) layout."""
+
+    def __init__(self, init=True):
+        self.embed_dim = 768
+        self.num_heads = 12
+        self.head_dim = self.embed_dim // self.num_heads
+        self.k_proj = Linear(self.embed_dim, self.embed_dim, init=init)
+        self.v_proj = Linear(self.embed_dim, self.embed_dim, init=init)
+        self.q_proj = Linear(self.embed_dim, self.embed_dim, init=init)
+        self.out_proj = Linear(self.embed_dim, self.embed_dim, init=init)
+        self._fused = None
+
+    def _qkv(self, ln):
+        ps = [self.q_proj, self.k_proj, self.v_proj]
+        key = tuple(p.weight.ptr for p in ps) + tuple(p.bias.ptr for p in ps) + ((ln.weight.ptr, ln.bias.ptr) if ln is not None else ())
+        if self._fused is None or self._fused[0] != key:
+            w = _concat_rows([p.weight for p in ps])
+            b = _concat_rows([p.bias.view((p.bias.shape[0], 1), "row") for p in ps]).view((3 * self.embed_dim,), "row")
+            self._fused = (key, fold_layer_norm(w, b, ln) if ln is not None else (w, b), (w, b))
+        return self._fused[1]
+
+    def __call__(self, hidden_states, causal_attention_mask=None, residual=None, ln=None):
+        """causal_attention_mask: None or the causal mask of vae/encoder.py:79 (host array); anything else is refused."""
+        from .sdpa import _is_causal_mask
+        b, t, c = hidden_states.shape
+        nh, hs = self.num_heads, self.head_dim
+        causal = causal_attention_mask is not None
+        if causal and not _is_causal_mask(causal_attention_mask, t, t):
+            raise NotImplementedError("CLIPAttention supports no mask or the causal mask")
+        if ln is not None:
+            qkv = linear_ln_f16(hidden_states, self._qkv(ln), ln.eps)
+        else:
+            w, bias = self._qkv(None)
+            qkv = linear_f16(hidden_states, w, bias)
+        q, k, v = qkv, qkv.view((b, t, 3 * c), "row", c), qkv.view((b, t, 3 * c), "row", 2 * c)
+        st = (t * 3 * c, hs, 3 * c)
+        o = DeviceArray.empty((b, t, c), np.float16, "row")
+        sdpa_strided(o, q, k, v, b, nh, t, t, hs, st, st, st, (t * c, hs, c), causal)
+        return self.out_proj(o, residual=residual)

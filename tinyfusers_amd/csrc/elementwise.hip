@@ -290,6 +290,27 @@ __global__ void __launch_bounds__(EW_BLOCK) k_cfg_ddim(float* __restrict__ lat, 
   }
 }
 
+// ---- embedding gather (+ position rows): out[i, :] = table[ids[i], :] + pos[i % T, :]   (ff/embedding.py:10-24 as intended:
+// the reference builds a one-hot matrix on the host and multiplies it through cuBLAS).  One 16-B chunk per thread.
+__global__ void __launch_bounds__(256) k_embedding(half_t* __restrict__ out, const half_t* __restrict__ table, const int* __restrict__ ids,
+                                                   const half_t* __restrict__ pos, long long n_tok, int D, int vocab, int T) {
+  const int cv = D >> 3;
+  long long total = n_tok * cv;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    long long tkn = i / cv;
+    int c = (int)(i - tkn * cv) * 8;
+    int id = ids[tkn];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);     // memory safety only; the host entry validates host-side ids
+    h8 v = *reinterpret_cast<const h8*>(table + (long long)id * D + c);
+    if (pos) {
+      h8 pv = *reinterpret_cast<const h8*>(pos + (long long)(tkn % T) * D + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (half_t)((float)v[j] + (float)pv[j]);
+    }
+    *reinterpret_cast<h8*>(out + tkn * D + c) = v;
+  }
+}
+
 extern "C" {
 
 #define EW_UNARY(NAME, OP)                                                                 \
@@ -309,6 +330,15 @@ int tf_add_f16(void* y, const void* a, const void* b, long long n, tfStream_t s)
   TF_REQUIRE(y && a && b && n >= 0, "tf_add_f16: bad arguments");
   if (n == 0) return TF_OK;
   hipLaunchKernelGGL(k_add, dim3(ew_grid(n >> 3)), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)y, (const half_t*)a, (const half_t*)b, n);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_embedding_f16(void* out, const void* table, const void* ids, const void* pos, long long n_tokens, int dim, int vocab, int T, tfStream_t s) {
+  TF_REQUIRE(out && table && ids && n_tokens >= 0, "tf_embedding_f16: bad arguments");
+  TF_REQUIRE(dim > 0 && dim % 8 == 0 && vocab >= 1 && (pos == nullptr || T >= 1), "tf_embedding_f16: dim=%d must be a positive multiple of 8 (vocab=%d T=%d)", dim, vocab, T);
+  if (n_tokens == 0) return TF_OK;
+  hipLaunchKernelGGL(k_embedding, dim3(ew_grid(n_tokens * (dim >> 3))), dim3(256), 0, tf_hs(s), (half_t*)out, (const half_t*)table, (const int*)ids,
+                     (const half_t*)pos, n_tokens, dim, vocab, T > 0 ? T : 1);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }

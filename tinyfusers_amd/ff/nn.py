@@ -74,11 +74,19 @@ class FeedForward:
 
 
 class CLIPMLP:
-    """ff/nn.py:25-34 (CLIP text encoder; next-row f2)."""
+    """ff/nn.py:25-34 -- fc1 -> quick_gelu -> fc2.  ``ln``: the LayerNorm in front of the block, folded into fc1;
+    ``residual`` is added in fc2's epilogue (vae/encoder.py:62-65)."""
 
     def __init__(self, init=True):
         self.fc1 = Linear(768, 3072, init=init)
         self.fc2 = Linear(3072, 768, init=init)
 
-    def __call__(self, hidden_states):
-        return self.fc2(Tensor.quick_gelu(self.fc1(hidden_states)))
+    def _folded(self, ln):
+        key = (self.fc1.weight.ptr, self.fc1.bias.ptr, ln.weight.ptr, ln.bias.ptr)
+        if getattr(self, "_ln_fold", None) is None or self._ln_fold[0] != key:
+            self._ln_fold = (key, fold_layer_norm(self.fc1.weight, self.fc1.bias, ln))
+        return self._ln_fold[1]
+
+    def __call__(self, hidden_states, residual=None, ln=None):
+        h = linear_ln_f16(hidden_states, self._folded(ln), ln.eps) if ln is not None else self.fc1(hidden_states)
+        return self.fc2(Tensor.quick_gelu(h), residual=residual)

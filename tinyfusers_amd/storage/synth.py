@@ -31,7 +31,7 @@ def synth_tensor(seed, name, shape):
     shape = tuple(shape)
     is_norm = len(shape) == 1 and (".norm" in name or name.endswith("in_layers.0.weight") or name.endswith("in_layers.0.bias")
                                    or name.endswith("out_layers.0.weight") or name.endswith("out_layers.0.bias")
-                                   or name.startswith("out.0."))
+                                   or name.startswith("out.0.") or "layer_norm" in name)
     x = _rng(seed, name).standard_normal(size=shape, dtype=np.float32)
     if name.endswith(".weight") and len(shape) >= 2:
         fan_in = int(np.prod(shape[1:]))

@@ -6,8 +6,9 @@ returns x_{t-1}.  Differences, all MI355X-first:
     update are two tiny kernels; the latent state stays fp32 NCHW on the device;
   * batch generalised from the reference's hard-coded 1 (D8) to [uncond x B ; cond x B];
   * ``compile()`` captures the whole step (≈450 launches) into one HIP graph replayed per step.
-Only the UNet denoising path is built: first_stage_model (VAE) and cond_stage_model (CLIP) are
-next-row items and are None here.
+Beyond the UNet denoising path the next rows are built too: first_stage_model (VAE decode side, 8(f1))
+and cond_stage_model.transformer.text_model (CLIP text encoder, 8(f2)), under the reference's attribute names so that
+update_state walks the same LDM checkpoint keys.
 """
 import ctypes
 from collections import namedtuple
@@ -36,7 +37,11 @@ class StableDiffusion:
         self.model = namedtuple("DiffusionModel", ["diffusion_model"])(diffusion_model=UNetModel(cfg, init=init))
         from ..vae.vae import AutoencoderKL
         self.first_stage_model = AutoencoderKL(init=init) if cfg is SD15 else None   # decode side only
-        self.cond_stage_model = None     # CLIPTextTransformer: SURVEY 8(f2)
+        self.cond_stage_model = None
+        if cfg is SD15:                  # variants/sd.py:12: cond_stage_model.transformer.text_model
+            from ..vae.encoder import CLIPTextTransformer
+            self.cond_stage_model = namedtuple("CondStageModel", ["transformer"])(
+                transformer=namedtuple("Transformer", ["text_model"])(text_model=CLIPTextTransformer(init=init)))
         self._params = None
         self._graph = None
 
