@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""Sampler driver -- mirrors example/sd1.py:54-79 of the reference (timesteps = range(1,1000,1000//steps), reversed loop,
-decode at the end) on synthetic weights / contexts (no checkpoint, vocab or CLIP exists offline).
+"""Sampler driver -- mirrors example/sd1.py:34-79 of the reference: load weights, run the prompt's token ids through the
+CLIP text encoder for the two contexts (:44-49), timesteps = range(1,1000,1000//steps), reversed loop, VAE decode.
+No checkpoint or BPE vocabulary exists offline, so by default the weights are the seeded synthetic ones and
+the "prompt" is a seeded list of token ids; ``--ckpt file.ckpt|file.safetensors`` reads real LDM weights through
+storage/unpicker.py + update_state instead (example/sd1.py:40-41).
 BASELINE config 3: full 50-step sampler, batch 1, end-to-end img/s.
 
-    python -m example.sd1 --steps 50 [--out rendered.npy]
+    python -m example.sd1 --steps 50 [--ckpt sd-v1-4.ckpt] [--out rendered.npy]
 """
 import argparse
 import os
@@ -21,6 +24,7 @@ if __name__ == "__main__":
     ap.add_argument("--guidance", type=float, default=7.5)
     ap.add_argument("--images", type=int, default=3, help="images to time after the first (compile + warm-up) one")
     ap.add_argument("--out", default="")
+    ap.add_argument("--ckpt", default="", help="LDM checkpoint (.ckpt torch zip or .safetensors); default: synthetic weights")
     args = ap.parse_args()
 
     import oracle  # only for the parameter-shape enumerator of the VAE (names); no oracle compute is used
@@ -32,13 +36,31 @@ if __name__ == "__main__":
     T.ensure_init(0)
     model = StableDiffusion()
     t0 = time.time()
-    shapes = {"model.diffusion_model." + k: v for k, v in unet_param_shapes(model.model.diffusion_model).items()}
     import io, contextlib
+    if args.ckpt:
+        from tinyfusers_amd.storage.unpicker import load_checkpoint
+        state = load_checkpoint(args.ckpt)                       # memory-mapped; update_state streams tensor by tensor
+    else:
+        shapes = {"model.diffusion_model." + k: v for k, v in unet_param_shapes(model.model.diffusion_model).items()}
+        state = {**synth_state_dict(shapes, 0), **synth_state_dict(oracle.vae_decoder_param_shapes(), 0),
+                 **synth_state_dict(oracle.clip_param_shapes(), 0)}
     with contextlib.redirect_stdout(io.StringIO()):
-        update_state(model, {**synth_state_dict(shapes, 0), **synth_state_dict(oracle.vae_decoder_param_shapes(), 0)}, "")
+        update_state(model, state, "")
+    del state
     print(f"weights installed in {time.time() - t0:.1f}s")
-    context = T.DeviceArray.from_numpy(synth_normal(args.seed, "sd.context", (1, 77, 768)))
-    unconditional_context = T.DeviceArray.from_numpy(synth_normal(args.seed, "sd.uncond", (1, 77, 768)))
+    # run through CLIP to get the contexts (example/sd1.py:44-49); token ids stand in for tokenizer.encode(prompt)
+    rng = np.random.default_rng(args.seed)
+    n_words = 9
+    prompt = np.full((1, 77), 49407, dtype=np.int64); prompt[0, 0] = 49406; prompt[0, 1:1 + n_words] = rng.integers(0, 49406, n_words)
+    empty = np.full((1, 77), 49407, dtype=np.int64); empty[0, 0] = 49406
+    text_model = model.cond_stage_model.transformer.text_model
+    text_model(prompt)                                           # first call folds the LayerNorms / fuses q|k|v once
+    T.hip.tf_stream_sync(None)
+    t0 = time.perf_counter()
+    context = text_model(prompt)
+    unconditional_context = text_model(empty)
+    T.hip.tf_stream_sync(None)
+    print(f"CLIP context: {context.shape}, unconditional CLIP context: {unconditional_context.shape}  ({1e3 * (time.perf_counter() - t0):.2f} ms for both)")
     timesteps = list(range(1, 1000, 1000 // args.steps))
     alphas = model.alphas_cumprod[timesteps]
     alphas_prev = np.concatenate((np.array([1.0]), alphas[:-1])).astype(np.float32)
