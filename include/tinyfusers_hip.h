@@ -74,6 +74,9 @@ int tf_event_create(tfEvent_t* out);
 int tf_event_destroy(tfEvent_t e);
 int tf_event_record(tfEvent_t e, tfStream_t s);
 int tf_event_sync(tfEvent_t e);
+/* work launched on s after this call waits for everything recorded into e (fork / join of side branches, also while a
+ * graph is being captured: the side stream joins the capture and the dependency becomes a graph edge) */
+int tf_stream_wait_event(tfStream_t s, tfEvent_t e);
 int tf_event_elapsed_ms(float* ms, tfEvent_t start, tfEvent_t stop);
 int tf_graph_begin_capture(tfStream_t s);
 int tf_graph_end_capture(tfStream_t s, tfGraph_t* out);

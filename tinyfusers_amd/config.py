@@ -11,3 +11,11 @@ head_merge = "reference_exact"
 # row statistics from the streamed fragments, gamma/beta folded into the weights once).  False = separate
 # tf_layer_norm_f16 launches (the unfused reference structure).
 fuse_layer_norm = True
+
+# Independent sub-chains of the step (a ResBlock's 1x1 skip projection next to its GroupNorm -> conv -> GroupNorm main
+# path; the context K|V projection next to the time-embedding MLP) run as parallel branches of the step graph on a side
+# stream.  Results are bit-identical either way; False serialises everything on one stream.
+# MEASURED SLOWER on MI355X (ROCm 7.2): 15 fork/join pairs per step cost 5.30 ms/step against 5.12 ms serial -- every
+# cross-stream graph edge is a barrier packet + signal round trip of several microseconds, more than the ~10 us kernels it
+# hides.  Kept as a switch for larger batches, off by default.
+parallel_branches = False

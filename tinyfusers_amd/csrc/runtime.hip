@@ -115,6 +115,11 @@ int tf_event_create(tfEvent_t* out) {
 }
 int tf_event_destroy(tfEvent_t e) { if (!e) return TF_OK; TF_HIP(hipEventDestroy(e->e)); delete e; return TF_OK; }
 int tf_event_record(tfEvent_t e, tfStream_t s) { TF_REQUIRE(e, "null event"); TF_HIP(hipEventRecord(e->e, tf_hs(s))); return TF_OK; }
+int tf_stream_wait_event(tfStream_t s, tfEvent_t e) {
+  TF_REQUIRE(e, "tf_stream_wait_event: null event");
+  TF_HIP(hipStreamWaitEvent(tf_hs(s), e->e, 0));
+  return TF_OK;
+}
 int tf_event_sync(tfEvent_t e) { TF_REQUIRE(e, "null event"); TF_HIP(hipEventSynchronize(e->e)); return TF_OK; }
 int tf_event_elapsed_ms(float* ms, tfEvent_t a, tfEvent_t b) {
   TF_REQUIRE(ms && a && b, "tf_event_elapsed_ms: null argument");

@@ -84,6 +84,7 @@ class Pool:
         self.free_blocks = {}
         self.allocated = 0
         self.frozen = False      # True while capturing a graph: growing the pool would call hipMalloc
+        self.held = None         # list of (ptr, n) released while a Branch is recording (see Branch)
 
     def alloc(self, nbytes):
         n = max(_ALIGN, (int(nbytes) + _ALIGN - 1) // _ALIGN * _ALIGN)
@@ -99,10 +100,70 @@ class Pool:
         return p.value, n
 
     def release(self, ptr, n):
+        if self.held is not None:
+            self.held.append((ptr, n))       # a side branch is open: its temporaries stay out of the pool until the join
+            return
         self.free_blocks.setdefault(n, []).append(ptr)
 
 
 _pool = Pool()
+
+
+class Branch:
+    """Fork / join of an independent chain of ops onto a side stream (a parallel branch of the step graph).
+
+        br = Branch()
+        with br:
+            skip = conv1x1(x)        # launched on the side stream, after everything already queued on the current one
+        ...                          # the caller keeps launching on the current stream: runs concurrently
+        br.join()                    # the current stream waits for the branch; use ``skip`` afterwards
+
+    Stream-ordered allocation stays valid: blocks the branch takes from the pool were freed in program order before the
+    fork (the side stream waits for the fork event); blocks the branch frees are held back until ``join`` so that nothing
+    queued on the main stream in between can be handed memory the branch is still using; the branch's INPUTS must be kept
+    referenced by the caller until ``join``.  Works inside hipGraph capture (the edges become graph dependencies)."""
+
+    _side = []          # idle side streams
+    _events = []        # idle events
+
+    def __init__(self):
+        self.main = current_stream()
+        self.side = Branch._side.pop() if Branch._side else Stream()
+        self.ev_fork, self.ev_join = self._event(), self._event()
+        self.held = []
+        self._joined = False
+
+    @staticmethod
+    def _event():
+        if Branch._events:
+            return Branch._events.pop()
+        e = ctypes.c_void_p()
+        hip.tf_event_create(ctypes.byref(e))
+        return e
+
+    def __enter__(self):
+        hip.tf_event_record(self.ev_fork, self.main.handle)
+        hip.tf_stream_wait_event(self.side.handle, self.ev_fork)
+        _stream_stack.append(self.side)
+        assert _pool.held is None, "nested Branch recording is not supported"
+        _pool.held = self.held
+        return self
+
+    def __exit__(self, *a):
+        _pool.held = None
+        _stream_stack.pop()
+        hip.tf_event_record(self.ev_join, self.side.handle)
+
+    def join(self):
+        if self._joined:
+            return
+        self._joined = True
+        hip.tf_stream_wait_event(current_stream().handle, self.ev_join)
+        for ptr, n in self.held:
+            _pool.release(ptr, n)
+        self.held = []
+        Branch._side.append(self.side)
+        Branch._events.extend((self.ev_fork, self.ev_join))
 
 
 def pool():

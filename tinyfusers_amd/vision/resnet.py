@@ -3,7 +3,8 @@ GN+SiLU (2 launches) -> conv3x3 (+bias +emb) -> GN+SiLU -> conv3x3 (+bias +skip)
 ``x`` may be the pair (x, skip) of the UNet's output path: the concat of vision/unet.py:72 is never built."""
 from ..ff.group_norm import GroupNorm
 from ..ff.linear import Linear
-from ..storage.tensor import Tensor
+from .. import config
+from ..storage.tensor import Branch, Tensor
 from .conv2d import Conv2d
 
 
@@ -28,13 +29,21 @@ class ResBlock:
 
     def __call__(self, x, emb, emb_out=None, out_gn=0):
         """out_gn = G: the block's output is read next by a GroupNorm(G); its statistics ride on the last conv."""
+        br = None
+        if config.parallel_branches and isinstance(self.skip_connection, Conv2d):
+            br = Branch()                                              # the 1x1 skip projection only needs x: parallel branch
+            with br:
+                skip = self.skip_connection(x)
         h = self.in_layers[0](x, silu=True)
         if emb_out is None:
             emb_out = self.emb_layers[1](emb, silu_input=True)         # Linear(SiLU(emb)): (rows, Cout)
         g2 = self.out_layers[0].num_groups
         h = self.in_layers[2](h, bias_nc=emb_out, gn=g2)               # conv + bias + emb[:, :, None, None] (+ stats for norm2)
         h = self.out_layers[0](h, silu=True)
-        skip = self.skip_connection(x)
+        if br is not None:
+            br.join()
+        else:
+            skip = self.skip_connection(x)
         assert not isinstance(skip, (tuple, list)), "identity skip needs a single tensor (cin == cout)"
         return self.out_layers[3](h, residual=skip, gn=out_gn)
 

@@ -21,7 +21,8 @@ from ..attention.attention import SpatialTransformer, _concat_rows
 from ..ff.group_norm import GroupNorm
 from ..ff.linear import Linear, gemv_f16, linear_f16
 from ..native import hip
-from ..storage.tensor import DeviceArray, Tensor, _sh, asarray
+from .. import config
+from ..storage.tensor import Branch, DeviceArray, Tensor, _sh, asarray
 from .conv2d import Conv2d
 from .resnet import ResBlock
 
@@ -156,10 +157,16 @@ class UNetModel:
     def __call__(self, x, timesteps=None, context=None):
         cfg = self.cfg
         bt = self._prepare()
+        br = None
+        if config.parallel_branches and bt["kv_w"] is not None:
+            br = Branch()                          # the context projection is independent of the time-embedding chain
+            with br:
+                kv_all = linear_f16(context, bt["kv_w"])
         t_emb = timestep_embedding(timesteps, cfg.model_channels)
         emb = self.time_embed[2](self.time_embed[0](t_emb), silu_input=True)          # Linear -> SiLU -> Linear
         emb_all = gemv_f16(emb, bt["emb_w"], bt["emb_b"], silu_input=True)            # every ResBlock's Linear(SiLU(emb))
-        kv_all = linear_f16(context, bt["kv_w"]) if bt["kv_w"] is not None else None  # every attn2's K|V of the context
+        if br is None:
+            kv_all = linear_f16(context, bt["kv_w"]) if bt["kv_w"] is not None else None  # every attn2's K|V of the context
 
         def run(x, bb, nxt):
             # nxt = the module that reads this one's output as a single tensor (None across a concat): when it opens
@@ -176,6 +183,7 @@ class UNetModel:
             return bb(x)
 
         saved_inputs = []
+        joined = br is None
         seq = [bb for b in self.input_blocks for bb in b] + list(self.middle_block)
         ends = set()                                # indices after which the tensor is also saved for a skip concat
         i = 0
@@ -184,9 +192,13 @@ class UNetModel:
             ends.add(i - 1)
         for i, bb in enumerate(seq):
             nxt = seq[i + 1] if i + 1 < len(seq) else None     # the middle block's output enters a concat
+            if not joined and isinstance(bb, SpatialTransformer):
+                br.join(); joined = True            # first consumer of kv_all
             x = run(x, bb, nxt)
             if i in ends:
                 saved_inputs.append(x)
+        if not joined:
+            br.join()
         for bi, b in enumerate(self.output_blocks):
             x = (x, saved_inputs.pop())            # channel concat (unet.py:72), consumed un-materialised
             for j, bb in enumerate(b):
