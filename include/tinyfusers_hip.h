@@ -126,19 +126,30 @@ int tf_conv2d_f16(void* y, const void* x, const void* x2, const void* w, const v
                   long long bias_nc_stride, const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R,
                   int S, int stride, int pad, int upsample, void* workspace, size_t workspace_bytes, tfStream_t s);
 size_t tf_conv2d_workspace(int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample);
-/* tf_conv2d_gn_f16 = tf_conv2d_f16 whose epilogue also emits the GroupNorm statistics of its OUTPUT, for the
- * GroupNorm(32) that consumes it next (vision/resnet.py:17-18 after :11; attention/attention.py:60 after
- * resnet.py:31): the group_norm of ff/group_norm.py:3-11 then needs no statistics pass of its own.
+/* tf_conv2d_fused_f16 = tf_conv2d_f16 plus two optional fusions of what surrounds a conv in ResBlock (vision/resnet.py:6-31):
+ *
+ * (1) extra 1x1 sources x3 | x4 (C3 | C4 channels, same N,H,W as x; NULL / 0 = off): K continues after the R*S taps with
+ *     the channels of x3 then x4 read at the output pixel itself, i.e. y += conv1x1([x3 | x4]).  w is then
+ *     (Cout, R*S*(C1+C2) + C3 + C4): each row = the KRSC conv row followed by the 1x1 row; bias = the sum of both biases.
+ *     This is ResBlock's ``skip_connection(x) + h`` (:24, :31) computed inside its last conv instead of a separate
+ *     Conv2d(1x1) launch plus a residual read.  Not combinable with upsample.
+ *
+ * (2) GroupNorm statistics of the OUTPUT (gn_partial != NULL), for the GroupNorm(32) that consumes it next
+ *     (vision/resnet.py:17-18 after :11; attention/attention.py:60 after resnet.py:31): the group_norm of
+ *     ff/group_norm.py:3-11 then needs no statistics pass of its own.
  *   gn_partial : f32 scratch of tf_conv2d_gn_partial_bytes(N, gn_groups) bytes, laid out (N, chunks, groups, 2)
  *                = per-chunk partial (sum, sum of squares) of the fp16 outputs, summed in a fixed order
  *   *gn_chunks : out; number of chunks written per image, to be handed to tf_group_norm_apply_f16.  0 means the
  *                statistics could not ride along for this shape (group wider than 64 channels or narrower than
  *                4, tiles that straddle images): y is complete, gn_partial is untouched, and the caller runs
  *                tf_group_norm_f16 instead. */
-int tf_conv2d_gn_f16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc,
-                     long long bias_nc_stride, const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R,
-                     int S, int stride, int pad, int upsample, void* workspace, size_t workspace_bytes, void* gn_partial,
-                     size_t gn_partial_bytes, int gn_groups, int* gn_chunks, tfStream_t s);
+int tf_conv2d_fused_f16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc,
+                        long long bias_nc_stride, const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R,
+                        int S, int stride, int pad, int upsample, void* workspace, size_t workspace_bytes, const void* x3,
+                        const void* x4, int C3, int C4, void* gn_partial, size_t gn_partial_bytes, int gn_groups,
+                        int* gn_chunks, tfStream_t s);
+size_t tf_conv2d_fused_workspace(int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
+                                 int C3, int C4);
 size_t tf_conv2d_gn_partial_bytes(int N, int groups);
 /* tf_linear_f16 replaces Linear.__call__ (ff/linear.py:112-121; live branch cp.dot(x, W^T)+b) and the
  * test-only cuBLAS/cuDNN paths linear_cublas / linear / gemm_batch (ff/linear.py:8-110):
@@ -184,7 +195,7 @@ int tf_group_norm_f16(void* y, const void* x, const void* x2, const void* gamma,
                       int C1, int C2, int G, float eps, int silu, void* workspace, size_t workspace_bytes, tfStream_t s);
 size_t tf_group_norm_workspace(int N, int HW, int C, int G);
 /* second half of tf_group_norm_f16 (normalise + affine [+ SiLU]) on statistics already produced by
- * tf_conv2d_gn_f16: partial (N, chunks, G, 2) f32.  Same arithmetic as tf_group_norm_f16 from the fold onwards. */
+ * tf_conv2d_fused_f16: partial (N, chunks, G, 2) f32.  Same arithmetic as tf_group_norm_f16 from the fold onwards. */
 int tf_group_norm_apply_f16(void* y, const void* x, const void* gamma, const void* beta, const void* partial, int chunks,
                             int N, int HW, int C, int G, float eps, int silu, tfStream_t s);
 /* LayerNorm over the last dim (ff/layer_norm.py:8-32, :34-49; semantics = F.layer_norm, tests/layer_norm.py:38) */

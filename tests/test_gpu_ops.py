@@ -205,7 +205,7 @@ GN_FUSED_CASES = [  # n, cin, hw, cout, k, groups, forced (bm, bn, splitk) or No
 
 @pytest.mark.parametrize("n,cin,hw,cout,k,groups,force", GN_FUSED_CASES)
 def test_conv2d_emits_group_norm_statistics(tf, n, cin, hw, cout, k, groups, force):
-    """conv -> GroupNorm(+SiLU) with the statistics produced by the conv's epilogue / split-K reduce (tf_conv2d_gn_f16 +
+    """conv -> GroupNorm(+SiLU) with the statistics produced by the conv's epilogue / split-K reduce (tf_conv2d_fused_f16 +
     tf_group_norm_apply_f16) against the oracle's conv followed by its own group_norm (vision/resnet.py:11,17-18), and
     bit-identical to the unfused two-kernel GroupNorm on the same conv output."""
     from oracle import ops as O
@@ -235,6 +235,43 @@ def test_conv2d_emits_group_norm_statistics(tf, n, cin, hw, cout, k, groups, for
     y.gn = None
     plain = g(y, silu=True).numpy()                        # stand-alone statistics pass on the same tensor
     np.testing.assert_allclose(fused, plain, atol=2e-3, rtol=2e-3)
+
+
+FOLD_CASES = [  # n, hw, c_mid (= cout), c3, c4, forced (bm, bn, splitk) or None, gn
+    (2, 16, 128, 64, 0, None, 0), (2, 16, 128, 64, 64, (64, 64, 1), 32), (2, 8, 1280, 1280, 1280, None, 32), (2, 16, 64, 24, 8, None, 0),
+    (1, 16, 320, 640, 320, (64, 160, 2), 32), (2, 8, 128, 192, 64, (64, 64, 4), 32), (2, 32, 320, 640, 0, (128, 160, 1), 32),
+]
+
+
+@pytest.mark.parametrize("n,hw,cm,c3,c4,force,gn", FOLD_CASES)
+def test_conv2d_with_folded_skip_projection(tf, n, hw, cm, c3, c4, force, gn):
+    """ResBlock tail (vision/resnet.py:24, :31): conv3x3(h) + skip_connection(x), x possibly the concat pair of the UNet's
+    output path, as ONE GEMM with the 1x1 projection riding as extra K columns (tf_conv2d_fused_f16) -- vs the oracle's two
+    convs and their sum, and (gn) with the GroupNorm statistics of the sum emitted on the way."""
+    from oracle import ops as O
+    from tinyfusers_amd.native import lib
+    from tinyfusers_amd.ff.group_norm import GroupNorm
+    from tinyfusers_amd.vision.conv2d import Conv2d
+    h = rnd("fs.h", (n, cm, hw, hw)); xa = rnd("fs.xa", (n, c3, hw, hw)); xb = rnd("fs.xb", (n, c4, hw, hw)) if c4 else None
+    w2 = rnd("fs.w2", (cm, cm, 3, 3), (cm * 9) ** -0.5); b2 = rnd("fs.b2", (cm,), 0.1)
+    ws = rnd("fs.ws", (cm, c3 + c4, 1, 1), (c3 + c4) ** -0.5); bs = rnd("fs.bs", (cm,), 0.1)
+    conv = Conv2d(cm, cm, [3, 3], padding=[1, 1], init=False); conv.weight = dev(tf, w2); conv.bias = dev(tf, b2)
+    proj = Conv2d(c3 + c4, cm, [1, 1], init=False); proj.weight = dev(tf, ws); proj.bias = dev(tf, bs)
+    xs = (dev(tf, xa), dev(tf, xb)) if c4 else dev(tf, xa)
+    if force:
+        lib.tf_gemm_force_config(*force)
+    try:
+        y = conv(dev(tf, h), gn=gn, extra=(proj, xs))
+    finally:
+        lib.tf_gemm_force_config(0, 0, 0)
+    xcat = np.concatenate((xa, xb), 1) if c4 else xa
+    want = O.conv2d_bias(h, w2, b2, (1, 1)) + O.conv2d_bias(xcat, ws, bs, (0, 0))
+    close(y.numpy(), want.numpy())
+    if gn:
+        assert y.gn is not None
+        gam = 1.0 + rnd("fs.g", (cm,), 0.1); bet = rnd("fs.bt", (cm,), 0.1)
+        g = GroupNorm(gn, cm, init=False); g.weight = dev(tf, gam, "row"); g.bias = dev(tf, bet, "row")
+        close(g(y, silu=True).numpy(), O.silu(O.group_norm_affine(torch.from_numpy(y.numpy()), gn, gam, bet, 1e-5)).numpy())
 
 
 SDPA_CASES = [  # b, nh, tq, tk, hs

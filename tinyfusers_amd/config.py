@@ -19,3 +19,7 @@ fuse_layer_norm = True
 # cross-stream graph edge is a barrier packet + signal round trip of several microseconds, more than the ~10 us kernels it
 # hides.  Kept as a switch for larger batches, off by default.
 parallel_branches = False
+
+# ResBlock: fold the 1x1 skip_connection into the last 3x3 conv as extra K columns (one launch instead of two plus a
+# residual read); False runs the reference's two convs.
+fold_skip_projection = True

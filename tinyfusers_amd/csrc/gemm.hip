@@ -21,6 +21,11 @@
 
 struct GemmP {
   const half_t* x; const half_t* x2; const half_t* w; half_t* y;
+  // extra K segment after the R*S taps (tf_conv2d_fused_f16): a 1x1 projection of a second activation (pair) x3 | x4 read
+  // at the output pixel itself -- the ResBlock's skip_connection folded into its last conv (vision/resnet.py:24, :31)
+  const half_t* x3; const half_t* x4;
+  int C3, C4, Kc;       // Kc = R*S*(C1+C2): where the extra segment starts inside K
+  unsigned x3_bytes, x4_bytes;
   const half_t* bias; const half_t* bias_nc; const half_t* residual; float* partial;
   long long bias_nc_stride;
   const float* ln_colsum;   // LayerNorm folded into this GEMM (see tf_linear_ln_f16): colsum[n] = sum_k w'[n,k]; NULL = off
@@ -36,7 +41,7 @@ struct GemmP {
   int order;            // block -> tile order inside an XCD's run: 0 = n fastest (share activation rows), 1 = m fastest (share the weight tile)
   unsigned dv_howo_mul, dv_howo_shr, dv_wo_mul, dv_wo_shr;   // magic numbers: n / HoWo, n / Wo without a divide
   int dbg;              // diagnostic builds only (tools/gemm_bench.py): 1 no stores, 2 no MFMA, 4 no staging
-  // GroupNorm statistics of the OUTPUT emitted by the epilogue (tf_conv2d_gn_f16): per (image, chunk, group) partial
+  // GroupNorm statistics of the OUTPUT emitted by the epilogue (tf_conv2d_fused_f16): per (image, chunk, group) partial
   // (sum, sum of squares) of the fp16-rounded outputs, in the layout k_gn_apply folds; NULL = off
   float* gn_part;
   int gn_G, gn_cpg, gn_chunks;
@@ -292,6 +297,8 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
     // =============================== LOADER WAVES ===============================================
     const rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x), 0, p.x2_bytes, 0x00020000);
+    const rsrc_t rs_x3 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x3 ? p.x3 : p.x), 0, p.x3_bytes, 0x00020000);
+    const rsrc_t rs_x4 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x4 ? p.x4 : p.x), 0, p.x4_bytes, 0x00020000);
     const rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
     // loader wave w4 owns groups g = w4 + 4 i; lane -> row 8 g + (lane >> 3), 16-B chunk lane & 7.
     // XOR swizzle on the SOURCE chunk (LDS image stays lane-linear): chunk ^ ((row >> 1) & 7); g = w4 (mod 4), so the
@@ -345,32 +352,54 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
     int st_r, st_s, st_c;                                  // wave-uniform (tap, channel) of the next tile to stage
     {
       int kg0 = kt_begin * 64;
-      int tap = kg0 / p.C;
-      st_c = kg0 - tap * p.C;
-      st_r = tap / p.S;
-      st_s = tap - st_r * p.S;
+      if (kg0 < p.Kc) {
+        int tap = kg0 / p.C;
+        st_c = kg0 - tap * p.C;
+        st_r = tap / p.S;
+        st_s = tap - st_r * p.S;
+      } else {                                             // inside the extra 1x1 segment: st_r = -1 marks it
+        st_r = -1; st_s = 0; st_c = kg0 - p.Kc;
+      }
     }
     auto stage = [&](int buf, int kt) {
       if (p.dbg & 4) return;
       char* base = smem + buf * STAGE;
       int r, s_, cc, ld;
-      bool kvalid = true, second;
+      bool kvalid = true, second, extra;
       if (GENERIC) {
         int kg = kt * 64 + cs * 8;
-        int tap = kg / p.C;
-        int c = kg - tap * p.C;
-        r = tap / p.S; s_ = tap - r * p.S;
         kvalid = kg < p.K;
-        second = c >= p.C1;
-        ld = second ? p.C2 : p.C1;
-        cc = second ? c - p.C1 : c;
+        extra = kg >= p.Kc;
+        if (!extra) {
+          int tap = kg / p.C;
+          int c = kg - tap * p.C;
+          r = tap / p.S; s_ = tap - r * p.S;
+          second = c >= p.C1;
+          ld = second ? p.C2 : p.C1;
+          cc = second ? c - p.C1 : c;
+        } else {
+          int c = kg - p.Kc;
+          r = p.pad; s_ = p.pad;                           // the output pixel itself: hi = ho * stride
+          second = c >= p.C3;
+          ld = second ? p.C4 : p.C3;
+          cc = second ? c - p.C3 : c;
+        }
       } else {
-        r = st_r; s_ = st_s;                               // all wave-uniform (SGPR)
-        second = st_c >= p.C1;
-        ld = second ? p.C2 : p.C1;
-        cc = (second ? st_c - p.C1 : st_c) + cs * 8;
-        st_c += 64;
-        if (st_c >= p.C) { st_c = 0; if (++st_s == p.S) { st_s = 0; ++st_r; } }
+        extra = st_r < 0;                                  // all wave-uniform (SGPR)
+        if (!extra) {
+          r = st_r; s_ = st_s;
+          second = st_c >= p.C1;
+          ld = second ? p.C2 : p.C1;
+          cc = (second ? st_c - p.C1 : st_c) + cs * 8;
+          st_c += 64;
+          if (st_c >= p.C) { st_c = 0; if (++st_s == p.S) { st_s = 0; if ((++st_r) * p.S * p.C >= p.Kc) st_r = -1; } }
+        } else {
+          r = p.pad; s_ = p.pad;
+          second = st_c >= p.C3;
+          ld = second ? p.C4 : p.C3;
+          cc = (second ? st_c - p.C3 : st_c) + cs * 8;
+          st_c += 64;
+        }
       }
       const unsigned kb = (unsigned)kt * 128u;
 #pragma unroll
@@ -382,10 +411,12 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
           bool ok = kvalid && (unsigned)hi < (unsigned)Hl && (unsigned)wi < (unsigned)Wl;
           int pix = g_c[i] + (hi >> p.ups) * p.W + (wi >> p.ups);
           unsigned off = ok ? (unsigned)(pix * ld + cc) * 2u : TF_OOB;
-          if (GENERIC) {
-            if (second) bload_lds16(rs_x2, off, dst); else bload_lds16(rs_x, off, dst);
+          if (GENERIC) {                                   // per-lane source: one masked issue per descriptor
+            if (extra) { if (second) bload_lds16(rs_x4, off, dst); else bload_lds16(rs_x3, off, dst); }
+            else { if (second) bload_lds16(rs_x2, off, dst); else bload_lds16(rs_x, off, dst); }
           } else {
-            bload_lds16(second ? rs_x2 : rs_x, off, dst);
+            if (extra) bload_lds16(second ? rs_x4 : rs_x3, off, dst);
+            else bload_lds16(second ? rs_x2 : rs_x, off, dst);
           }
         } else {
           unsigned wo = (unsigned)g_c[i];
@@ -629,7 +660,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(half_t* __restrict__ y, c
   }
 }
 
-// split-K reduce + epilogue + GroupNorm statistics of the output (tf_conv2d_gn_f16 on a split-K shape): a block owns R
+// split-K reduce + epilogue + GroupNorm statistics of the output (tf_conv2d_fused_f16 on a split-K shape): a block owns R
 // whole output rows (R = HoWo / chunks); thread t owns column quad t % nq and the rows r = t / nq (mod RL), so the
 // per-channel sums stay in its registers; row lanes and channels -> groups meet through LDS in a fixed order.
 // The split partials of an element are fetched 8 at a time (independent loads) and added in split order.
@@ -815,7 +846,7 @@ static int launch_cfg3(const GemmP& p, hipStream_t st) {
 }
 template <int BM, int BN, bool WIDE_OK>
 static int launch_cfg(const GemmP& p, hipStream_t st, bool wide) {
-  bool generic = (p.C1 % 64) != 0 || (p.C2 % 64) != 0;
+  bool generic = (p.C1 % 64) != 0 || (p.C2 % 64) != 0 || (p.C3 % 64) != 0 || (p.C4 % 64) != 0;
   if (WIDE_OK && wide) return generic ? launch_cfg3<BM, BN, true, WIDE_OK>(p, st) : launch_cfg3<BM, BN, false, WIDE_OK>(p, st);
   return generic ? launch_cfg3<BM, BN, true, false>(p, st) : launch_cfg3<BM, BN, false, false>(p, st);
 }
@@ -965,7 +996,7 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
   if (g_prof) {
     TF_HIP(hipEventCreate(&rec.a)); TF_HIP(hipEventCreate(&rec.b));
     rec.flops = 2.0 * p.M * (double)p.N * p.K;
-    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.taps = p.K / p.C; rec.bm = t.c.bm; rec.bn = t.c.bn; rec.splitk = t.c.splitk * (wide ? -1 : 1);
+    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.taps = p.Kc / p.C; rec.bm = t.c.bm; rec.bn = t.c.bn; rec.splitk = t.c.splitk * (wide ? -1 : 1);
     TF_HIP(hipEventRecord(rec.a, st));
   }
   if (g_force_order >= 0) t.order = g_force_order;
@@ -1106,8 +1137,11 @@ size_t tf_conv2d_workspace(int N, int H, int W, int C1, int C2, int Cout, int R,
 static int conv2d_impl(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
                        const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
                        void* workspace, size_t workspace_bytes, float* gn_partial, size_t gn_partial_bytes, int gn_groups, int* gn_chunks,
-                       tfStream_t s) {
+                       const void* x3, const void* x4, int C3, int C4, tfStream_t s) {
   if (gn_chunks) *gn_chunks = 0;
+  TF_REQUIRE(C3 >= 0 && C4 >= 0 && (C3 == 0 || x3) && (C4 == 0 || (x4 && C3 > 0)) && C3 % 8 == 0 && C4 % 8 == 0,
+             "tf_conv2d_fused_f16: extra sources C3=%d C4=%d must be multiples of 8 with their tensors given (x4 needs x3)", C3, C4);
+  TF_REQUIRE(C3 == 0 || upsample == 0, "tf_conv2d_fused_f16: the extra 1x1 sources cannot be combined with upsample");
   TF_REQUIRE(y && x && w, "tf_conv2d_f16: null tensor");
   TF_REQUIRE(C1 > 0 && C2 >= 0 && (C2 == 0 || x2), "tf_conv2d_f16: C1=%d C2=%d x2=%p", C1, C2, x2);
   TF_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0, "tf_conv2d_f16: channel counts must be multiples of 8 (C1=%d C2=%d); use tf_im2col_nhwc_f16 for tiny C", C1, C2);
@@ -1121,17 +1155,21 @@ static int conv2d_impl(void* y, const void* x, const void* x2, const void* w, co
   p.bias = (const half_t*)bias; p.bias_nc = (const half_t*)bias_nc; p.residual = (const half_t*)residual;
   p.bias_nc_stride = bias_nc_stride;
   TF_REQUIRE(bias_nc_stride % 4 == 0 || Cout % 4 != 0, "tf_conv2d_f16: bias_nc_stride must be a multiple of 4");
-  p.M = N * Ho * Wo; p.N = Cout; p.C1 = C1; p.C2 = C2; p.C = C1 + C2; p.K = R * S * p.C;
+  p.M = N * Ho * Wo; p.N = Cout; p.C1 = C1; p.C2 = C2; p.C = C1 + C2; p.Kc = R * S * p.C; p.K = p.Kc + C3 + C4;
+  p.x3 = (const half_t*)x3; p.x4 = (const half_t*)x4; p.C3 = C3; p.C4 = C4;
   p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.HoWo = Ho * Wo; p.S = S; p.stride = stride; p.pad = pad; p.ups = ups; p.act = 0;
   {
     long long xb = (long long)N * H * W * C1 * 2, x2b = (long long)N * H * W * C2 * 2, wb = (long long)Cout * p.K * 2;
     TF_REQUIRE(xb < (1LL << 31) && x2b < (1LL << 31) && wb < (1LL << 31), "tf_conv2d_f16: tensors must be < 2 GiB each");
     p.x_bytes = (unsigned)xb; p.x2_bytes = C2 ? (unsigned)x2b : (unsigned)xb; p.w_bytes = (unsigned)wb;
+    long long x3b = (long long)N * H * W * C3 * 2, x4b = (long long)N * H * W * C4 * 2;
+    TF_REQUIRE(x3b < (1LL << 31) && x4b < (1LL << 31), "tf_conv2d_fused_f16: tensors must be < 2 GiB each");
+    p.x3_bytes = C3 ? (unsigned)x3b : (unsigned)xb; p.x4_bytes = C4 ? (unsigned)x4b : (unsigned)xb;
   }
   if (gn_partial) {
-    TF_REQUIRE(gn_chunks, "tf_conv2d_gn_f16: gn_chunks must not be NULL");
-    TF_REQUIRE(gn_groups >= 1 && Cout % gn_groups == 0, "tf_conv2d_gn_f16: Cout=%d not divisible by groups=%d", Cout, gn_groups);
-    TF_REQUIRE(gn_partial_bytes >= tf_conv2d_gn_partial_bytes(N, gn_groups), "tf_conv2d_gn_f16: statistics buffer too small (%zu bytes)", gn_partial_bytes);
+    TF_REQUIRE(gn_chunks, "tf_conv2d_fused_f16: gn_chunks must not be NULL");
+    TF_REQUIRE(gn_groups >= 1 && Cout % gn_groups == 0, "tf_conv2d_fused_f16: Cout=%d not divisible by groups=%d", Cout, gn_groups);
+    TF_REQUIRE(gn_partial_bytes >= tf_conv2d_gn_partial_bytes(N, gn_groups), "tf_conv2d_fused_f16: statistics buffer too small (%zu bytes)", gn_partial_bytes);
     int cpg = Cout / gn_groups;
     // group width the epilogue can fold (a group spans at most two n-tiles, one lane per group of a tile); anything else
     // simply reports chunks = 0 and the caller runs tf_group_norm_f16 as usual
@@ -1146,16 +1184,22 @@ int tf_conv2d_f16(void* y, const void* x, const void* x2, const void* w, const v
                   const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
                   void* workspace, size_t workspace_bytes, tfStream_t s) {
   return conv2d_impl(y, x, x2, w, bias, bias_nc, bias_nc_stride, residual, N, H, W, C1, C2, Cout, R, S, stride, pad, upsample, workspace,
-                     workspace_bytes, nullptr, 0, 0, nullptr, s);
+                     workspace_bytes, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, s);
 }
 
-int tf_conv2d_gn_f16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
-                     const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
-                     void* workspace, size_t workspace_bytes, void* gn_partial, size_t gn_partial_bytes, int gn_groups, int* gn_chunks,
-                     tfStream_t s) {
-  TF_REQUIRE(gn_partial && gn_chunks, "tf_conv2d_gn_f16: null statistics buffer");
+int tf_conv2d_fused_f16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
+                        const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
+                        void* workspace, size_t workspace_bytes, const void* x3, const void* x4, int C3, int C4, void* gn_partial,
+                        size_t gn_partial_bytes, int gn_groups, int* gn_chunks, tfStream_t s) {
+  TF_REQUIRE(!gn_partial || gn_chunks, "tf_conv2d_fused_f16: gn_chunks must be given with gn_partial");
   return conv2d_impl(y, x, x2, w, bias, bias_nc, bias_nc_stride, residual, N, H, W, C1, C2, Cout, R, S, stride, pad, upsample, workspace,
-                     workspace_bytes, (float*)gn_partial, gn_partial_bytes, gn_groups, gn_chunks, s);
+                     workspace_bytes, (float*)gn_partial, gn_partial_bytes, gn_groups, gn_chunks, x3, x4, C3, C4, s);
+}
+
+size_t tf_conv2d_fused_workspace(int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample, int C3, int C4) {
+  int Ho, Wo;
+  if (stride < 1 || conv_geometry(H, W, R, S, stride, pad, upsample ? 1 : 0, &Ho, &Wo)) return 0;
+  return gemm_workspace(N * Ho * Wo, Cout, R * S * (C1 + C2) + C3 + C4, 0);
 }
 
 size_t tf_linear_workspace(int M, int N, int K, int act) { return gemm_workspace(M, act == 1 ? 2 * N : N, K, act); }
@@ -1169,7 +1213,7 @@ int tf_linear_f16(void* y, const void* x, const void* w, const void* bias, const
   if (M == 0) return TF_OK;
   GemmP p = {};
   p.x = (const half_t*)x; p.w = (const half_t*)w; p.y = (half_t*)y; p.bias = (const half_t*)bias; p.residual = (const half_t*)residual;
-  p.M = M; p.N = act == 1 ? 2 * N : N; p.K = K; p.C1 = K; p.C2 = 0; p.C = K;
+  p.M = M; p.N = act == 1 ? 2 * N : N; p.K = K; p.Kc = K; p.C1 = K; p.C2 = 0; p.C = K;
   p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.HoWo = M; p.S = 1; p.stride = 1; p.pad = 0; p.ups = 0; p.act = act;
   {
     long long xb = (long long)M * K * 2, wb = (long long)p.N * K * 2;
@@ -1198,7 +1242,7 @@ int tf_linear_ln_f16(void* y, const void* x, const void* w_folded, const void* b
   GemmP p = {};
   p.x = (const half_t*)x; p.w = (const half_t*)w_folded; p.y = (half_t*)y; p.bias = (const half_t*)bias_folded; p.residual = (const half_t*)residual;
   p.ln_colsum = (const float*)colsum; p.ln_eps = eps;
-  p.M = M; p.N = act == 1 ? 2 * N : N; p.K = K; p.C1 = K; p.C2 = 0; p.C = K;
+  p.M = M; p.N = act == 1 ? 2 * N : N; p.K = K; p.Kc = K; p.C1 = K; p.C2 = 0; p.C = K;
   p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.HoWo = M; p.S = 1; p.stride = 1; p.pad = 0; p.ups = 0; p.act = act;
   {
     long long xb = (long long)M * K * 2, wb = (long long)p.N * K * 2;

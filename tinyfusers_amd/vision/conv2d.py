@@ -13,7 +13,7 @@ from ..storage.tensor import DeviceArray, _sh, asarray
 from ..ff.linear import workspace, linear_f16
 
 
-def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, upsample=False, gn=0):
+def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, upsample=False, gn=0, extra=None):
     x2 = None
     if isinstance(x, (tuple, list)):
         x, x2 = x
@@ -21,13 +21,22 @@ def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, up
     assert stride[0] == stride[1] and padding[0] == padding[1]
     n, c1, h, wd = x.shape
     c2 = x2.shape[1] if x2 is not None else 0
-    k, c, r, s = w.shape
-    assert c == c1 + c2, (w.shape, x.shape)
+    x3 = x4 = None
+    c3 = c4 = 0
+    if extra is not None:
+        # w is then a packed (K, r*s*(c1+c2) + c3 + c4) row matrix: conv rows followed by the 1x1 rows of the extra sources
+        k, r, s = extra["cout"], extra["r"], extra["s"]
+        x3, x4 = extra["x"] if isinstance(extra["x"], (tuple, list)) else (extra["x"], None)
+        c3, c4 = x3.shape[1], (x4.shape[1] if x4 is not None else 0)
+        assert w.shape == (k, r * s * (c1 + c2) + c3 + c4), (w.shape, k, r, s, c1, c2, c3, c4)
+    else:
+        k, c, r, s = w.shape
+        assert c == c1 + c2, (w.shape, x.shape)
     up = 1 if upsample else 0
     ho = ((h << up) + 2 * padding[0] - r) // stride[0] + 1
     wo = ((wd << up) + 2 * padding[1] - s) // stride[1] + 1
     y = DeviceArray.empty((n, k, ho, wo), np.float16, "nhwc")
-    nb = hip.tf_conv2d_workspace(n, h, wd, c1, c2, k, r, s, stride[0], padding[0], up)
+    nb = hip.tf_conv2d_fused_workspace(n, h, wd, c1, c2, k, r, s, stride[0], padding[0], up, c3, c4)
     ws = workspace(nb)
     bnc_stride = 0
     if bias_nc is not None:
@@ -35,13 +44,16 @@ def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, up
     args = (y.ptr, x.ptr, x2.ptr if x2 is not None else None, w.ptr, bias.ptr if bias is not None else None,
             bias_nc.ptr if bias_nc is not None else None, bnc_stride, residual.ptr if residual is not None else None,
             n, h, wd, c1, c2, k, r, s, stride[0], padding[0], up, ws.ptr if ws else None, nb)
+    ex = (x3.ptr if x3 is not None else None, x4.ptr if x4 is not None else None, c3, c4)
     if gn:
         # the GroupNorm(gn) that consumes y next gets its statistics from this conv's epilogue (when the shape allows)
         pb = hip.tf_conv2d_gn_partial_bytes(n, gn)
         part, chunks = workspace(pb), ctypes.c_int(0)
-        hip.tf_conv2d_gn_f16(*args, part.ptr, pb, gn, ctypes.byref(chunks), _sh())
+        hip.tf_conv2d_fused_f16(*args, *ex, part.ptr, pb, gn, ctypes.byref(chunks), _sh())
         if chunks.value > 0:
             y.gn = (part, chunks.value, gn)
+    elif extra is not None:
+        hip.tf_conv2d_fused_f16(*args, *ex, None, 0, 0, None, _sh())
     else:
         hip.tf_conv2d_f16(*args, _sh())
     return y
@@ -88,8 +100,32 @@ class Conv2d:
             self.bias = asarray(np.random.uniform(-bound, bound, (out_channels,)).astype(np.float16)) if bias else None
         self._cache = {}
 
-    def __call__(self, x, bias_nc=None, residual=None, upsample=False, gn=0):
-        """gn = G: also emit the statistics of the output for the GroupNorm(G) that reads it next (y.gn)."""
+    def fold_1x1(self, proj):
+        """(w, bias) of this conv with the 1x1 conv ``proj`` folded in as extra K columns (see __call__'s ``extra``): packed
+        once on the device, rebuilt when either module's weights are replaced."""
+        key = (self.weight.ptr, self.bias.ptr, proj.weight.ptr, proj.bias.ptr)
+        if self._cache.get("fold_key") != key:
+            k, c, r, s = self.weight.shape
+            kc, ce = r * s * c, proj.weight.shape[1]
+            assert proj.weight.shape[0] == k and tuple(proj.weight.shape[2:]) == (1, 1)
+            wp = DeviceArray.empty((k, kc + ce), np.float16, "row")
+            hip.tf_memcpy_2d_async(wp.ptr, (kc + ce) * 2, self.weight.ptr, kc * 2, kc * 2, k, _sh())
+            hip.tf_memcpy_2d_async(wp.ptr + kc * 2, (kc + ce) * 2, proj.weight.ptr, ce * 2, ce * 2, k, _sh())
+            bp = DeviceArray.empty((k,), np.float16, "row")
+            hip.tf_add_f16(bp.ptr, self.bias.ptr, proj.bias.ptr, k, _sh())
+            self._cache["fold_key"], self._cache["fold"] = key, (wp, bp)
+        return self._cache["fold"]
+
+    def __call__(self, x, bias_nc=None, residual=None, upsample=False, gn=0, extra=None):
+        """gn = G: also emit the statistics of the output for the GroupNorm(G) that reads it next (y.gn).
+        extra = (proj, x3): add ``proj(x3)`` (a Conv2d 1x1; x3 a tensor or a concat pair) inside this conv's GEMM."""
+        if extra is not None:
+            proj, x3 = extra
+            wp, bp = self.fold_1x1(proj)
+            k, _, r, s = self.weight.shape
+            assert not isinstance(x, (tuple, list)) and x.shape[1] % 8 == 0
+            return _conv(x, wp, bp, self.padding, self.stride, self.dilation, bias_nc, residual, upsample, gn,
+                         {"x": x3, "cout": k, "r": r, "s": s})
         cin = (x[0].shape[1] + x[1].shape[1]) if isinstance(x, (tuple, list)) else x.shape[1]
         if cin % 8 != 0:
             assert bias_nc is None and residual is None and not upsample

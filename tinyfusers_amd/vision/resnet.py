@@ -42,6 +42,10 @@ class ResBlock:
         h = self.out_layers[0](h, silu=True)
         if br is not None:
             br.join()
+        elif config.fold_skip_projection and isinstance(self.skip_connection, Conv2d) and self.out_layers[3].weight.shape[0] % 8 == 0 \
+                and self.skip_connection.weight.shape[1] % 8 == 0:
+            # skip_connection(x) + h in ONE GEMM: the 1x1 projection rides as extra K columns of the last conv
+            return self.out_layers[3](h, gn=out_gn, extra=(self.skip_connection, x))
         else:
             skip = self.skip_connection(x)
         assert not isinstance(skip, (tuple, list)), "identity skip needs a single tensor (cin == cout)"

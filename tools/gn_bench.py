@@ -27,7 +27,7 @@ for n, hw, cin, cout, k, force in CASES:
     lib.tf_gemm_force_config(*force)
     args = (y.ptr, x.ptr, None, w.ptr, b.ptr, None, 0, None, n, hw, hw, cin, 0, cout, k, k, 1, k // 2, 0, ws.ptr, ws.nbytes)
     t0 = time_call(lambda: hip.tf_conv2d_f16(*args, st.handle))
-    t1 = time_call(lambda: hip.tf_conv2d_gn_f16(*args, part.ptr, pb, 32, ctypes.byref(ch), st.handle))
+    t1 = time_call(lambda: hip.tf_conv2d_fused_f16(*args, None, None, 0, 0, part.ptr, pb, 32, ctypes.byref(ch), st.handle))
     t2 = time_call(lambda: hip.tf_group_norm_f16(y2.ptr, y.ptr, None, gam.ptr, gam.ptr, n, hw * hw, cout, 0, 32, 1e-5, 1, gws.ptr, gws.nbytes, st.handle))
     t3 = time_call(lambda: hip.tf_group_norm_apply_f16(y2.ptr, y.ptr, gam.ptr, gam.ptr, part.ptr, max(ch.value, 1), n, hw * hw, cout, 32, 1e-5, 1, st.handle)) if ch.value else float("nan")
     lib.tf_gemm_force_config(0, 0, 0)
