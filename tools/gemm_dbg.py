@@ -23,18 +23,19 @@ def run(n, h, w, cin, cout, k, bm, bn, sk, label):
     lib.tf_gemm_debug(0); lib.tf_gemm_force_config(0, 0, 0)
     print(f"{label:24s} {bm}x{bn}/{sk}: full {out[0]:6.1f} | nostore {out[1]:6.1f} | nomfma {out[2]:6.1f} | nomfma+nostore {out[3]:6.1f} | noload {out[4]:6.1f} | noload+nostore {out[5]:6.1f} | noload+nomfma {out[6]:6.1f} | nothing {out[7]:6.1f}")
 
-run(2, 64, 64, 320, 320, 1, 64, 160, 1, "conv1x1 320@64")
-run(2, 64, 64, 320, 320, 3, 64, 160, 1, "conv3x3 320@64")
-run(2, 64, 64, 320, 320, 3, 128, 160, 1, "conv3x3 320@64")
-run(2, 32, 32, 640, 640, 3, 128, 160, 4, "conv3x3 640@32")
-run(2, 32, 32, 640, 640, 1, 64, 64, 1, "conv1x1 640@32")
-run(2, 16, 16, 1280, 1280, 3, 128, 160, 8, "conv3x3 1280@16")
-print("--- small-K shapes")
-run(2, 64, 64, 320, 2560, 1, 128, 128, 1, "geglu 320->2560@64")
-run(2, 64, 64, 320, 2560, 1, 64, 128, 1, "geglu 320->2560@64")
-run(2, 64, 64, 320, 2560, 1, 128, 160, 1, "geglu 320->2560@64")
-run(2, 64, 64, 320, 960, 1, 128, 160, 1, "qkv 320->960@64")
-run(2, 64, 64, 320, 960, 1, 64, 160, 1, "qkv 320->960@64")
-run(2, 64, 64, 1280, 320, 1, 64, 160, 1, "ff2 1280->320@64")
-run(2, 32, 32, 640, 640, 1, 64, 128, 1, "lin 640@32")
-run(2, 16, 16, 1280, 1280, 1, 64, 64, 1, "lin 1280@16")
+if __name__ == "__main__":
+    run(2, 64, 64, 320, 320, 1, 64, 160, 1, "conv1x1 320@64")
+    run(2, 64, 64, 320, 320, 3, 64, 160, 1, "conv3x3 320@64")
+    run(2, 64, 64, 320, 320, 3, 128, 160, 1, "conv3x3 320@64")
+    run(2, 32, 32, 640, 640, 3, 128, 160, 4, "conv3x3 640@32")
+    run(2, 32, 32, 640, 640, 1, 64, 64, 1, "conv1x1 640@32")
+    run(2, 16, 16, 1280, 1280, 3, 128, 160, 8, "conv3x3 1280@16")
+    print("--- small-K shapes")
+    run(2, 64, 64, 320, 2560, 1, 128, 128, 1, "geglu 320->2560@64")
+    run(2, 64, 64, 320, 2560, 1, 64, 128, 1, "geglu 320->2560@64")
+    run(2, 64, 64, 320, 2560, 1, 128, 160, 1, "geglu 320->2560@64")
+    run(2, 64, 64, 320, 960, 1, 128, 160, 1, "qkv 320->960@64")
+    run(2, 64, 64, 320, 960, 1, 64, 160, 1, "qkv 320->960@64")
+    run(2, 64, 64, 1280, 320, 1, 64, 160, 1, "ff2 1280->320@64")
+    run(2, 32, 32, 640, 640, 1, 64, 128, 1, "lin 640@32")
+    run(2, 16, 16, 1280, 1280, 1, 64, 64, 1, "lin 1280@16")
