@@ -402,6 +402,14 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
         }
       }
       const unsigned kb = (unsigned)kt * 128u;
+      // non-GENERIC: the source tensor of this K tile is wave-uniform -> ONE descriptor built here from the argument
+      // block instead of four kept alive for the whole kernel (the kernel is SGPR-bound: 106 of 106)
+      rsrc_t rs_a = rs_w;
+      if (!GENERIC) {
+        const half_t* sp = extra ? (second ? p.x4 : p.x3) : (second ? p.x2 : p.x);
+        const unsigned sbytes = extra ? (second ? p.x4_bytes : p.x3_bytes) : (second ? p.x2_bytes : p.x_bytes);
+        rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)sp, 0, sbytes, 0x00020000);
+      }
 #pragma unroll
       for (int i = 0; i < LPS; ++i) {
         const int g = w4 + 4 * i;                          // wave-uniform
@@ -415,8 +423,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
             if (extra) { if (second) bload_lds16(rs_x4, off, dst); else bload_lds16(rs_x3, off, dst); }
             else { if (second) bload_lds16(rs_x2, off, dst); else bload_lds16(rs_x, off, dst); }
           } else {
-            if (extra) bload_lds16(second ? rs_x4 : rs_x3, off, dst);
-            else bload_lds16(second ? rs_x2 : rs_x, off, dst);
+            bload_lds16(rs_a, off, dst);                   // this K tile's (wave-uniform) source
           }
         } else {
           unsigned wo = (unsigned)g_c[i];
