@@ -3,7 +3,8 @@
 CLIP text encoder for the two contexts (:44-49), timesteps = range(1,1000,1000//steps), reversed loop, VAE decode.
 No checkpoint or BPE vocabulary exists offline, so by default the weights are the seeded synthetic ones and
 the "prompt" is a seeded list of token ids; ``--ckpt file.ckpt|file.safetensors`` reads real LDM weights through
-storage/unpicker.py + update_state instead (example/sd1.py:40-41).
+storage/unpicker.py + update_state instead (example/sd1.py:40-41), ``--vocab bpe_simple_vocab_16e6.txt.gz --prompt "..."``
+tokenizes a real prompt (tokenizer/clip.py).
 BASELINE config 3: full 50-step sampler, batch 1, end-to-end img/s.
 
     python -m example.sd1 --steps 50 [--ckpt sd-v1-4.ckpt] [--out rendered.npy]
@@ -25,6 +26,8 @@ if __name__ == "__main__":
     ap.add_argument("--images", type=int, default=3, help="images to time after the first (compile + warm-up) one")
     ap.add_argument("--out", default="")
     ap.add_argument("--ckpt", default="", help="LDM checkpoint (.ckpt torch zip or .safetensors); default: synthetic weights")
+    ap.add_argument("--vocab", default="", help="local bpe_simple_vocab_16e6.txt.gz for the prompt; default: seeded token ids")
+    ap.add_argument("--prompt", default="a horse sized cat eating a bagel")
     args = ap.parse_args()
 
     import oracle  # only for the parameter-shape enumerator of the VAE (names); no oracle compute is used
@@ -49,10 +52,15 @@ if __name__ == "__main__":
     del state
     print(f"weights installed in {time.time() - t0:.1f}s")
     # run through CLIP to get the contexts (example/sd1.py:44-49); token ids stand in for tokenizer.encode(prompt)
-    rng = np.random.default_rng(args.seed)
-    n_words = 9
-    prompt = np.full((1, 77), 49407, dtype=np.int64); prompt[0, 0] = 49406; prompt[0, 1:1 + n_words] = rng.integers(0, 49406, n_words)
-    empty = np.full((1, 77), 49407, dtype=np.int64); empty[0, 0] = 49406
+    if args.vocab:
+        from tinyfusers_amd.tokenizer.clip import ClipTokenizer
+        tokenizer = ClipTokenizer(args.vocab)
+        prompt, empty = np.array([tokenizer.encode(args.prompt)]), np.array([tokenizer.encode("")])
+    else:
+        rng = np.random.default_rng(args.seed)
+        n_words = 9
+        prompt = np.full((1, 77), 49407, dtype=np.int64); prompt[0, 0] = 49406; prompt[0, 1:1 + n_words] = rng.integers(0, 49406, n_words)
+        empty = np.full((1, 77), 49407, dtype=np.int64); empty[0, 0] = 49406
     text_model = model.cond_stage_model.transformer.text_model
     text_model(prompt)                                           # first call folds the LayerNorms / fuses q|k|v once
     T.hip.tf_stream_sync(None)

@@ -15,7 +15,7 @@ so it is imported under stand-in modules, exactly as SURVEY 8(c) describes:
   * ``tinyfusers.tensor.tensor`` aliased to ``tinyfusers.storage.tensor`` (D1).
 Nothing from the reference is written anywhere: outputs are numeric arrays only.
 
-Usage:  python tests/golden/make_golden.py [ops] [blocks] [unet] [vae] [clip]
+Usage:  python tests/golden/make_golden.py [ops] [blocks] [unet] [vae] [clip] [tokenizer]
 """
 import os
 import sys
@@ -343,6 +343,66 @@ def gen_clip():
     print("clip_text.npz written (hidden: synth 'clip.hidden' seed 1234 std 0.05; weights: synth seed 0)")
 
 
+TOKENIZER_TEXTS = [
+    "a horse sized cat eating a bagel", "", "  Multiple   spaces\tand\nnewlines  ", "It's the cat's pyjamas, isn't it? They've won!",
+    "UPPER lower MiXeD", "naive cafe \u00e9l\u00e8ve \u00fcber stra\u00dfe", "emoji \U0001F600 and symbols #$%&*()[]{}", "<|startoftext|>quoted<|endoftext|> specials",
+    "aaaaaaaaaaaaaaaaaaaa bbbbbbbbbb abababababab", "the quick brown fox jumps over the lazy dog " * 12,
+    "supercalifragilisticexpialidocious antidisestablishmentarianism", "1234567890 3.14159 2024-10-03", "x",
+]
+
+
+def toy_merges(n_merges=400):
+    """A small byte-level BPE merge table trained here on a fixed paragraph (most frequent pair first, ties broken by
+    the pair itself): DATA for the tokenizer fixture, in the format of bpe_simple_vocab_16e6.txt.gz."""
+    from collections import Counter
+    from tinyfusers_amd.tokenizer.clip import byte_symbols
+    table, _ = byte_symbols()
+    corpus = (" ".join(TOKENIZER_TEXTS) + " the cat sat on the mat and ate the bagel while a horse watched the lazy dog jump over "
+              "the quick brown fox again and again because eating is something that cats horses and dogs all like doing").lower().split()
+    words = Counter(tuple(table[b] for b in w.encode("utf-8"))[:-1] + (table[w.encode("utf-8")[-1]] + "</w>",) for w in corpus)
+    merges = []
+    for _ in range(n_merges):
+        pairs = Counter()
+        for w, c in words.items():
+            for a, b in zip(w, w[1:]):
+                pairs[(a, b)] += c
+        if not pairs:
+            break
+        best = min(pairs, key=lambda p: (-pairs[p], p))
+        merges.append(best)
+        nw = Counter()
+        for w, c in words.items():
+            out, i = [], 0
+            while i < len(w):
+                if i + 1 < len(w) and (w[i], w[i + 1]) == best:
+                    out.append(w[i] + w[i + 1]); i += 2
+                else:
+                    out.append(w[i]); i += 1
+            nw[tuple(out)] += c
+        words = nw
+    return merges
+
+
+def gen_tokenizer():
+    """ClipTokenizer of the reference (tokenizer/clip.py) on a toy merge table: its module calls tinygrad's fetch() for the
+    real table while being imported, so tinygrad.helpers is a stand-in whose fetch returns the toy file."""
+    import gzip, json
+    path = os.path.join(HERE, "clip_bpe_toy.txt.gz")
+    merges = toy_merges()
+    with gzip.GzipFile(path, "wb", mtime=0) as f:
+        f.write(("#version: toy table for tests, %d merges\n" % len(merges) + "\n".join(a + " " + b for a, b in merges)).encode("utf-8"))
+    tg = types.ModuleType("tinygrad"); th = types.ModuleType("tinygrad.helpers")
+    th.fetch = lambda url, name=None: path
+    tg.helpers = th
+    sys.modules["tinygrad"], sys.modules["tinygrad.helpers"] = tg, th
+    from tinyfusers.tokenizer.clip import ClipTokenizer
+    tok = ClipTokenizer()
+    out = {t: tok.encode(t) for t in TOKENIZER_TEXTS}
+    with open(os.path.join(HERE, "clip_tokens.json"), "w") as f:
+        json.dump({"texts": TOKENIZER_TEXTS, "ids": [out[t] for t in TOKENIZER_TEXTS], "vocab_size": len(tok.encoder)}, f)
+    print("clip_bpe_toy.txt.gz (%d merges), clip_tokens.json (%d texts, vocab %d)" % (len(merges), len(out), len(tok.encoder)))
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["ops", "blocks"]
     import_reference()
@@ -351,3 +411,4 @@ if __name__ == "__main__":
     if "unet" in what: gen_unet()
     if "vae" in what: gen_vae()
     if "clip" in what: gen_clip()
+    if "tokenizer" in what: gen_tokenizer()
