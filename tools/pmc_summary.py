@@ -6,7 +6,7 @@ usage: pmc_summary.py <fetch_dir> <write_dir> [out.json]"""
 import csv, glob, json, sys
 
 def load(d, counter):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     tot, n = {}, {}
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter: continue
