@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of the HIP-graph replay")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--tune-cache", default="", help="file to load/save the GEMM autotuner's per-shape choices (optional)")
+    ap.add_argument("--images", type=int, default=1, help="images per GPU (UNet batch = 2x); default 1 = BASELINE config 2")
+    ap.add_argument("--latent", type=int, default=64, help="latent height = width; default 64 (512x512 images); 96 = 768x768 (config 5)")
     return ap.parse_args()
 
 
@@ -131,9 +133,10 @@ def main():
     sd = StableDiffusion()
     arena, arena_bytes, t_gen, t_bcast = build_weight_arena(sd.model.diffusion_model, rank, world, local_rank)
     seed = 1234 + rank
-    lat = sd.latent_from_numpy(synth_normal(seed, "sd.latent", (1, 4, 64, 64)))
-    ctx = T.DeviceArray.from_numpy(synth_normal(seed, "sd.context", (1, 77, 768)))
-    unc = T.DeviceArray.from_numpy(synth_normal(seed, "sd.uncond", (1, 77, 768)))
+    B, S = args.images, args.latent
+    lat = sd.latent_from_numpy(synth_normal(seed, "sd.latent", (B, 4, S, S)))
+    ctx = T.DeviceArray.from_numpy(synth_normal(seed, "sd.context", (B, 77, 768)))
+    unc = T.DeviceArray.from_numpy(synth_normal(seed, "sd.uncond", (B, 77, 768)))
     timesteps = list(range(1, 1000, 20))
     ac = sd.alphas_cumprod
     alphas = ac[timesteps]
@@ -199,17 +202,18 @@ def main():
                     "gemm_ms_per_step": round(gms.value / n_inst, 4), "gemm_flop_per_step": gfl.value / n_inst}
 
     if rank == 0:
-        steps_per_s = world * args.steps / wall
+        steps_per_s = world * B * args.steps / wall      # image-steps per second (one unit = one denoising step of one image)
+        flop_unit = {64: FLOP_PER_STEP, 96: 4.30e12}.get(S)       # algorithmic FLOP per image-step
         out = {
             "metric": "unet_denoise_steps_per_sec", "value": round(steps_per_s, 2), "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "SD1.5 UNet single denoise step (CFG batch 2 + DDIM update), 64x64x4 latent, 1 image per GPU, fp16, 50-step DDIM schedule",
-                       "global_batch": world, "latent": [4, 64, 64], "parallelism": f"dp{world} (batch-sharded, RCCL weight broadcast only, no per-step collective)",
+            "config": {"workload": f"SD1.5 UNet single denoise step (CFG batch 2 + DDIM update), {S}x{S}x4 latent, {B} image{'s' if B > 1 else ''} per GPU, fp16, 50-step DDIM schedule",
+                       "global_batch": world * B, "latent": [4, S, S], "parallelism": f"dp{world} (batch-sharded, RCCL weight broadcast only, no per-step collective)",
                        "launch": "eager" if args.eager else "hipGraph"},
             "device_ms_per_step": round(ms.value / args.steps, 4),
-            "step_tflops": round(FLOP_PER_STEP * args.steps / (ms.value * 1e-3) / 1e12, 1),
-            "step_mfma_frac": round(FLOP_PER_STEP * args.steps / (ms.value * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4),
+            "step_tflops": round(flop_unit * B * args.steps / (ms.value * 1e-3) / 1e12, 1) if flop_unit else None,
+            "step_mfma_frac": round(flop_unit * B * args.steps / (ms.value * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4) if flop_unit else None,
             "weights": {"bytes": arena_bytes, "synth_s": round(t_gen, 2), "bcast_s": round(t_bcast, 4)},
             "roofline": roofline,
         }
