@@ -147,9 +147,16 @@ def main():
     if args.tune_cache and rank == 0:
         hip.tf_gemm_tune_save(args.tune_cache.encode())
 
+    lat0 = T.DeviceArray.empty(lat.shape, np.float32, "row")
+    hip.tf_memcpy(lat0.ptr, lat.ptr, lat.nbytes, 3)
+
     def run(n, eager):
         for s in range(n):
             i = 49 - (s % 50)
+            if i == 49 and s > 0:
+                # a new 50-step trajectory starts from the initial noise again (64 KB device copy on the step stream): with
+                # synthetic weights a latent pushed through several schedules back to back eventually overflows fp16
+                hip.tf_memcpy_async(lat.ptr, lat0.ptr, lat.nbytes, 3, sd._stream.handle)
             sd.step(timesteps[i], alphas[i], alphas_prev[i], 7.5, eager=eager)
 
     def barrier():

@@ -34,8 +34,8 @@ __device__ __forceinline__ s4v lds_tr16(const half_t* p) {
 // the query block fastest, so all query blocks of one (batch, head) sit on one XCD and its K/V stream through that
 // L2 once instead of through all eight (bijective remap, any grid size).
 struct SdpaBlk { int qb, h, b; };
-__device__ __forceinline__ SdpaBlk sdpa_block(const SdpaP& p) {
-  const int nqb = (p.Tq + 127) / 128, nblk = nqb * p.NH * p.B;
+__device__ __forceinline__ SdpaBlk sdpa_block(const SdpaP& p, const int QB = 128) {
+  const int nqb = (p.Tq + QB - 1) / QB, nblk = nqb * p.NH * p.B;
   int bid = blockIdx.x;
   int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
   bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -311,8 +311,9 @@ struct SdpaDma {
   static_assert(S >= 2, "ring needs two stages");
 };
 
-template <int HS>
+template <int HS, int QT>
 __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
+  constexpr int QW = 16 * QT, QB = 4 * QW;          // queries per wave / per block
   using C = SdpaDma<HS>;
   constexpr int NKS = C::NKS, NDT = C::NDT, CK = C::CK, KPC = C::KPC, VPC = C::VPC, KP = C::KP, VP = C::VP;
   constexpr int S = C::S, NI = C::NI, LPW = C::LPW, STAGE_B = C::STAGE_B;
@@ -320,9 +321,9 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
-  const SdpaBlk blk = sdpa_block(p);
+  const SdpaBlk blk = sdpa_block(p, QB);
   const int b = blk.b, h = blk.h;
-  const int qblk = blk.qb * 128 + wid * 32;
+  const int qblk = blk.qb * QB + wid * QW;
   const half_t* qb = p.q + b * p.q_sb + h * p.q_sh;
   const half_t* kb = p.k + b * p.k_sb + h * p.k_sh;
   const half_t* vb = p.v + b * p.v_sb + h * p.v_sh;
@@ -330,9 +331,9 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   for (int i = tid; i < S * STAGE_B / 16; i += 256) reinterpret_cast<u4*>(smem_raw)[i] = (u4){0, 0, 0, 0};
 
-  h8 qf[2][NKS];
+  h8 qf[QT][NKS];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     int qi = qblk + qt * 16 + lr;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
@@ -346,7 +347,7 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
 
   int ntiles = (p.Tk + 63) / 64;
   if (p.causal) {
-    int last_q = min(p.Tq, blk.qb * 128 + 128) - 1;
+    int last_q = min(p.Tq, blk.qb * QB + QB) - 1;
     ntiles = min(ntiles, last_q / 64 + 1);
   }
 
@@ -380,11 +381,12 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
     }
   };
 
-  f4 ot[NDT][2], lt[2];
+  f4 ot[NDT][QT], lt[QT];
 #pragma unroll
-  for (int dt = 0; dt < NDT; ++dt) { ot[dt][0] = (f4){0, 0, 0, 0}; ot[dt][1] = (f4){0, 0, 0, 0}; }
-  lt[0] = (f4){0, 0, 0, 0}; lt[1] = (f4){0, 0, 0, 0};
-  float m_run[2] = {0.f, 0.f};
+  for (int dt = 0; dt < NDT; ++dt) { for (int q_ = 0; q_ < QT; ++q_) ot[dt][q_] = (f4){0, 0, 0, 0}; }
+  for (int q_ = 0; q_ < QT; ++q_) lt[q_] = (f4){0, 0, 0, 0};
+  float m_run[QT];
+  for (int q_ = 0; q_ < QT; ++q_) m_run[q_] = 0.f;
   const h8 ones = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
 
   __syncthreads();                       // zero fill done (and drained) before the first DMA lands
@@ -407,15 +409,17 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
     const half_t* ks_ = reinterpret_cast<const half_t*>(smem_raw + (t % S) * STAGE_B);
     const half_t* vs_ = ks_ + 64 * KP;
 
-    f4 st[4][2];
-    const f4 init4[2] = {{-m_run[0], -m_run[0], -m_run[0], -m_run[0]}, {-m_run[1], -m_run[1], -m_run[1], -m_run[1]}};
+    f4 st[4][QT];
+    f4 init4[QT];
+#pragma unroll
+    for (int q_ = 0; q_ < QT; ++q_) init4[q_] = (f4){-m_run[q_], -m_run[q_], -m_run[q_], -m_run[q_]};
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         h8 kf = *reinterpret_cast<const h8*>(ks_ + (16 * kt + lr) * KP + ks * 32 + lg * 8);
-        st[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], ks == 0 ? init4[0] : st[kt][0], 0, 0, 0);
-        st[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], ks == 0 ? init4[1] : st[kt][1], 0, 0, 0);
+#pragma unroll
+        for (int q_ = 0; q_ < QT; ++q_) st[kt][q_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[q_][ks], ks == 0 ? init4[q_] : st[kt][q_], 0, 0, 0);
       }
     }
     const int kbase = t * 64 + 8 * lg;
@@ -426,16 +430,16 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
         for (int e = 0; e < 4; ++e) {
           int key = kbase + 32 * (kt >> 1) + 4 * (kt & 1) + e;
 #pragma unroll
-          for (int qt = 0; qt < 2; ++qt) {
+          for (int qt = 0; qt < QT; ++qt) {
             int qi = qblk + qt * 16 + lr;
             if (key >= p.Tk || (p.causal && key > qi)) st[kt][qt][e] = -INFINITY;
           }
         }
     }
     constexpr float RESCALE_THR = 6.0f;
-    float mx[2];
+    float mx[QT];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
       float m0_ = fmaxf(fmaxf(st[0][qt][0], st[0][qt][1]), fmaxf(st[0][qt][2], st[0][qt][3]));
 #pragma unroll
       for (int kt = 1; kt < 4; ++kt) {
@@ -446,9 +450,12 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
       m0_ = fmaxf(m0_, __shfl_xor(m0_, 32, 64));
       mx[qt] = m0_;
     }
-    if (t == 0 || __any((mx[0] > RESCALE_THR) || (mx[1] > RESCALE_THR))) {
+    bool over = false;
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
+    for (int q_ = 0; q_ < QT; ++q_) over = over || (mx[q_] > RESCALE_THR);
+    if (t == 0 || __any(over)) {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
         float delta = mx[qt] == -INFINITY ? 0.f : (t == 0 ? mx[qt] : fmaxf(mx[qt], 0.f));
         m_run[qt] += delta;
         if (t != 0) {
@@ -463,17 +470,17 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
           for (int e = 0; e < 4; ++e) st[kt][qt][e] -= delta;
       }
     }
-    h8 pf[2][2];
+    h8 pf[2][QT];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) pf[kt >> 1][qt][(kt & 1) * 4 + e] = (half_t)__builtin_amdgcn_exp2f(st[kt][qt][e]);
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
-      lt[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[kc][0], lt[0], 0, 0, 0);
-      lt[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[kc][1], lt[1], 0, 0, 0);
+#pragma unroll
+      for (int q_ = 0; q_ < QT; ++q_) lt[q_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[kc][q_], lt[q_], 0, 0, 0);
     }
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
@@ -483,15 +490,15 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
         s4v v0 = lds_tr16(va), v1 = lds_tr16(va + 4 * VP);
         union { struct { s4v a, b; } s; h8 h; } u;
         u.s.a = v0; u.s.b = v1;
-        ot[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.h, pf[kc][0], ot[dt][0], 0, 0, 0);
-        ot[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.h, pf[kc][1], ot[dt][1], 0, 0, 0);
+#pragma unroll
+        for (int q_ = 0; q_ < QT; ++q_) ot[dt][q_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.h, pf[kc][q_], ot[dt][q_], 0, 0, 0);
       }
     }
   }
 
   half_t* ob = p.o + b * p.o_sb + h * p.o_sh;
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     float l = lt[qt][0];
     float inv = l > 0.f ? 1.0f / l : 0.f;
     int qi = qblk + qt * 16 + lr;
@@ -510,15 +517,16 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
   }
 }
 
-template <int HS>
+template <int HS, int QT>
 static int launch_sdpa_dma(const SdpaP& p, hipStream_t st) {
   constexpr int smem = SdpaDma<HS>::S * SdpaDma<HS>::STAGE_B;
+  constexpr int QB = 64 * QT;
   static bool attr_set = false;
   if (!attr_set) {
-    TF_HIP(hipFuncSetAttribute((const void*)k_sdpa_dma<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    TF_HIP(hipFuncSetAttribute((const void*)k_sdpa_dma<HS, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_sdpa_dma<HS>), dim3((unsigned)((p.Tq + 127) / 128 * p.NH * p.B)), dim3(256), smem, st, p);
+  hipLaunchKernelGGL((k_sdpa_dma<HS, QT>), dim3((unsigned)((p.Tq + QB - 1) / QB * p.NH * p.B)), dim3(256), smem, st, p);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
@@ -536,7 +544,8 @@ static int launch_sdpa(const SdpaP& p, hipStream_t st) {
   return TF_OK;
 }
 
-static bool g_sdpa_generic = getenv("TF_SDPA_GENERIC") != nullptr;   // debugging: force the register-staged kernel
+static bool g_sdpa_generic = getenv("TF_SDPA_GENERIC") != nullptr;
+static int g_sdpa_qt = getenv("TF_SDPA_QT") ? atoi(getenv("TF_SDPA_QT")) : 0;   // debugging: force the register-staged kernel
 
 extern "C" int tf_sdpa_f16(void* o, const void* q, const void* k, const void* v, int B, int NH, int Tq, int Tk, int HS, long long q_sb,
                            long long q_sh, long long q_st, long long k_sb, long long k_sh, long long k_st, long long v_sb, long long v_sh,
@@ -544,7 +553,7 @@ extern "C" int tf_sdpa_f16(void* o, const void* q, const void* k, const void* v,
   TF_REQUIRE(o && q && k && v, "tf_sdpa_f16: null tensor");
   TF_REQUIRE(B >= 0 && NH >= 1 && Tq >= 0 && Tk >= 1, "tf_sdpa_f16: bad sizes B=%d NH=%d Tq=%d Tk=%d", B, NH, Tq, Tk);
   TF_REQUIRE(HS >= 8 && HS % 8 == 0 && HS <= 160, "tf_sdpa_f16: head size %d must be a multiple of 8 in [8, 160]", HS);
-  TF_REQUIRE((long long)((Tq + 127) / 128) * NH * B < (1ll << 31), "tf_sdpa_f16: too many (query block, head, batch) work items");
+  TF_REQUIRE((long long)((Tq + 63) / 64) * NH * B < (1ll << 31), "tf_sdpa_f16: too many (query block, head, batch) work items");
   const long long str[] = {q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st};
   for (int i = 0; i < 9; ++i) TF_REQUIRE(str[i] % 8 == 0, "tf_sdpa_f16: q/k/v strides must be multiples of 8 elements (16-B rows)");
   TF_REQUIRE(o_sb % 4 == 0 && o_sh % 4 == 0 && o_st % 4 == 0, "tf_sdpa_f16: output strides must be multiples of 4 elements");
@@ -560,11 +569,23 @@ extern "C" int tf_sdpa_f16(void* o, const void* q, const void* k, const void* v,
   // K/V offsets inside a (batch, head) slice must fit the 32-bit buffer offsets of the DMA kernels
   const bool small = ((long long)Tk * k_st + HS) * 2 < (1ll << 31) && ((long long)Tk * v_st + HS) * 2 < (1ll << 31);
   if (small && !g_sdpa_generic) {
-    if (HS == 40) return launch_sdpa_dma<40>(p, st);
-    if (HS == 64) return launch_sdpa_dma<64>(p, st);
-    if (HS == 80) return launch_sdpa_dma<80>(p, st);
-    if (HS == 128) return launch_sdpa_dma<128>(p, st);
-    if (HS == 160) return launch_sdpa_dma<160>(p, st);
+    // 16 queries per wave (QT = 1) doubles the waves in flight; g_sdpa_qt: 0 = per-shape choice, 1 / 2 forced (TF_SDPA_QT)
+    // (measured: 32x32 d80 22.5 -> 19.7 us, 16x16 d160 13.4 -> 10.6 us with 16-query waves; 64x64 d40 93.8 -> 118.7 us: only when
+    // the 32-query grid would leave CUs without a block)
+    const long long blocks2 = (long long)((Tq + 127) / 128) * NH * B;
+    const bool narrow = g_sdpa_qt ? g_sdpa_qt == 1 : blocks2 < 256;
+    if (narrow) {
+      if (HS == 40) return launch_sdpa_dma<40, 1>(p, st);
+      if (HS == 64) return launch_sdpa_dma<64, 1>(p, st);
+      if (HS == 80) return launch_sdpa_dma<80, 1>(p, st);
+      if (HS == 128) return launch_sdpa_dma<128, 1>(p, st);
+      if (HS == 160) return launch_sdpa_dma<160, 1>(p, st);
+    }
+    if (HS == 40) return launch_sdpa_dma<40, 2>(p, st);
+    if (HS == 64) return launch_sdpa_dma<64, 2>(p, st);
+    if (HS == 80) return launch_sdpa_dma<80, 2>(p, st);
+    if (HS == 128) return launch_sdpa_dma<128, 2>(p, st);
+    if (HS == 160) return launch_sdpa_dma<160, 2>(p, st);
   }
   // (DQK, DV) = (HS rounded up to 32, HS + 1 rounded up to 16): the V tile always has room for the ones column
   if (HS <= 32) return launch_sdpa<32, 48>(p, st);
