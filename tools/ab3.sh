@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B on one box: tools/ab.sh "ENV_A=.." "ENV_B=.." [rounds]  -- alternates bench.py runs, prints ms/step of each
-A="$1"; B="$2"; R=${3:-3}
+# tools/ab3.sh rounds VAR=val1 VAR=val2 ... : alternates bench runs over the listed settings on one box
+R=$1; shift
 mkdir -p gpurun_out
 for i in $(seq 1 $R); do
-  for v in "$A" "$B"; do
+  for v in "$@"; do
     ( export $v; exec python bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-roofline > gpurun_out/ab.json 2> gpurun_out/ab.err )
     python - <<PY
 import json
