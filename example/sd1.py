@@ -30,9 +30,8 @@ if __name__ == "__main__":
     ap.add_argument("--prompt", default="a horse sized cat eating a bagel")
     args = ap.parse_args()
 
-    import oracle  # only for the parameter-shape enumerator of the VAE (names); no oracle compute is used
     import tinyfusers_amd.storage.tensor as T
-    from tinyfusers_amd.storage.state import unet_param_shapes, update_state
+    from tinyfusers_amd.storage.state import param_shapes, update_state
     from tinyfusers_amd.storage.synth import synth_normal, synth_state_dict
     from tinyfusers_amd.variants.sd import StableDiffusion
 
@@ -44,9 +43,7 @@ if __name__ == "__main__":
         from tinyfusers_amd.storage.unpicker import load_checkpoint
         state = load_checkpoint(args.ckpt)                       # memory-mapped; update_state streams tensor by tensor
     else:
-        shapes = {"model.diffusion_model." + k: v for k, v in unet_param_shapes(model.model.diffusion_model).items()}
-        state = {**synth_state_dict(shapes, 0), **synth_state_dict(oracle.vae_decoder_param_shapes(), 0),
-                 **synth_state_dict(oracle.clip_param_shapes(), 0)}
+        state = synth_state_dict(param_shapes(model), 0)       # UNet + VAE decoder + CLIP text encoder, by LDM name
     with contextlib.redirect_stdout(io.StringIO()):
         update_state(model, state, "")
     del state

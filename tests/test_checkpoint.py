@@ -112,3 +112,9 @@ def test_update_state_key_walk_matches_checkpoint_names():
     extra = {k for k in seen - want if not k.endswith((".to_q.bias", ".to_k.bias", ".to_v.bias"))}
     assert not extra, sorted(extra)[:5]
     assert not (want - seen), sorted(want - seen)[:5]
+    # the package's own shape enumerator (what example/sd1.py synthesises weights from) agrees name for name, shape for shape
+    from tinyfusers_amd.storage.state import param_shapes
+    shapes = {"model.diffusion_model." + k: tuple(v) for k, v in oracle.unet_param_shapes(oracle.SD15).items()}
+    shapes.update({k: tuple(v) for k, v in oracle.vae_decoder_param_shapes().items()})
+    shapes.update({k: tuple(v) for k, v in oracle.clip_param_shapes().items()})
+    assert param_shapes(StableDiffusion(init=False)) == shapes

@@ -3,6 +3,8 @@ dict building dotted LDM checkpoint names and replacing each ``weight`` / ``bias
 fp16 DeviceArray (4-D conv weights are stored KRSC by the NHWC rule), uploaded once."""
 from collections import OrderedDict
 
+import types
+
 import numpy as np
 
 from .tensor import DeviceArray, asarray
@@ -41,36 +43,50 @@ def update_state(obj, state_dict, prefix=''):
                 update_state(v, state_dict, f"{pre}")
 
 
+def param_shapes(obj, prefix=""):
+    """name -> logical shape of every weight/bias leaf below ``obj`` (any of the package's modules, lists / namedtuples of
+    them, or the whole StableDiffusion), by the same attribute walk as update_state; nothing needs to be initialised."""
+    from ..ff.embedding import Embedding
+    from ..ff.group_norm import GroupNorm
+    from ..ff.layer_norm import LayerNorm
+    from ..ff.linear import Linear
+    from ..vision.conv2d import Conv2d
+    shapes = {}
+
+    def visit(o, pre):
+        if o is None or isinstance(o, (DeviceArray, np.ndarray, int, float, str, bool)):
+            return
+        if isinstance(o, Linear):
+            shapes[pre + ".weight"] = (o.out_features, o.in_features)
+            if o._has_bias:
+                shapes[pre + ".bias"] = (o.out_features,)
+        elif isinstance(o, Conv2d):
+            shapes[pre + ".weight"] = tuple(o._shape)
+            shapes[pre + ".bias"] = (o._shape[0],)
+        elif isinstance(o, GroupNorm):
+            shapes[pre + ".weight"] = (o.num_channels,); shapes[pre + ".bias"] = (o.num_channels,)
+        elif isinstance(o, LayerNorm):
+            shapes[pre + ".weight"] = tuple(o.normalized_shape); shapes[pre + ".bias"] = tuple(o.normalized_shape)
+        elif isinstance(o, Embedding):
+            shapes[pre + ".weight"] = (o.vocab_sz, o.embed_sz)
+        elif hasattr(o, "_asdict"):
+            for k, v in o._asdict().items():
+                visit(v, f"{pre}.{k}" if pre else k)
+        elif isinstance(o, (list, tuple)):
+            for i, x in enumerate(o):
+                visit(x, f"{pre}.{i}")
+        elif isinstance(o, dict):
+            for k, v in o.items():
+                visit(v, f"{pre}.{k}" if pre else str(k))
+        elif hasattr(o, "__dict__") and not isinstance(o, (type, types.FunctionType, types.BuiltinFunctionType, types.MethodType)):
+            for k, v in o.__dict__.items():
+                if k.startswith("_") or k in ("cfg", "alphas_cumprod"):
+                    continue
+                visit(v, f"{pre}.{k}" if pre else k)
+    visit(obj, prefix)
+    return shapes
+
+
 def unet_param_shapes(unet):
     """name -> logical shape of every weight/bias leaf of a (possibly uninitialised) UNetModel, by the same walk."""
-    from ..vision.unet import UNetModel  # noqa
-    shapes = {}
-    cfg = unet.cfg
-    emb = cfg.model_channels * 4
-
-    def visit(obj, prefix):
-        from ..ff.linear import Linear
-        from ..ff.group_norm import GroupNorm
-        from ..ff.layer_norm import LayerNorm
-        from ..vision.conv2d import Conv2d
-        if isinstance(obj, Linear):
-            shapes[prefix + ".weight"] = (obj.out_features, obj.in_features)
-            if obj._has_bias:
-                shapes[prefix + ".bias"] = (obj.out_features,)
-        elif isinstance(obj, Conv2d):
-            shapes[prefix + ".weight"] = obj._shape
-            shapes[prefix + ".bias"] = (obj._shape[0],)
-        elif isinstance(obj, GroupNorm):
-            shapes[prefix + ".weight"] = (obj.num_channels,); shapes[prefix + ".bias"] = (obj.num_channels,)
-        elif isinstance(obj, LayerNorm):
-            shapes[prefix + ".weight"] = obj.normalized_shape; shapes[prefix + ".bias"] = obj.normalized_shape
-        elif isinstance(obj, (list, tuple)):
-            for i, x in enumerate(obj):
-                visit(x, f"{prefix}.{i}")
-        elif hasattr(obj, "__dict__") and not callable(obj) or (hasattr(obj, "__dict__") and not isinstance(obj, type(lambda: 0))):
-            for k, v in obj.__dict__.items():
-                if k.startswith("_") or k == "cfg":
-                    continue
-                visit(v, f"{prefix}.{k}" if prefix else k)
-    visit(unet, "")
-    return shapes
+    return param_shapes(unet)

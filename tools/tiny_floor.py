@@ -1,16 +1,15 @@
 import ctypes, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import oracle
 import tinyfusers_amd.storage.tensor as T
 from tinyfusers_amd.native import hip
-from tinyfusers_amd.storage.state import update_state
+from tinyfusers_amd.storage.state import param_shapes, update_state
 from tinyfusers_amd.storage.synth import synth_normal, synth_state_dict
 from tinyfusers_amd.variants.sd import StableDiffusion
 from tinyfusers_amd.vision.unet import TINY
 T.ensure_init(0)
-W = synth_state_dict(oracle.unet_param_shapes(oracle.TINY), 5)
-sd = StableDiffusion(TINY); update_state(sd.model.diffusion_model, W, "")
+sd = StableDiffusion(TINY)
+update_state(sd.model.diffusion_model, synth_state_dict(param_shapes(sd.model.diffusion_model), 5), "")
 lat = sd.latent_from_numpy(synth_normal(5, "lat", (1, 4, 16, 16)))
 ctx = T.DeviceArray.from_numpy(synth_normal(5, "c", (1, 13, 64))); unc = T.DeviceArray.from_numpy(synth_normal(5, "u", (1, 13, 64)))
 sd.compile(unc, ctx, lat)
