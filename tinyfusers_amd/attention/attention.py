@@ -16,7 +16,7 @@ from ..ff.linear import Linear, fold_layer_norm, linear_f16, linear_ln_f16
 from ..ff.nn import FeedForward
 from ..native import hip
 from ..storage.tensor import DeviceArray, _sh
-from ..vision.conv2d import Conv2d
+from ..vision.conv2d import Conv2d, _conv
 from .sdpa import sdpa_strided
 
 
@@ -136,14 +136,19 @@ class BasicTransformerBlock:
         self.norm2 = LayerNorm(dim, init=init)
         self.norm3 = LayerNorm(dim, init=init)
 
-    def __call__(self, x, context=None, kv=None):
+    def __call__(self, x, context=None, kv=None, defer_ff2=False):
+        """defer_ff2: stop after GEGLU and return (hidden (b, t, 4*dim), x): the caller folds ff.net[2] into what follows."""
         if config.fuse_layer_norm and x.shape[-1] % 64 == 0:
             x = self.attn1(x, residual=x, ln=self.norm1)
             x = self.attn2(x, context=context, residual=x, kv=kv, ln=self.norm2)
+            if defer_ff2:
+                return self.ff.net[0](x, ln=self.norm3), x
             x = self.ff(x, residual=x, ln=self.norm3)
             return x
         x = self.attn1(self.norm1(x), residual=x)
         x = self.attn2(self.norm2(x), context=context, residual=x, kv=kv)
+        if defer_ff2:
+            return self.ff.net[0](self.norm3(x)), x
         x = self.ff(self.norm3(x), residual=x)
         return x
 
@@ -155,6 +160,23 @@ class SpatialTransformer:
         self.proj_in = Conv2d(channels, n_heads * d_head, kernel_size=[1, 1], init=init)
         self.transformer_blocks = [BasicTransformerBlock(channels, context_dim, n_heads, d_head, init=init)]
         self.proj_out = Conv2d(n_heads * d_head, channels, kernel_size=[1, 1], init=init)
+        self._fold = None
+
+    def _ff2_proj_out(self):
+        """ff.net[2] (Linear 4C -> C, + residual x2) followed by proj_out (1x1 conv C -> C) has nothing non-linear in between:
+        proj_out(h W2^T + b2 + x2) = [h | x2] [Wp W2 | Wp]^T + (Wp b2 + bp).  One GEMM with K = 5C over the pair (h, x2) --
+        the same FLOPs as the two it replaces, one launch and one activation round trip less.  Folded once per weight set
+        on the host in fp32 (first eager call; cached by weight pointers)."""
+        ff2, po = self.transformer_blocks[-1].ff.net[2], self.proj_out
+        key = (ff2.weight.ptr, ff2.bias.ptr, po.weight.ptr, po.bias.ptr)
+        if self._fold is None or self._fold[0] != key:
+            c = po.weight.shape[0]
+            w2, b2 = ff2.weight.numpy(), ff2.bias.numpy()
+            wp, bp = po.weight.numpy().reshape(c, -1), po.bias.numpy()
+            wf = np.concatenate((wp @ w2, wp), axis=1).astype(np.float32)
+            bf = (wp @ b2 + bp).astype(np.float32)
+            self._fold = (key, DeviceArray.from_numpy(wf.reshape(c, -1, 1, 1)), DeviceArray.from_numpy(bf, layout="row"))
+        return self._fold[1], self._fold[2]
 
     def __call__(self, x, context=None, kv=None, out_gn=0):
         b, c, h, w = x.shape
@@ -162,6 +184,13 @@ class SpatialTransformer:
         x = self.norm(x)
         x = self.proj_in(x)
         x = x.tokens()                                   # (b, hw, c): free re-view of NHWC (attention.py:71)
+        if config.fold_proj_out and c % 8 == 0 and self.proj_out.weight.shape[0] == c:
+            for block in self.transformer_blocks[:-1]:
+                x = block(x, context=context, kv=kv)
+            hid, x2 = self.transformer_blocks[-1](x, context=context, kv=kv, defer_ff2=True)
+            wf, bf = self._ff2_proj_out()
+            pair = (hid.image(b, hid.shape[-1], h, w), x2.image(b, c, h, w))
+            return _conv(pair, wf, bf, [0, 0], [1, 1], [1, 1], residual=x_in, gn=out_gn)
         for block in self.transformer_blocks:
             x = block(x, context=context, kv=kv)
         x = x.image(b, c, h, w)                          # attention.py:74

@@ -1,4 +1,12 @@
-"""Process-wide switches of the drop-in path."""
+"""Process-wide switches of the drop-in path.  The boolean fusions can be turned off from the environment for A/B runs
+(TF_FUSE_LAYER_NORM=0, TF_FOLD_SKIP=0, TF_FOLD_PROJ_OUT=0, TF_PARALLEL_BRANCHES=1); results stay within the stated tolerance."""
+import os
+
+
+def _flag(name, default):
+    v = os.environ.get(name)
+    return default if v is None else v not in ("0", "", "false", "False")
+
 
 # Head-merge layout after SDPA in CrossAttention:
 #   "reference_exact": (b,h,t,d) reshaped straight to (b,-1,h*d) with no transpose back -- what
@@ -10,7 +18,7 @@ head_merge = "reference_exact"
 # LayerNorm -> Linear pairs of the transformer blocks run as ONE GEMM on the raw activations (tf_linear_ln_f16:
 # row statistics from the streamed fragments, gamma/beta folded into the weights once).  False = separate
 # tf_layer_norm_f16 launches (the unfused reference structure).
-fuse_layer_norm = True
+fuse_layer_norm = _flag("TF_FUSE_LAYER_NORM", True)
 
 # Independent sub-chains of the step (a ResBlock's 1x1 skip projection next to its GroupNorm -> conv -> GroupNorm main
 # path; the context K|V projection next to the time-embedding MLP) run as parallel branches of the step graph on a side
@@ -18,8 +26,12 @@ fuse_layer_norm = True
 # MEASURED SLOWER on MI355X (ROCm 7.2): 15 fork/join pairs per step cost 5.30 ms/step against 5.12 ms serial -- every
 # cross-stream graph edge is a barrier packet + signal round trip of several microseconds, more than the ~10 us kernels it
 # hides.  Kept as a switch for larger batches, off by default.
-parallel_branches = False
+parallel_branches = _flag("TF_PARALLEL_BRANCHES", False)
 
 # ResBlock: fold the 1x1 skip_connection into the last 3x3 conv as extra K columns (one launch instead of two plus a
 # residual read); False runs the reference's two convs.
-fold_skip_projection = True
+fold_skip_projection = _flag("TF_FOLD_SKIP", True)
+
+# SpatialTransformer: fold the last FeedForward Linear (4C -> C) and proj_out (1x1 conv) into one GEMM with K = 5C over the
+# pair (GEGLU output, FF input); weights folded once on the host in fp32.  False runs the reference's two GEMMs.
+fold_proj_out = _flag("TF_FOLD_PROJ_OUT", True)
