@@ -151,6 +151,15 @@ int tf_conv2d_fused_f16(void* y, const void* x, const void* x2, const void* w, c
 size_t tf_conv2d_fused_workspace(int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
                                  int C3, int C4);
 size_t tf_conv2d_gn_partial_bytes(int N, int groups);
+/* cublasSgemm_v2 / cublasSgemmBatched (native/cublas/ops.py:22-53) as linear_cublas / gemm_batch call them
+ * (ff/linear.py:58-61, :98-101): fp32, column-major, C = alpha op(A) op(B) + beta C; transa/transb 0 = N, 1 = T, 2 = C
+ * (the cublasOperation_t numbers, native/cublas/ops.py:55-58).  alpha / beta are passed by value (the reference passes
+ * host pointers to them).  The batched form takes DEVICE arrays of device pointers, like cuBLAS.  Test-only paths of the
+ * reference (tests/linear.py:64-110): a plain fp32 FMA kernel, ascending-k accumulation. */
+int tf_sgemm_f32(int transa, int transb, int m, int n, int k, float alpha, const void* A, int lda, const void* B, int ldb,
+                 float beta, void* C, int ldc, tfStream_t s);
+int tf_sgemm_batched_f32(int transa, int transb, int m, int n, int k, float alpha, const void* const* Aarray, int lda,
+                         const void* const* Barray, int ldb, float beta, void* const* Carray, int ldc, int batch, tfStream_t s);
 /* tf_linear_f16 replaces Linear.__call__ (ff/linear.py:112-121; live branch cp.dot(x, W^T)+b) and the
  * test-only cuBLAS/cuDNN paths linear_cublas / linear / gemm_batch (ff/linear.py:8-110):
  *   y(M,N) = act(x(M,K) . w(N,K)^T + bias(N)) + residual(M,N)

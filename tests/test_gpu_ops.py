@@ -368,3 +368,49 @@ def test_linear_with_folded_layer_norm(tf, m, n, k, act):
         w, bias = rnd("lnf.w", (2 * n, k), k ** -0.5), rnd("lnf.bias", (2 * n,), 0.1)
         ge = GEGLU(k, n, init=False); ge.proj.weight = dev(tf, w); ge.proj.bias = dev(tf, bias)
         close(ge(dev(tf, x), ln=ln).numpy(), O.geglu(xn, w, bias).numpy())
+
+
+def test_linear_cublas_and_gemm_batch_fp32(tf):
+    """The reference's fp32 cuBLAS paths (ff/linear.py:8-110) behind the same names and memory conventions, checked the way
+    tests/linear.py:64-110 checks them: column-major results against numpy."""
+    import ctypes
+    from tinyfusers_amd.ff.linear import gemm_batch, linear_cublas
+    from tinyfusers_amd.native import hip
+    rng = np.random.default_rng(3)
+    for m, k, n in ((4, 3, 50), (130, 257, 65), (1, 1, 1), (64, 1000, 200)):
+        w_np, x_np = rng.standard_normal((m, k)).astype(np.float32), rng.standard_normal((k, n)).astype(np.float32)
+        b_np = rng.standard_normal((1, n)).astype(np.float32)                                # tests/linear.py:84: a (1, N) bias
+        w, x = tf.Tensor.from_np(w_np).eval(), tf.Tensor.from_np(x_np).eval()
+        res = linear_cublas(w, x, None).to("cpu").data.reshape(n, m).T                    # tests/linear.py:70
+        np.testing.assert_allclose(res, w_np.astype(np.float64) @ x_np.astype(np.float64), rtol=2e-5, atol=2e-5 * np.sqrt(k))
+        w, x = tf.Tensor.from_np(w_np).eval(), tf.Tensor.from_np(x_np).eval()
+        res = linear_cublas(w, x, tf.Tensor.from_np(b_np).eval()).to("cpu").data.reshape(n, m).T
+        np.testing.assert_allclose(res, w_np.astype(np.float64) @ x_np + b_np, rtol=2e-5, atol=2e-5 * np.sqrt(k))
+        from tinyfusers_amd.storage.device import Device
+        r2 = tf.Tensor.from_np(np.ascontiguousarray((w_np @ x_np).T)).eval()                # column-major (m x n)
+        Device("hip").add_bias(r2.dt_ptr, tf.Tensor.from_np(b_np).eval().dt_ptr, m, n)
+        np.testing.assert_allclose(r2.to("cpu").data.T, w_np @ x_np + b_np, rtol=1e-6, atol=1e-6)
+    B, M, K, N = 7, 4, 3, 50                                                                  # tests/linear.py:97-110 (integers: exact)
+    A_np = rng.integers(0, K, size=(B, M, K)).astype(np.float32); B_np = rng.integers(0, K, size=(B, K, N)).astype(np.float32)
+    c_gpu = gemm_batch(tf.Tensor.from_np(A_np), tf.Tensor.from_np(B_np))
+    C_np = np.zeros((B, M, N), dtype=np.float32)
+    for i in range(B):
+        hip.tf_memcpy(C_np[i].ctypes.data, c_gpu[i], M * N * 4, 2)
+        hip.tf_free(c_gpu[i])
+    np.testing.assert_array_equal(np.transpose(C_np.reshape(B, N, M), axes=(0, 2, 1)), A_np @ B_np)
+    # the raw entry with all four transpose combinations, alpha / beta, padded leading dimensions
+    m, n, k = 37, 29, 41
+    A, Bm, C0 = rng.standard_normal((m, k)), rng.standard_normal((k, n)), rng.standard_normal((m, n))
+    for ta in (0, 1):
+        for tb in (0, 1):
+            lda, ldb, ldc = (k if ta else m) + 3, (n if tb else k) + 2, m + 5
+            a_st = np.zeros((m if ta else k, lda), np.float32); a_st[:, : (k if ta else m)] = A if ta else A.T      # column-major storage = rows of the transpose
+            b_st = np.zeros((k if tb else n, ldb), np.float32); b_st[:, : (n if tb else k)] = Bm if tb else Bm.T
+            c_st = np.zeros((n, ldc), np.float32); c_st[:, :m] = C0.T
+            da, db, dc = tf.Tensor.from_np(a_st).eval(), tf.Tensor.from_np(b_st).eval(), tf.Tensor.from_np(c_st).eval()
+            hip.tf_sgemm_f32(ta, tb, m, n, k, 0.5, da.dt_ptr, lda, db.dt_ptr, ldb, -2.0, dc.dt_ptr, ldc, None)
+            got = dc.to("cpu").data[:, :m].T
+            np.testing.assert_allclose(got, 0.5 * (A.astype(np.float32) @ Bm.astype(np.float32)) - 2.0 * C0.astype(np.float32), rtol=1e-4, atol=1e-4)
+            da.to("cpu"); db.to("cpu")
+    with pytest.raises(RuntimeError):
+        hip.tf_sgemm_f32(0, 0, 4, 4, 4, 1.0, da.dt_ptr, 2, db.dt_ptr, 4, 0.0, dc.dt_ptr, 4, None)          # lda < m

@@ -54,6 +54,63 @@ def linear_ln_f16(x, folded, eps, residual=None, act=0, out_features=None):
     return y
 
 
+# cublasOperation_t (native/cublas/ops.py:55-58)
+CUBLAS_OP_N, CUBLAS_OP_T, CUBLAS_OP_C = 0, 1, 2
+
+
+def linear_cublas(weight, x, bias):
+    """ff/linear.py:82-110, the reference's fp32 cuBLAS path (tests/linear.py:64-95): ``weight`` (m, k), ``x`` (k, n) and
+    ``bias`` (n,) or None are evaluated storage Tensors (fp32, row-major); the result is the flat (m*n) fp32 Tensor that
+    cublasSgemm(OP_T, OP_T, m, n, k, weight, lda=k, x, ldb=n, C, ldc=m) leaves behind, i.e. weight @ x stored
+    column-major (``res.data.reshape(n, m).T`` on the host); bias[j] is added to column j of it, as Device.add_bias(res, bias, m, n)
+    does in the reference (tests/linear.py:77-95 compares with ``torch.matmul(w, x) + bias`` for a (1, N) bias)."""
+    from ..storage.tensor import Tensor
+    m, k = weight.shape[0], weight.shape[1]
+    n = x.shape[1]
+    assert x.shape[0] == k, (weight.shape, x.shape)
+    res = Tensor.zeros((m * n), dtype=np.float32).eval()
+    hip.tf_sgemm_f32(CUBLAS_OP_T, CUBLAS_OP_T, m, n, k, 1.0, weight.dt_ptr, k, x.dt_ptr, n, 0.0, res.dt_ptr, m, None)
+    if bias is not None:
+        if not bias.dt_ptr:
+            bias.eval()
+        hip.tf_add_bias_colmajor_f32(res.dt_ptr, bias.dt_ptr, m, n, None)
+    return res
+
+
+def gemm_batch(W, X):
+    """ff/linear.py:8-64: batched fp32 GEMM of host Tensors W (B, M, K) and X (B, K, N) through cublasSgemmBatched(OP_T, OP_T):
+    returns the list of B device pointers, each holding W[i] @ X[i] stored column-major (M x N, ldc = M), as the reference
+    does (tests/linear.py:97-110 copies them back with cudaMemcpy).  The caller owns the buffers (tf_free)."""
+    import ctypes
+    B, M, K = W.shape
+    N = X.shape[2]
+    wd, xd = np.ascontiguousarray(W.data, dtype=np.float32), np.ascontiguousarray(X.data, dtype=np.float32)
+    ptrs = []
+    for arr, nbytes in ((wd, M * K * 4), (xd, K * N * 4), (None, M * N * 4)):
+        col = []
+        for i in range(B):
+            p = ctypes.c_void_p()
+            hip.tf_malloc(ctypes.byref(p), nbytes)
+            if arr is not None:
+                hip.tf_memcpy(p, arr[i].ctypes.data, nbytes, 1)
+            col.append(p)
+        ptrs.append(col)
+    tables = []
+    for col in ptrs:                                   # device arrays of device pointers, as cuBLAS wants them
+        host = (ctypes.c_void_p * B)(*[c.value for c in col])
+        t = ctypes.c_void_p()
+        hip.tf_malloc(ctypes.byref(t), ctypes.sizeof(host))
+        hip.tf_memcpy(t, ctypes.addressof(host), ctypes.sizeof(host), 1)
+        tables.append(t)
+    hip.tf_sgemm_batched_f32(CUBLAS_OP_T, CUBLAS_OP_T, M, N, K, 1.0, tables[0], K, tables[1], N, 0.0, tables[2], M, B, None)
+    hip.tf_device_sync()
+    for t in tables:
+        hip.tf_free(t)
+    for p in ptrs[0] + ptrs[1]:
+        hip.tf_free(p)
+    return ptrs[2]
+
+
 class Linear:
     def __init__(self, in_features, out_features, bias=True, init=True):
         self.in_features, self.out_features = in_features, out_features

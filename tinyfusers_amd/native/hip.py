@@ -9,7 +9,7 @@ HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "
 _CT = {
     "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "size_t": ctypes.c_size_t,
     "long long": ctypes.c_longlong, "void*": ctypes.c_void_p, "const void*": ctypes.c_void_p,
-    "void**": ctypes.POINTER(ctypes.c_void_p), "int*": ctypes.POINTER(ctypes.c_int), "const int*": ctypes.POINTER(ctypes.c_int),
+    "void**": ctypes.POINTER(ctypes.c_void_p), "const void*const*": ctypes.c_void_p, "void*const*": ctypes.c_void_p, "int*": ctypes.POINTER(ctypes.c_int), "const int*": ctypes.POINTER(ctypes.c_int),
     "float*": ctypes.POINTER(ctypes.c_float), "double*": ctypes.POINTER(ctypes.c_double),
     "long long*": ctypes.POINTER(ctypes.c_longlong), "char*": ctypes.c_char_p, "const char*": ctypes.c_char_p,
     "tfStream_t": ctypes.c_void_p, "tfEvent_t": ctypes.c_void_p, "tfGraph_t": ctypes.c_void_p,

@@ -27,8 +27,9 @@ class Device:
                            "in libtinyfusers_hip.so (build with `python -m tinyfusers_amd.build`)")
 
     def add_bias(self, result_pntr, bias_pntr, m, n):
-        """storage/device.py:79-102 / add_bias_func.cu: bias add into a column-major (m x n) cuBLAS result."""
-        hip.tf_add_bias_colmajor_f32(_p(result_pntr), _p(bias_pntr), n, m, None)
+        """storage/device.py:79-102 / add_bias_func.cu: result is a column-major (m x n) cuBLAS result (ldc = m); bias[j] is
+        added to every element of column j (the kernel runs with BT = m, OC = n)."""
+        hip.tf_add_bias_colmajor_f32(_p(result_pntr), _p(bias_pntr), m, n, None)
         return result_pntr
 
     def scale_tensor(self, x_ptr, scaler, B, T, NH, OC):
