@@ -319,7 +319,8 @@ class Tensor:
         self.num_elem = math.prod(self.shape)
         self.nbytes = self.num_elem * self.dtype.itemsize
         self.dt_ptr = ctypes.c_void_p()
-        self.device = device or "hip"
+        self.device = device if device is not None else Tensor.default_device()     # a Device, as in storage/tensor.py:11
+        self.strides = None
 
     def eval(self):
         """cudaMalloc + H2D copy (storage/tensor.py:20-34)."""
@@ -334,7 +335,7 @@ class Tensor:
 
     def to(self, device):
         """D2H copy + free (storage/tensor.py:36-50)."""
-        if device == "cpu" and self.dt_ptr:
+        if str(device) == "cpu" and self.dt_ptr:
             if self.data is None or not self.data.flags.writeable:
                 self.data = np.empty(self.shape, dtype=self.dtype)
             self.data = np.ascontiguousarray(self.data)
@@ -342,8 +343,15 @@ class Tensor:
             hip.tf_memcpy(self.data.ctypes.data, self.dt_ptr, self.data.nbytes, D2H)
             hip.tf_free(self.dt_ptr)
             self.dt_ptr = ctypes.c_void_p()
-            self.device = "cpu"
+            from .device import Device
+            self.device = Device("cpu")
         return self
+
+    @staticmethod
+    def default_device():
+        """storage/tensor.py:59-61 (Device("cuda") there)."""
+        from .device import Device
+        return Device("hip")
 
     @staticmethod
     def from_np(data):
