@@ -290,24 +290,26 @@ __device__ __forceinline__ void sdpa_dma16(i4v rsrc, unsigned voffset_bytes, uns
                :: "s"(__builtin_amdgcn_readfirstlane((int)lds_base)), "v"(voffset_bytes), "s"(rsrc) : "memory");   // M0 has no other user in k_sdpa_dma (gfx9 DS ops do not read it)
 }
 
-constexpr bool sdpa_v_pitch_ok(int vpc) {
-  for (int i = 0; i < 4; ++i)
-    for (int j = i + 1; j < 4; ++j) {
-      int d = ((i - j) * vpc * 16 % 256 + 256) % 256;
-      if (d < 32 || d > 224) return false;
-    }
-  return true;
-}
-constexpr int sdpa_v_pitch(int ck) { int v = ck; while (!sdpa_v_pitch_ok(v)) ++v; return v; }
+// LDS layouts are chosen against the real bank model of the chip (64 banks x 4 B; a ds_read_b128 is served in four groups of
+// 16 NON-contiguous lanes, a ds_read_b64_tr_b16 in two groups of 32; tools/lds_conflicts.py enumerates the costs):
+//   K rows (16 consecutive rows per 16-lane read, 4 chunk columns across the lane groups): conflict-free exactly when the
+//     pitch in 16-B chunks is 2 (mod 4): 6 / 10 / 10 / 18 / 22 chunks for d = 40 / 64 / 80 / 128 / 160 (an odd pitch costs 2x);
+//   V rows (keys k and k + 8 of a 32-key half land in the same 32-lane group): no plain pitch is conflict-free; a skew of a
+//     few chunks after every 8 rows is: (pitch, skew) = (6, 8) / (10, 8) / (10, 8) / (18, 8) / (20, 2) chunks.
+constexpr int sdpa_k_pitch(int ck) { return ck + (2 - ck % 4 + 4) % 4; }
+constexpr int sdpa_v_pitch(int ck) { return ck <= 6 ? 6 : ck <= 10 ? 10 : ck <= 18 ? 18 : ck <= 20 ? 20 : 22; }
+constexpr int sdpa_v_skew(int ck) { return ck <= 18 ? 8 : ck <= 20 ? 2 : 8; }
 
 template <int HS>
 struct SdpaDma {
   static constexpr int DQK = (HS + 31) / 32 * 32, NKS = DQK / 32, NDT = (HS + 15) / 16, CK = HS / 8;
-  static constexpr int KPC = CK | 1, VPC = sdpa_v_pitch(CK);      // pitches in 16-B chunks
-  static constexpr int KP = KPC * 8, VP = VPC * 8;                // pitches in halves
-  static constexpr int K_BYTES = 64 * KPC * 16, STAGE_B = 64 * (KPC + VPC) * 16;
+  static constexpr int KPC = sdpa_k_pitch(CK), VPC = sdpa_v_pitch(CK), VSC = sdpa_v_skew(CK);   // pitches / skew in 16-B chunks
+  static constexpr int KP = KPC * 8, VP = VPC * 8, VSK = VSC * 8; // pitches / skew in halves
+  static constexpr int VGC = 8 * VPC + VSC;                        // chunks per group of 8 V rows (rows + skew pad)
+  static constexpr int NKI = KPC, NVI = (8 * VGC + 63) / 64;       // 1-KiB pieces of the K / V image (64 rows each)
+  static constexpr int K_BYTES = NKI * 1024, STAGE_B = (NKI + NVI) * 1024;
   static constexpr int S = (144 * 1024 / STAGE_B) >= 4 ? 4 : (144 * 1024 / STAGE_B);
-  static constexpr int NI = KPC + VPC, LPW = (NI + 3) / 4;        // 1-KiB pieces per tile / per wave
+  static constexpr int NI = NKI + NVI, LPW = (NI + 3) / 4;        // 1-KiB pieces per tile / per wave
   static_assert(S >= 2, "ring needs two stages");
 };
 
@@ -315,7 +317,7 @@ template <int HS, int QT>
 __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
   constexpr int QW = 16 * QT, QB = 4 * QW;          // queries per wave / per block
   using C = SdpaDma<HS>;
-  constexpr int NKS = C::NKS, NDT = C::NDT, CK = C::CK, KPC = C::KPC, VPC = C::VPC, KP = C::KP, VP = C::VP;
+  constexpr int NKS = C::NKS, NDT = C::NDT, CK = C::CK, KPC = C::KPC, VPC = C::VPC, KP = C::KP, VP = C::VP, VSK = C::VSK, VGC = C::VGC;
   constexpr int S = C::S, NI = C::NI, LPW = C::LPW, STAGE_B = C::STAGE_B;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
@@ -366,8 +368,10 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
       int key = 32 * (kt >> 1) + 8 * (rr >> 2) + 4 * (kt & 1) + (rr & 3);
       voff[i] = cc < CK ? (unsigned)(key * (int)p.k_st + cc * 8) * 2u : 0x80000000u;
     } else {
-      int x = 64 * (j - KPC) + lane, r = x / VPC, cc = x - r * VPC;
-      voff[i] = cc < CK ? (unsigned)(r * (int)p.v_st + cc * 8) * 2u : 0x80000000u;
+      // V image: groups of 8 rows (VPC chunks each) followed by VSC skew chunks; pad / skew / tail chunks are fetched out of range
+      int x = 64 * (j - KPC) + lane, grp = x / VGC, rem = x - grp * VGC;
+      int rr = rem / VPC, cc = rem - rr * VPC, r = 8 * grp + rr;
+      voff[i] = (rr < 8 && grp < 8 && cc < CK) ? (unsigned)(r * (int)p.v_st + cc * 8) * 2u : 0x80000000u;
     }
   }
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
@@ -407,7 +411,7 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
     if (t + S - 1 < ntiles) issue(t + S - 1);
 
     const half_t* ks_ = reinterpret_cast<const half_t*>(smem_raw + (t % S) * STAGE_B);
-    const half_t* vs_ = ks_ + 64 * KP;
+    const half_t* vs_ = ks_ + C::K_BYTES / 2;
 
     f4 st[4][QT];
     f4 init4[QT];
@@ -486,7 +490,7 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
     for (int dt = 0; dt < NDT; ++dt) {
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc) {
-        const half_t* va = vs_ + (32 * kc + 8 * lg + (lr >> 2)) * VP + dt * 16 + 4 * (lr & 3);
+        const half_t* va = vs_ + (32 * kc + 8 * lg + (lr >> 2)) * VP + (4 * kc + lg) * VSK + dt * 16 + 4 * (lr & 3);
         s4v v0 = lds_tr16(va), v1 = lds_tr16(va + 4 * VP);
         union { struct { s4v a, b; } s; h8 h; } u;
         u.s.a = v0; u.s.b = v1;
