@@ -207,6 +207,12 @@ size_t tf_group_norm_workspace(int N, int HW, int C, int G);
  * tf_conv2d_fused_f16: partial (N, chunks, G, 2) f32.  Same arithmetic as tf_group_norm_f16 from the fold onwards. */
 int tf_group_norm_apply_f16(void* y, const void* x, const void* gamma, const void* beta, const void* partial, int chunks,
                             int N, int HW, int C, int G, float eps, int silu, tfStream_t s);
+/* GroupNorm(G) of the channel concat [x | x2] of two EQUALLY wide tensors (vision/unet.py:72 into resnet.py:8) whose
+ * statistics came from tf_conv2d_fused_f16 as G-group partials of each half: a group of the concat is two adjacent
+ * groups of one half, so no statistics pass over the concat is needed.  partial (N, chunks, G, 2), partial2 (N, chunks2, G, 2). */
+int tf_group_norm_apply2_f16(void* y, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial,
+                             int chunks, const void* partial2, int chunks2, int N, int HW, int C1, int G, float eps, int silu,
+                             tfStream_t s);
 /* LayerNorm over the last dim (ff/layer_norm.py:8-32, :34-49; semantics = F.layer_norm, tests/layer_norm.py:38) */
 int tf_layer_norm_f16(void* y, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s);
 

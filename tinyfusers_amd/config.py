@@ -35,3 +35,7 @@ fold_skip_projection = _flag("TF_FOLD_SKIP", True)
 # SpatialTransformer: fold the last FeedForward Linear (4C -> C) and proj_out (1x1 conv) into one GEMM with K = 5C over the
 # pair (GEGLU output, FF input); weights folded once on the host in fp32.  False runs the reference's two GEMMs.
 fold_proj_out = _flag("TF_FOLD_PROJ_OUT", True)
+
+# GroupNorm over an equal-split channel concat (output path of the UNet) from the 32-group partials of the two producers
+# (pairs of groups merge) instead of a statistics pass over the concat.
+concat_stats = _flag("TF_CONCAT_STATS", True)

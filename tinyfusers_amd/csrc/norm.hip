@@ -70,7 +70,7 @@ __global__ void k_gn_stats(float* __restrict__ partial, const half_t* __restrict
 #define GN_APPLY_PPT 4
 __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ x2, const half_t* __restrict__ gamma,
                            const half_t* __restrict__ beta, const float* __restrict__ partial, int HW, int C1, int C2, int G, float eps,
-                           int do_silu, int chunks, int pix_per_block, int CV, int RPB) {
+                           int do_silu, int chunks, int pix_per_block, int CV, int RPB, const float* __restrict__ partial2, int chunks2) {
   extern __shared__ float st[];  // [G][2] : mean, rstd
   int n = blockIdx.y;
   int C = C1 + C2, cpg = C / G;
@@ -105,15 +105,29 @@ __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x,
       if (g < G) {
         // this lane's chunks k = sub, sub + 8, ...: 8 independent loads in flight per round, summed in k order
         const float* pp = partial + (long long)n * chunks * G * 2 + g * 2;
-        for (int k0 = sub; k0 < chunks; k0 += 64) {
-          f2 v[8];
+        int nch = chunks;
+        const int gstride = G * 2;
+        bool pair = false;
+        if (partial2) {
+          // concat of two equal halves whose statistics came as G-group partials of EACH half (tf_group_norm_apply2_f16):
+          // group g of the concat = groups (2g', 2g'+1) of one half, g' = g mod G/2
+          const int hg = G >> 1, gl = g < hg ? g : g - hg;
+          const float* src = g < hg ? partial : partial2;
+          nch = g < hg ? chunks : chunks2;
+          pp = src + (long long)n * nch * G * 2 + (2 * gl) * 2;
+          pair = true;
+        }
+        for (int k0 = sub; k0 < nch; k0 += 64) {
+          f4 v[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             int k = k0 + 8 * u;
-            v[u] = k < chunks ? *reinterpret_cast<const f2*>(pp + (long long)k * G * 2) : (f2){0.f, 0.f};
+            if (k >= nch) v[u] = (f4){0.f, 0.f, 0.f, 0.f};
+            else if (pair) v[u] = *reinterpret_cast<const f4*>(pp + (long long)k * gstride);        // (S, SS) of both groups
+            else { f2 w = *reinterpret_cast<const f2*>(pp + (long long)k * gstride); v[u] = (f4){w[0], w[1], 0.f, 0.f}; }
           }
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { S += (double)v[u][0]; SS += (double)v[u][1]; }
+          for (int u = 0; u < 8; ++u) { S += (double)v[u][0]; SS += (double)v[u][1]; S += (double)v[u][2]; SS += (double)v[u][3]; }
         }
       }
 #pragma unroll
@@ -257,7 +271,7 @@ int tf_group_norm_f16(void* y, const void* x, const void* x2, const void* gamma,
                      (const half_t*)x2, HW, C1, C2, G, chunks, ppc, CV, RPB);
   TF_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
-                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB);
+                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
@@ -274,7 +288,26 @@ int tf_group_norm_apply_f16(void* y, const void* x, const void* gamma, const voi
   gn_geometry(HW, C, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
   int tl = (threads + 7) & ~7;
   hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)nullptr,
-                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C, 0, G, eps, silu, chunks, appb, CV, RPB);
+                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+
+int tf_group_norm_apply2_f16(void* y, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial, int chunks,
+                             const void* partial2, int chunks2, int N, int HW, int C1, int G, float eps, int silu, tfStream_t s) {
+  TF_REQUIRE(y && x && x2 && partial && partial2, "tf_group_norm_apply2_f16: null tensor");
+  TF_REQUIRE((gamma == nullptr) == (beta == nullptr), "tf_group_norm_apply2_f16: gamma and beta must both be given or both NULL");
+  int C = 2 * C1;
+  TF_REQUIRE(N >= 0 && HW >= 0 && G >= 2 && G % 2 == 0 && C1 > 0 && C1 % G == 0, "tf_group_norm_apply2_f16: C1=%d must be divisible by the even G=%d", C1, G);
+  TF_REQUIRE(C1 % 8 == 0 && C / 8 <= 1024 && G <= 1024 && N <= 65535, "tf_group_norm_apply2_f16: C1=%d G=%d N=%d out of range", C1, G, N);
+  TF_REQUIRE(chunks >= 1 && chunks <= 4096 && chunks2 >= 1 && chunks2 <= 4096, "tf_group_norm_apply2_f16: chunks=%d chunks2=%d", chunks, chunks2);
+  if (N == 0 || HW == 0) return TF_OK;
+  int CV, RPB, threads, sc, ppc, ablocks, appb;
+  gn_geometry(HW, C, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
+  int tl = (threads + 7) & ~7;
+  hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
+                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C1, G, eps, silu, chunks, appb, CV, RPB,
+                     (const float*)partial2, chunks2);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }

@@ -3,6 +3,7 @@ Here: two HBM-bound launches (partial statistics; normalise + affine [+ SiLU]) o
 channel concat of vision/unet.py:72 can be folded in by passing a pair ``(x, skip)``."""
 import numpy as np
 
+from .. import config
 from ..native import hip
 from ..storage.tensor import DeviceArray, _sh, asarray
 from .linear import workspace
@@ -19,6 +20,12 @@ def _gn(x, num_groups, eps, gamma, beta, silu):
         part, chunks, _ = x.gn                         # statistics came with x from the conv that produced it
         hip.tf_group_norm_apply_f16(y.ptr, x.ptr, gamma.ptr if gamma is not None else None, beta.ptr if beta is not None else None,
                                     part.ptr, chunks, n, h * w, c1, num_groups, float(eps), 1 if silu else 0, _sh())
+        return y
+    if config.concat_stats and x2 is not None and c1 == c2 and num_groups % 2 == 0 and x.gn is not None and x2.gn is not None \
+            and x.gn[2] == num_groups and x2.gn[2] == num_groups:
+        # equal-split concat: a group of the concat is two adjacent groups of one half -> merge the producers' partials
+        hip.tf_group_norm_apply2_f16(y.ptr, x.ptr, x2.ptr, gamma.ptr if gamma is not None else None, beta.ptr if beta is not None else None,
+                                     x.gn[0].ptr, x.gn[1], x2.gn[0].ptr, x2.gn[1], n, h * w, c1, num_groups, float(eps), 1 if silu else 0, _sh())
         return y
     nb = hip.tf_group_norm_workspace(n, h * w, c1 + c2, num_groups)
     ws = workspace(nb)

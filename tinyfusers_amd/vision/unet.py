@@ -47,8 +47,8 @@ class Upsample:
     def __init__(self, channels, init=True):
         self.conv = Conv2d(channels, channels, kernel_size=[3, 3], padding=[1, 1], init=init)
 
-    def __call__(self, x):
-        return self.conv(x, upsample=True)       # nearest-2x (unet.py:81-83) folded into the conv gather
+    def __call__(self, x, out_gn=0):
+        return self.conv(x, upsample=True, gn=out_gn)       # nearest-2x (unet.py:81-83) folded into the conv gather
 
 
 class Downsample:
@@ -168,17 +168,18 @@ class UNetModel:
         if br is None:
             kv_all = linear_f16(context, bt["kv_w"]) if bt["kv_w"] is not None else None  # every attn2's K|V of the context
 
-        def run(x, bb, nxt):
+        def run(x, bb, nxt, force_gn=0):
             # nxt = the module that reads this one's output as a single tensor (None across a concat): when it opens
-            # with a GroupNorm, the statistics are produced by this module's last conv
-            gn = nxt.num_groups if isinstance(nxt, GroupNorm) else 32 if isinstance(nxt, (ResBlock, SpatialTransformer)) else 0
+            # with a GroupNorm, the statistics are produced by this module's last conv.  force_gn: the output (also) enters
+            # an equal-split concat whose GroupNorm merges the two producers' partials (tf_group_norm_apply2_f16)
+            gn = nxt.num_groups if isinstance(nxt, GroupNorm) else 32 if isinstance(nxt, (ResBlock, SpatialTransformer)) else force_gn
             if isinstance(bb, ResBlock):
                 off, n = bt["emb_off"][id(bb)]
                 return bb(x, emb, emb_out=emb_all.view((emb_all.shape[0], n), "row", off), out_gn=gn)
             if isinstance(bb, SpatialTransformer):
                 c = bb.proj_in.weight.shape[0]
                 return bb(x, context, kv=KVSlice(kv_all, bt["kv_off"][id(bb)], c, bt["kv_n"]), out_gn=gn)
-            if isinstance(bb, Downsample):
+            if isinstance(bb, (Downsample, Upsample)):
                 return bb(x, out_gn=gn)
             return bb(x)
 
@@ -194,7 +195,9 @@ class UNetModel:
             nxt = seq[i + 1] if i + 1 < len(seq) else None     # the middle block's output enters a concat
             if not joined and isinstance(bb, SpatialTransformer):
                 br.join(); joined = True            # first consumer of kv_all
-            x = run(x, bb, nxt)
+            # tensors saved for (or entering) the output path's concat carry 32-group statistics when the concat is an equal split
+            want = config.concat_stats and (i in ends or nxt is None)
+            x = run(x, bb, nxt, force_gn=32 if want else 0)
             if i in ends:
                 saved_inputs.append(x)
         if not joined:
@@ -204,7 +207,9 @@ class UNetModel:
             for j, bb in enumerate(b):
                 last = bi == len(self.output_blocks) - 1 and j == len(b) - 1
                 nxt = b[j + 1] if j + 1 < len(b) else (self.out[0] if last else None)
-                x = run(x, bb, nxt)
+                cout = bb.conv.weight.shape[0] if isinstance(bb, Upsample) else (bb.out_layers[3].weight.shape[0] if isinstance(bb, ResBlock) else bb.proj_out.weight.shape[0])
+                want = config.concat_stats and nxt is None and bool(saved_inputs) and cout == saved_inputs[-1].shape[1]
+                x = run(x, bb, nxt, force_gn=32 if want else 0)
         return self.out[2](self.out[0](x, silu=True))
 
 
