@@ -74,6 +74,10 @@ def _sh():
     return _stream_stack[-1].handle
 
 
+import os as _os
+_POISON = _os.environ.get("TF_POOL_POISON", "0") not in ("0", "")   # debugging: fill freed / fresh blocks with 0xFF (NaN in fp16 / fp32)
+
+
 class Pool:
     """Stream-ordered caching allocator: freed blocks are re-used (most recently freed first, so the
     re-used block is still hot in L2 / Infinity Cache) instead of returned to the driver.  Allocation
@@ -85,25 +89,64 @@ class Pool:
         self.allocated = 0
         self.frozen = False      # True while capturing a graph: growing the pool would call hipMalloc
         self.held = None         # list of (ptr, n) released while a Branch is recording (see Branch)
+        self.capture = None      # size -> [ptr] private free lists while a graph is being captured (see begin_capture)
+        self.owned = {}          # ptr -> size of every block that belongs to a captured graph
 
     def alloc(self, nbytes):
         n = max(_ALIGN, (int(nbytes) + _ALIGN - 1) // _ALIGN * _ALIGN)
+        if self.capture is not None:
+            lst = self.capture.get(n)
+            if lst:
+                return lst.pop(), n
         lst = self.free_blocks.get(n)
         if lst:
-            return lst.pop(), n
+            ptr = lst.pop()
+            if self.capture is not None:
+                self.owned[ptr] = n
+            return ptr, n
         if self.frozen:
             raise RuntimeError(f"Pool: allocation of {n} B while frozen (graph capture) -- warm up with one eager step first")
         ensure_init()
         p = ctypes.c_void_p()
         hip.tf_malloc(ctypes.byref(p), n)
         self.allocated += n
+        if _POISON:
+            hip.tf_memset_async(p, 0xFF, n, _sh())
         return p.value, n
 
     def release(self, ptr, n):
+        if _POISON:
+            hip.tf_memset_async(ptr, 0xFF, n, _sh())     # TF_POOL_POISON=1: a freed block reads back as NaN (stream-ordered)
         if self.held is not None:
             self.held.append((ptr, n))       # a side branch is open: its temporaries stay out of the pool until the join
             return
+        if self.capture is not None:
+            self.owned[ptr] = n              # freed inside the capture: re-usable by the capture only, the graph keeps it
+            self.capture.setdefault(n, []).append(ptr)
+            return
+        if ptr in self.owned:
+            return                           # a captured graph replays into this block: never hand it to anybody else
         self.free_blocks.setdefault(n, []).append(ptr)
+
+    # -- graph capture: every block the captured program touches becomes the graph's own.  Without this a block that the
+    # program freed (in Python's eyes) is handed to the next eager allocation -- e.g. a weight that a later eager call
+    # packs and caches -- and the next replay of the graph writes its activations over it.
+    def begin_capture(self):
+        assert self.capture is None, "nested graph capture"
+        self.capture = {}
+        self._owned_before = set(self.owned)
+        self.frozen = True
+
+    def end_capture(self):
+        """-> the blocks {ptr: size} owned by the graph just captured (hand them back with disown when it is destroyed)."""
+        self.capture = None
+        self.frozen = False
+        return {p: n for p, n in self.owned.items() if p not in self._owned_before}
+
+    def disown(self, blocks):
+        for ptr, n in blocks.items():
+            if self.owned.pop(ptr, None) is not None:
+                self.free_blocks.setdefault(n, []).append(ptr)
 
 
 _pool = Pool()

@@ -128,14 +128,18 @@ class StableDiffusion:
                 self._eager_step(sp)
             hip.tf_memcpy_async(latent.ptr, saved.ptr, latent.nbytes, 3, _sh())
             self._stream.synchronize()
-            pool().frozen = True
+            if getattr(self, "_graph_blocks", None):          # a previous graph of this model: its buffers go back to the pool
+                hip.tf_graph_destroy(self._graph)
+                pool().disown(self._graph_blocks)
+                self._graph, self._graph_blocks = None, None
+            pool().begin_capture()
             try:
                 hip.tf_graph_begin_capture(self._stream.handle)
                 self._eager_step(sp)
                 g = ctypes.c_void_p()
                 hip.tf_graph_end_capture(self._stream.handle, ctypes.byref(g))
             finally:
-                pool().frozen = False
+                self._graph_blocks = pool().end_capture()    # every block the captured step touches now belongs to the graph
             self._graph = g
         return self
 
