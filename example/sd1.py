@@ -73,12 +73,13 @@ if __name__ == "__main__":
     model.compile(unconditional_context, context, latent)
     times = []
     for n in range(args.images + 1):
-        T.hip.tf_memcpy(latent.ptr, np.ascontiguousarray(synth_normal(args.seed + n, "sd.latent", (1, 4, 64, 64))).ctypes.data, latent.nbytes, 1)
+        model.set_latent(synth_normal(args.seed + n, "sd.latent", (1, 4, 64, 64)))
         t0 = time.perf_counter()
         for index, timestep in list(enumerate(timesteps))[::-1]:
             model.step(timestep, alphas[index], alphas_prev[index], args.guidance)
         model.synchronize()
         t1 = time.perf_counter()
+        assert np.isfinite(latent.numpy()).all(), f"image {n}: the sampler produced a non-finite latent"
         with T.use_stream(model._stream):
             x = model.decode(latent)
         t2 = time.perf_counter()

@@ -225,6 +225,10 @@ int tf_quick_gelu_f16(void* y, const void* x, long long n, tfStream_t s);
  * out(n_tokens, dim) f16 = table[ids[i], :] (+ pos[i % T, :] when pos != NULL).  ids: n_tokens int32 ON THE DEVICE. */
 int tf_embedding_f16(void* out, const void* table, const void* ids, const void* pos, long long n_tokens, int dim, int vocab,
                      int T, tfStream_t s);
+/* Debugging aid, no reference counterpart: *flag (device int) = 1 when the nbytes at x hold a non-finite f16 (is_f32 = 0) or f32
+ * value.  Stream-ordered and capturable (tools/diag_graph.py instruments a whole step with it). */
+int tf_debug_nonfinite(const void* x, long long nbytes, int is_f32, void* flag, tfStream_t s);
+int tf_debug_checksum(const void* x, long long nbytes, void* sum, tfStream_t s);   /* *sum (device u64) += weighted word checksum of x */
 int tf_geglu_f16(void* y, const void* x, int rows, int C, tfStream_t s);          /* x (rows,2C) -> y (rows,C) */
 int tf_add_f16(void* y, const void* a, const void* b, long long n, tfStream_t s);
 int tf_add_bias_nc_f16(void* y, const void* x, const void* bias_nc, int N, int HW, int C, tfStream_t s);

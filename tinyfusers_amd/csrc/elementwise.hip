@@ -342,6 +342,39 @@ int tf_embedding_f16(void* out, const void* table, const void* ids, const void* 
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
+// Debugging aid (no reference counterpart): *flag = 1 when x holds a non-finite value.  Stream-ordered and capturable, so a
+// whole step (eager or graph replay) can be instrumented without a host sync (tools/diag_graph.py).
+__global__ void k_debug_nonfinite(const unsigned* __restrict__ x, long long nwords, int is_f32, int* flag) {
+  bool bad = false;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nwords; i += (long long)gridDim.x * blockDim.x) {
+    unsigned v = x[i];
+    bad |= is_f32 ? ((v & 0x7f800000u) == 0x7f800000u) : (((v & 0x7c00u) == 0x7c00u) || ((v & 0x7c000000u) == 0x7c000000u));
+  }
+  if (bad) *flag = 1;
+}
+// Debugging aid: *sum (device u64) += position-weighted integer checksum of the words at x (order independent, so two runs of
+// the same program over the same inputs must give identical sums for every array).
+__global__ void k_debug_checksum(const unsigned* __restrict__ x, long long nwords, unsigned long long* sum) {
+  unsigned long long acc = 0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nwords; i += (long long)gridDim.x * blockDim.x)
+    acc += (unsigned long long)x[i] * (unsigned long long)(((unsigned)i * 2654435761u) | 1u);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(sum, acc);
+}
+int tf_debug_checksum(const void* x, long long nbytes, void* sum, tfStream_t s) {
+  TF_REQUIRE(x && sum && nbytes >= 0, "tf_debug_checksum: bad arguments");
+  if (nbytes < 4) return TF_OK;
+  hipLaunchKernelGGL(k_debug_checksum, dim3(ew_grid(nbytes / 4)), dim3(256), 0, tf_hs(s), (const unsigned*)x, nbytes / 4, (unsigned long long*)sum);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_debug_nonfinite(const void* x, long long nbytes, int is_f32, void* flag, tfStream_t s) {
+  TF_REQUIRE(x && flag && nbytes >= 0, "tf_debug_nonfinite: bad arguments");
+  if (nbytes < 4) return TF_OK;
+  hipLaunchKernelGGL(k_debug_nonfinite, dim3(ew_grid(nbytes / 4)), dim3(256), 0, tf_hs(s), (const unsigned*)x, nbytes / 4, is_f32, (int*)flag);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
 int tf_geglu_f16(void* y, const void* x, int rows, int C, tfStream_t s) {
   TF_REQUIRE(y && x && rows >= 0 && C > 0 && C % 8 == 0, "tf_geglu_f16: C=%d must be a positive multiple of 8", C);
   if (rows == 0) return TF_OK;

@@ -73,6 +73,11 @@ static hipMemcpyKind kind_of(int kind) {
 int tf_memcpy(void* dst, const void* src, size_t nbytes, int kind) {
   TF_REQUIRE(kind >= 1 && kind <= 3, "tf_memcpy: kind %d (1=H2D 2=D2H 3=D2D)", kind);
   TF_HIP(hipMemcpy(dst, src, nbytes, kind_of(kind)));
+  // A copy from pageable host memory may return once the data sits in the staging buffer, with the DMA still queued on the
+  // NULL stream -- and the non-blocking streams this library creates are not ordered behind that stream.  The reference uses
+  // the call as "copy, then launch" (storage/tensor.py:25-29), so make it hold: drain the NULL stream after every copy that
+  // writes device memory (one host wait per upload; uploads are not on the step path).
+  if (kind != 2) TF_HIP(hipStreamSynchronize(nullptr));
   return TF_OK;
 }
 int tf_memcpy_async(void* dst, const void* src, size_t nbytes, int kind, tfStream_t s) {

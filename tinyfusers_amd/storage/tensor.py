@@ -62,12 +62,37 @@ def current_stream():
     return _stream_stack[-1]
 
 
-class use_stream:
-    """``with use_stream(s):`` routes every op launched inside onto stream ``s``."""
+def _order(after, before):
+    """Everything launched on ``after`` from now on runs after everything already launched on ``before``."""
+    if after is before:
+        return
+    e = Branch._event()
+    hip.tf_event_record(e, before.handle)
+    hip.tf_stream_wait_event(after.handle, e)
+    Branch._events.append(e)
 
-    def __init__(self, s): self.s = s
-    def __enter__(self): _stream_stack.append(self.s); return self.s
-    def __exit__(self, *a): _stream_stack.pop()
+
+class use_stream:
+    """``with use_stream(s):`` routes every op launched inside onto stream ``s``.
+
+    The switch keeps program order: ``s`` first waits for what was queued on the stream it takes over from, and that
+    stream waits for ``s`` on exit.  The streams are non-blocking HIP streams (no implicit ordering with the NULL stream),
+    and the pool hands a block freed on one stream to the next allocation on any stream, so without the two edges an op
+    on ``s`` could read an input, or be given a block, that work queued before the ``with`` has not finished with.
+    ``ordered=False`` skips the edges (a caller that re-enters the same stream back to back, e.g. the sampler loop)."""
+
+    def __init__(self, s, ordered=True): self.s, self.ordered = s, ordered
+
+    def __enter__(self):
+        if self.ordered:
+            _order(self.s, _stream_stack[-1])
+        _stream_stack.append(self.s)
+        return self.s
+
+    def __exit__(self, *a):
+        _stream_stack.pop()
+        if self.ordered:
+            _order(_stream_stack[-1], self.s)
 
 
 def _sh():
@@ -75,7 +100,8 @@ def _sh():
 
 
 import os as _os
-_POISON = _os.environ.get("TF_POOL_POISON", "0") not in ("0", "")   # debugging: fill freed / fresh blocks with 0xFF (NaN in fp16 / fp32)
+_POISON = _os.environ.get("TF_POOL_POISON", "0")   # debugging: fill freed ("release") / fresh ("fresh") / both ("1") blocks with 0xFF (NaN in fp16 / fp32)
+_POISON_FRESH, _POISON_RELEASE = _POISON in ("1", "fresh"), _POISON in ("1", "release")
 
 
 class Pool:
@@ -110,12 +136,13 @@ class Pool:
         p = ctypes.c_void_p()
         hip.tf_malloc(ctypes.byref(p), n)
         self.allocated += n
-        if _POISON:
-            hip.tf_memset_async(p, 0xFF, n, _sh())
+        if _POISON_FRESH:
+            hip.tf_memset_async(p, 0xFF, n, None)
+            hip.tf_device_sync()
         return p.value, n
 
     def release(self, ptr, n):
-        if _POISON:
+        if _POISON_RELEASE:
             hip.tf_memset_async(ptr, 0xFF, n, _sh())     # TF_POOL_POISON=1: a freed block reads back as NaN (stream-ordered)
         if self.held is not None:
             self.held.append((ptr, n))       # a side branch is open: its temporaries stay out of the pool until the join
@@ -246,13 +273,20 @@ class DeviceArray:
     @staticmethod
     def from_numpy(x, dtype=np.float16, layout=None):
         x = np.asarray(x)
-        a = DeviceArray.empty(x.shape, dtype, layout)
-        host = x.astype(dtype, copy=False)
-        if a.layout == "nhwc":
+        return DeviceArray.empty(x.shape, dtype, layout).copy_from_numpy(x)
+
+    def copy_from_numpy(self, x):
+        """Synchronous host -> device copy into this array (same logical shape; cast / laid out on the host first).
+        Use this instead of ``tf_memcpy(ptr, some_expression.ctypes.data, ...)``: an address taken from a temporary
+        array is dangling by the time the call runs, the staging array here stays referenced until the copy returned."""
+        host = np.asarray(x).astype(self.dtype, copy=False)
+        if host.shape != self.shape:
+            raise ValueError(f"copy_from_numpy: host shape {host.shape} != device shape {self.shape}")
+        if self.layout == "nhwc":
             host = host.transpose(0, 2, 3, 1)
         host = np.ascontiguousarray(host)
-        hip.tf_memcpy(a.ptr, host.ctypes.data, host.nbytes, H2D)
-        return a
+        hip.tf_memcpy(self.ptr, host.ctypes.data, host.nbytes, H2D)
+        return self
 
     @staticmethod
     def zeros(shape, dtype=np.float16, layout=None):

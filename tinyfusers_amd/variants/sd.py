@@ -112,6 +112,13 @@ class StableDiffusion:
         """(B,4,H,W) host array -> fp32 NCHW device latent (the sampler state)."""
         return DeviceArray.from_numpy(np.ascontiguousarray(x, dtype=np.float32), np.float32, "row")
 
+    def set_latent(self, x):
+        """Start a new image: host noise (B,4,H,W) -> the latent buffer the compiled step updates in place.  Ordered after
+        every step already queued (the sampler stream is drained first)."""
+        self.synchronize()
+        self._latent.copy_from_numpy(x)
+        return self._latent
+
     # -- whole-step HIP graph ------------------------------------------------------------------------
     def compile(self, unconditional_context, context, latent, stream=None, warmup=2):
         """Capture one denoising step for these (static) buffers into a HIP graph.  Afterwards

@@ -64,7 +64,8 @@ class StepParams:
     whose arguments carry the values, so it is stream-ordered with the step graph that reads them."""
 
     def __init__(self):
-        self.dev = DeviceArray.zeros((4,), np.float32, "row")
+        self.dev = DeviceArray.empty((4,), np.float32, "row")
+        self.set(0.0)
 
     def set(self, timestep, a_t=1.0, a_prev=1.0, guidance=1.0):
         hip.tf_set_step_params(self.dev.ptr, float(timestep), float(a_t), float(a_prev), float(guidance), _sh())
