@@ -74,7 +74,9 @@ def test_add_cast_layout(tf):
     close(src.astype(np.float16).astype(np.float32).numpy(), x, atol=0, rtol=0)
 
 
-@pytest.mark.parametrize("rows,c", [(1, 8), (5, 64), (154, 768), (2 * 4096, 320), (2 * 256, 1280), (3, 2560)])
+# (16 * 128, {768, 1024, 1280, 1600}) are the shapes of the reference's own tests/layer_norm.py:13-27
+@pytest.mark.parametrize("rows,c", [(1, 8), (5, 64), (154, 768), (2 * 4096, 320), (2 * 256, 1280), (3, 2560),
+                                    (2048, 768), (2048, 1024), (2048, 1280), (2048, 1600)])
 def test_layer_norm(tf, rows, c):
     from oracle import ops as O
     from tinyfusers_amd.ff.layer_norm import LayerNorm
@@ -83,8 +85,10 @@ def test_layer_norm(tf, rows, c):
     close(m(dev(tf, x)).numpy(), O.layer_norm(x, m.weight.numpy(), m.bias.numpy()).numpy())
 
 
+# (2048, {768, 1024, 1280, 1600}, 2, 2) with 2 groups are the shapes of the reference's own tests/group_norm.py:13-33
 @pytest.mark.parametrize("n,c,h,w,g", [(2, 64, 5, 3, 32), (2, 320, 64, 64, 32), (2, 1280, 8, 8, 32), (2, 2560, 16, 16, 32),
-                                       (2, 1920, 16, 16, 32), (2, 960, 32, 32, 32), (64, 768, 2, 2, 2), (3, 32, 1, 1, 32)])
+                                       (2, 1920, 16, 16, 32), (2, 960, 32, 32, 32), (64, 768, 2, 2, 2), (3, 32, 1, 1, 32),
+                                       (2048, 768, 2, 2, 2), (2048, 1024, 2, 2, 2), (2048, 1280, 2, 2, 2), (2048, 1600, 2, 2, 2)])
 def test_group_norm(tf, n, c, h, w, g):
     from oracle import ops as O
     from tinyfusers_amd.ff.group_norm import GroupNorm, group_norm
@@ -279,6 +283,7 @@ SDPA_CASES = [  # b, nh, tq, tk, hs
     (2, 8, 4096, 77, 40), (1, 2, 4096, 4096, 40), (2, 2, 130, 130, 32), (1, 12, 77, 77, 64), (1, 1, 200, 333, 128), (1, 2, 70, 70, 96),
     (1, 2, 200, 200, 40), (1, 2, 130, 130, 80), (1, 1, 192, 192, 64), (1, 1, 256, 256, 128), (1, 1, 129, 65, 160), (1, 1, 1, 1, 40),
     (1, 2, 250, 250, 56), (1, 1, 64, 300, 48),
+    (35, 12, 1024, 1024, 64),        # the dims of the reference's own tests/sdpa.py:13-20
 ]
 
 
@@ -443,3 +448,26 @@ def test_group_norm_of_equal_split_concat_from_producer_statistics(tf, c, hw, fo
     ys[0].gn = None
     plain = g((ys[0], ys[1]), silu=True).numpy()          # statistics pass over the concat
     np.testing.assert_allclose(got, plain, atol=2e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("vocab,dim,b,n,pos", [(10, 8, 1, 10, False), (10, 8, 1, 10, True), (49408, 768, 2, 77, True), (77, 1280, 3, 5, False)])
+def test_embedding(tf, vocab, dim, b, n, pos):
+    """tests/embedding.py:8-25 of the reference (vocab 10, 10 tokens, one sequence) against torch.nn.functional.embedding, plus
+    the CLIP sizes and the fused position add; ids from the host or already on the device; out-of-range ids are refused."""
+    from tinyfusers_amd.ff.embedding import Embedding, embedding
+    w = rnd("emb.w", (vocab, dim)); pw = rnd("emb.p", (n + 2, dim))
+    idx = np.random.default_rng(vocab + n).integers(0, vocab, size=(b, n))
+    want = torch.nn.functional.embedding(torch.from_numpy(idx), torch.from_numpy(w.astype(np.float16).astype(np.float32))).numpy()
+    if pos:
+        want = (want + pw.astype(np.float16).astype(np.float32)[:n][None]).astype(np.float16).astype(np.float32)
+    m = Embedding(vocab, dim, init=False); m.weight = dev(tf, w)
+    got = embedding(m.weight, idx, dev(tf, pw)) if pos else m(idx)
+    assert got.shape == (b, n, dim)
+    close(got.numpy(), want, atol=0 if not pos else 1e-3, rtol=0 if not pos else 1e-3)
+    ids_dev = tf.DeviceArray.from_numpy(idx.astype(np.int32), np.int32, "row")
+    np.testing.assert_array_equal(embedding(m.weight, ids_dev, dev(tf, pw) if pos else None).numpy(), got.numpy())
+    np.testing.assert_array_equal(m(idx.astype(np.float32)).numpy(), m(idx).numpy())       # the reference passes float position ids
+    with pytest.raises(IndexError):
+        m(np.full((1, 3), vocab))
+    with pytest.raises(IndexError):
+        m(np.full((1, 3), -1))
