@@ -93,7 +93,9 @@ int tf_gemm_force_config(int bm, int bn, int splitk);
 int tf_gemm_autotune(int on);
 int tf_gemm_tune_save(const char* path);
 int tf_gemm_tune_load(const char* path);
-/* diagnostic builds of tools/: bit 0 no stores, 1 no MFMA, 2 no staging, 3/4 force deep/wide ring, 5/6 force n-fastest/m-fastest order */
+/* diagnostic builds of tools/: bit 0 no stores, 1 no MFMA, 2 no staging, 3/4 force deep/wide ring, 5/6 force n-fastest/m-fastest order,
+ * 7 (128) the patch variant of the 3x3 convolutions (k_igemm_patch), 8 (256) the variant whose consumer waves issue part of the
+ * weight loads, each where the shape is eligible */
 int tf_gemm_debug(int flags);
 
 /* ---- layout / dtype converters (the API edge: the reference's arrays are fp32 NCHW) ----------- */

@@ -471,3 +471,93 @@ def test_embedding(tf, vocab, dim, b, n, pos):
         m(np.full((1, 3), vocab))
     with pytest.raises(IndexError):
         m(np.full((1, 3), -1))
+
+
+PATCH_CASES = [  # n, hw, c1, c2 (concat), cout, c3 (folded 1x1 skip source), forced (bm, bn, splitk), gn
+    (2, 64, 64, 0, 160, 0, (64, 160, 1), 0),       # one image row per m-tile, a single channel group
+    (2, 64, 320, 0, 320, 0, (64, 160, 1), 32),     # conv 3x3 320 @ 64^2 (the step's most frequent shape) + statistics
+    (2, 64, 320, 0, 320, 0, (128, 160, 2), 32),    # two image rows per tile, split-K cuts inside a channel group
+    (1, 32, 128, 64, 256, 0, (64, 128, 1), 0),     # concat input, two image rows per tile
+    (2, 32, 640, 0, 640, 0, (128, 160, 4), 32),    # 6-row patches, splits of 22/23 K tiles
+    (2, 16, 256, 128, 128, 0, (128, 128, 3), 0),   # 8 image rows per tile, odd split
+    (2, 8, 128, 0, 128, 0, (64, 128, 1), 32),      # a whole 8x8 image per tile
+    (2, 16, 128, 0, 128, 192, (64, 128, 1), 32),   # folded skip projection: extra 1x1 K tiles after the patches
+    (1, 64, 128, 0, 160, 64, (64, 160, 2), 0),
+]
+
+
+@pytest.mark.parametrize("n,hw,c1,c2,cout,c3,force,gn", PATCH_CASES)
+def test_conv2d_patch_variant(tf, n, hw, c1, c2, cout, c3, force, gn):
+    """k_igemm_patch (3x3 / stride 1 / pad 1: the activation patch of a channel group staged once for its nine taps) forced through
+    tf_gemm_debug(128), against the oracle and against the tap-by-tap kernel on the same inputs."""
+    from oracle import ops as O
+    from tinyfusers_amd.native import lib
+    from tinyfusers_amd.vision.conv2d import Conv2d
+    xa = rnd("pv.xa", (n, c1, hw, hw)); xb = rnd("pv.xb", (n, c2, hw, hw)) if c2 else None
+    cin = c1 + c2
+    wt = rnd("pv.w", (cout, cin, 3, 3), (cin * 9) ** -0.5); b = rnd("pv.b", (cout,), 0.1)
+    e = rnd("pv.e", (n, cout), 0.5)
+    m = Conv2d(cin, cout, [3, 3], padding=[1, 1], init=False); m.weight = dev(tf, wt); m.bias = dev(tf, b)
+    x = (dev(tf, xa), dev(tf, xb)) if c2 else dev(tf, xa)
+    kw = {}
+    want = O.conv2d_bias(np.concatenate((xa, xb), 1) if c2 else xa, wt, b, (1, 1))
+    if c3:
+        x3 = rnd("pv.x3", (n, c3, hw, hw)); ws = rnd("pv.ws", (cout, c3, 1, 1), c3 ** -0.5); bs = rnd("pv.bs", (cout,), 0.1)
+        proj = Conv2d(c3, cout, [1, 1], init=False); proj.weight = dev(tf, ws); proj.bias = dev(tf, bs)
+        kw["extra"] = (proj, dev(tf, x3))
+        want = want + O.conv2d_bias(x3, ws, bs, (0, 0))
+    else:
+        kw["bias_nc"] = dev(tf, e)
+        want = want + torch.from_numpy(e)[:, :, None, None]
+    got = {}
+    for flags in (128, 8):                                  # patch variant, then the deep-ring tap-by-tap kernel
+        lib.tf_gemm_force_config(*force); lib.tf_gemm_debug(flags)
+        try:
+            y = m(x, gn=gn, **kw)
+            got[flags] = (y.numpy(), None if y.gn is None else (y.gn[0].numpy().copy(), y.gn[1]))
+        finally:
+            lib.tf_gemm_force_config(0, 0, 0); lib.tf_gemm_debug(0)
+    close(got[128][0], want.numpy())
+    np.testing.assert_allclose(got[128][0], got[8][0], atol=4e-3, rtol=4e-3)      # same products, another summation order
+    if gn:
+        assert got[128][1] is not None and got[128][1][1] == got[8][1][1]
+
+
+ALL8_CASES = [  # kind, dims, forced (bm, bn, splitk)
+    ("conv", (2, 320, 64, 320, 3), (64, 160, 1)), ("conv", (2, 320, 64, 320, 3), (128, 160, 2)), ("conv", (2, 1280, 16, 1280, 3), (128, 160, 8)),
+    ("conv", (2, 1280, 8, 1280, 3), (64, 160, 16)), ("conv", (2, 640, 32, 640, 1), (64, 128, 1)), ("conv", (1, 128, 16, 64, 3), (128, 64, 1)),
+    ("lin", (8192, 320, 1280), (128, 128, 1)), ("lin", (512, 1280, 1280), (64, 64, 4)), ("lin", (154, 320, 768), (64, 64, 1)),
+]
+
+
+@pytest.mark.parametrize("kind,dims,force", ALL8_CASES)
+def test_gemm_all8_variant_is_bit_identical(tf, kind, dims, force):
+    """tf_gemm_debug(256): the consumer waves issue part of the weight loads of every K tile.  Same tiles, same K order, same
+    accumulation as the deep-ring kernel, so the result must be bit-identical to it (and correct against the oracle)."""
+    from oracle import ops as O
+    from tinyfusers_amd.native import lib
+    from tinyfusers_amd.ff.linear import Linear
+    from tinyfusers_amd.vision.conv2d import Conv2d
+    if kind == "conv":
+        n, cin, hw, cout, k = dims
+        x = rnd("a8.x", (n, cin, hw, hw)); wt = rnd("a8.w", (cout, cin, k, k), (cin * k * k) ** -0.5); b = rnd("a8.b", (cout,), 0.1)
+        m = Conv2d(cin, cout, [k, k], padding=[k // 2, k // 2], init=False); m.weight = dev(tf, wt); m.bias = dev(tf, b)
+        xd = dev(tf, x)
+        call = lambda: m(xd)
+        want = O.conv2d_bias(x, wt, b, (k // 2, k // 2)).numpy()
+    else:
+        mm, nn, kk = dims
+        x = rnd("a8.x", (mm, kk)); wt = rnd("a8.w", (nn, kk), kk ** -0.5); b = rnd("a8.b", (nn,), 0.1)
+        m = Linear(kk, nn, init=False); m.weight = dev(tf, wt); m.bias = dev(tf, b)
+        xd = dev(tf, x)
+        call = lambda: m(xd)
+        want = O.linear(x, wt, b).numpy()
+    got = {}
+    for flags in (256, 8):
+        lib.tf_gemm_force_config(*force); lib.tf_gemm_debug(flags)
+        try:
+            got[flags] = call().numpy()
+        finally:
+            lib.tf_gemm_force_config(0, 0, 0); lib.tf_gemm_debug(0)
+    close(got[256], want)
+    np.testing.assert_array_equal(got[256], got[8])

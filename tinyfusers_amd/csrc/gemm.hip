@@ -45,6 +45,8 @@ struct GemmP {
   // (sum, sum of squares) of the fp16-rounded outputs, in the layout k_gn_apply folds; NULL = off
   float* gn_part;
   int gn_G, gn_cpg, gn_chunks;
+  // k_igemm_patch geometry (patch_setup): pieces / pixels of one activation patch, bytes of a ring slot, ring depth, log2(W)
+  int pt_ppc, pt_ppix, pt_stage, pt_ns, pt_log2w;
 };
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;   // 128-bit buffer resource
@@ -257,11 +259,19 @@ __device__ __forceinline__ void igemm_gn_stats(const GemmP& p, char* smem, int m
 // WIDE = true is the short-K variant: 2-slot ring, one fragment set, <= 128 VGPRs, so TWO blocks share a CU and one
 // block's prologue / epilogue overlaps the other's K loop (shapes with many tiles and few K tiles per tile);
 // WIDE = false is the deep variant: 4-slot ring, fragments of tile t+1 prefetched during tile t, one block per CU.
-template <int BM, int BN, bool GENERIC, bool WIDE>
+// ALL8 = true (deep variant only): the consumer waves issue LPC of the WEIGHT pieces of every stage themselves.  Data that is
+// not L2 resident (each layer's weights arrive cold from HBM / Infinity Cache) streams at a rate set by the number of waves
+// that have loads outstanding, not by the pieces each keeps in flight (tools/micro/ingest.hip: 28 GB/s per CU with 4
+// issuing waves, 44-52 GB/s with 8), so the weight-bound shapes gain from eight issuing waves what the L2-resident ones
+// lose in MFMA issue slots; one of the autotuned variants.
+template <int BM, int BN, bool GENERIC, bool WIDE, bool ALL8 = false>
 __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   constexpr int TM = BM / 2, TN = BN / 2, MJ = TM / 16, NI = TN / 16;
   constexpr int NG = (BM + BN) / 8;                       // 8-row staging groups: activation rows first, then weight rows
-  constexpr int LPS = NG / 4;                             // LDS-DMA pieces per loader wave per stage
+  constexpr int LPC = ALL8 ? (BN >= 128 ? (BM + BN >= 256 ? 3 : 2) : 1) : 0;   // weight pieces per CONSUMER wave per stage (the last 4 LPC groups)
+  constexpr int LPS = NG / 4 - LPC;                       // LDS-DMA pieces per loader wave per stage
+  static_assert(!(ALL8 && (WIDE || GENERIC)), "ALL8 is a deep-ring, 64-channel-aligned variant");
+  static_assert(4 * LPC <= BN / 8, "the consumers take weight groups only");
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int NS = WIDE ? 2 : ring_slots(BM, BN);      // ring slots
   static_assert(NG % 4 == 0 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
@@ -527,6 +537,27 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
     xa[j] = row * 128 + ((lg ^ ((row >> 1) & 7)) << 4);
   }
   const int nt = kt_end - kt_begin;
+  // ALL8: this wave's share of the weight rows (groups NG - 4 LPC + w4 + 4 i), same lane -> (row, swizzled chunk) map as the loaders
+  unsigned cw[LPC > 0 ? LPC : 1];
+  rsrc_t rs_cw;
+  if constexpr (ALL8) {
+    rs_cw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    const int sub = lane >> 3;
+    const int cs = (lane & 7) ^ ((4 * (w4 & 1) + (sub >> 1)) & 7);
+#pragma unroll
+    for (int i = 0; i < LPC; ++i) {
+      int n = n0 + 8 * (NG - 4 * LPC + w4 + 4 * i) + sub - BM;
+      cw[i] = n < p.N ? (unsigned)(n * p.K + cs * 8) * 2u : TF_OOB;
+    }
+  }
+  auto cstage = [&](int buf, int kt) {                    // the consumer's pieces of stage (buf, kt)
+    if constexpr (ALL8) {
+      char* base = smem + buf * STAGE;
+#pragma unroll
+      for (int i = 0; i < LPC; ++i)
+        bload_lds16(rs_cw, cw[i] != TF_OOB ? cw[i] + (unsigned)kt * 128u : TF_OOB, base + (NG - 4 * LPC + w4 + 4 * i) * 1024);
+    }
+  };
   if (WIDE) {
     for (int it = 0; it < nt; ++it) {
       __builtin_amdgcn_s_barrier();                       // barrier(it): tile it landed
@@ -586,21 +617,31 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
 #pragma unroll
         for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[k2][i], xf[k2][j], acc[i][j], 0, 0, 0);
   };
+  if constexpr (ALL8) {
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_)
+      if (s_ < nt) cstage(s_, kt_begin + s_);
+    wait_stages<LPC, NS - 1>(nt - 1);                      // this wave's pieces of tile 0 landed
+  }
   __builtin_amdgcn_s_barrier();                           // barrier P: tile 0 landed
   asm volatile("" ::: "memory");
   if (nt > 0) read_frags(0, wfA, xfA);
   for (int it = 0; it < nt; it += 2) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // fragments of tile it are in registers: its slot may be refilled
+    if constexpr (ALL8) { if (it + 1 < nt) wait_stages<LPC, NS - 2>(nt - 2 - it); }   // ... and this wave's pieces of tile it+1 landed
     __builtin_amdgcn_s_barrier();                         // barrier(it): tile it+1 landed
     asm volatile("" ::: "memory");
+    if constexpr (ALL8) { if (it + NS < nt) cstage(it % NS, kt_begin + it + NS); }
     if (it + 1 < nt) read_frags((it + 1) % NS, wfB, xfB);
     __builtin_amdgcn_sched_barrier(0);
     mma(wfA, xfA);
     __builtin_amdgcn_sched_barrier(0);
     if (it + 1 >= nt) break;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (ALL8) { if (it + 2 < nt) wait_stages<LPC, NS - 2>(nt - 3 - it); }
     __builtin_amdgcn_s_barrier();                         // barrier(it+1)
     asm volatile("" ::: "memory");
+    if constexpr (ALL8) { if (it + 1 + NS < nt) cstage((it + 1) % NS, kt_begin + it + 1 + NS); }
     if (it + 2 < nt) read_frags((it + 2) % NS, wfA, xfA);
     __builtin_amdgcn_sched_barrier(0);
     mma(wfB, xfB);
@@ -620,6 +661,367 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
     __builtin_amdgcn_s_barrier();                         // barrier Z: the loaders' (mean, rstd) table is in LDS
     asm volatile("" ::: "memory");
   }
+  igemm_scratch_write<BM, BN>(p, acc, csum, smem, w4, lane);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                           // barrier Y
+  asm volatile("" ::: "memory");
+  igemm_epilogue<BM, BN>(p, smem, m0, n0, split, w4, 0, lane);
+  if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 0, lane);
+}
+
+// =====================================================================================================================
+// PATCH variant for 3x3 / stride 1 / pad 1 convolutions (no up-sampling, channel counts multiples of 64) whose m-tile is a
+// whole number of image rows.  k_igemm stages the activation tile of every filter tap separately: nine overlapping
+// copies of the same (rows + 2) x (W + 2) pixel patch.  Here the K loop runs channel-group major -- for each 64-channel
+// group the 9 taps -- and the patch of a group is brought into LDS ONCE (two patch buffers); the consumers read the
+// tap (dy, dx) fragments at pixel offset dy * (W + 2) + dx inside it.  Ring slots then hold the weight tile only (plus
+// the activation tile of the K tiles of the extra 1x1 segment, which keep the k_igemm layout).  LDS-DMA pieces per K
+// tile and loader wave: 5 + 7/9 instead of 7 at 64x160 (W = 64), 5 + 1 instead of 9 at 128x160.
+//   K-tile order t: conv part t < 9 G1: group g = t / 9, tap = t % 9; extra part: tile t - 9 G1 of the 1x1 segment.
+//   patch(G) lives in buffer G & 1.  Its pieces ride on the stages of group G-1 from tap 4 >= NS-1 on (the buffer was last read
+//   for group G-2, whose last tile is behind every barrier those stages are issued after), two pieces per stage; the first
+//   patch of a split (and what the skipped stages would have carried) is issued in the prologue.
+//   Stages carry different numbers of loads, so the counted vmcnt waits follow the schedule (W in the loader loop).
+// MEASURED (tools/patch_bench.py, MI355X): 1.02-1.13x k_igemm on the long-K 3x3 shapes of the step (0.95-1.0x on the shortest
+// ones: the prologue stages a whole patch before the first barrier); one candidate of the per-shape autotuner.
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n in [0, 63]: computed jump into a table of (s_waitcnt, s_branch) pairs
+// (8 bytes each) -- the counter is an immediate field, and a compare chain costs more than the K tile it guards.
+__device__ __forceinline__ void wait_vm_dyn(int n) {
+  n = __builtin_amdgcn_readfirstlane(n < 0 ? 0 : n > 63 ? 63 : n);
+  asm volatile(
+      "s_getpc_b64 s[96:97]\n"                 // address of the next instruction
+      "s_lshl_b32 s98, %0, 3\n"                // 4 bytes each from here to the table: 6 instructions = 24 bytes
+      "s_add_u32 s96, s96, s98\n"
+      "s_addc_u32 s97, s97, 0\n"
+      "s_add_u32 s96, s96, 24\n"
+      "s_addc_u32 s97, s97, 0\n"
+      "s_setpc_b64 s[96:97]\n"
+      "s_waitcnt vmcnt(0)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(1)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(2)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(3)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(4)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(5)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(6)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(7)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(8)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(9)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(10)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(11)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(12)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(13)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(14)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(15)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(16)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(17)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(18)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(19)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(20)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(21)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(22)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(23)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(24)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(25)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(26)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(27)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(28)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(29)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(30)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(31)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(32)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(33)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(34)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(35)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(36)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(37)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(38)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(39)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(40)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(41)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(42)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(43)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(44)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(45)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(46)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(47)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(48)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(49)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(50)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(51)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(52)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(53)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(54)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(55)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(56)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(57)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(58)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(59)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(60)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(61)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(62)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(63)\n s_branch 1f\n"
+      "1:\n"
+      :: "s"(n) : "s96", "s97", "s98", "scc", "memory");
+}
+
+#define TF_PATCH_PPW 9     // patch pieces per loader wave at most (33 pieces: BM = 128, W = 64)
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
+  constexpr int TM = BM / 2, TN = BN / 2, MJ = TM / 16, NI = TN / 16;
+  constexpr int BNP = BN / 32;                            // weight pieces per loader wave per K tile
+  constexpr int AXP = BM / 32;                            // activation pieces per loader wave of an extra (1x1) K tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wid >= 4;
+  const int w4 = wid & 3;
+  const int ntiles = p.ntm * p.ntn;
+  const int nblk = ntiles * p.splitk;
+  int bid = blockIdx.x;
+  {
+    int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;      // XCD-aware order, as in k_igemm
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int split = bid / ntiles;
+  const int tid_ = bid - split * ntiles;
+  int tile_m, tile_n;
+  if (p.order == 0) { tile_m = tid_ / p.ntn; tile_n = tid_ - tile_m * p.ntn; }
+  else { tile_n = tid_ / p.ntm; tile_m = tid_ - tile_n * p.ntm; }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kt_begin = split * p.ktiles_per_split;
+  const int kt_end = min(p.ktiles, kt_begin + p.ktiles_per_split);
+  const int nt = kt_end - kt_begin;
+
+  const int PC = p.W + 2;                                 // patch row pitch (pixels)
+  const int PPC = p.pt_ppc;                               // 1-KiB pieces (8 pixels x 64 channels) of one patch
+  const int PB = PPC * 1024;
+  char* const ring = smem + 2 * PB;
+  const int STG = p.pt_stage, NS = p.pt_ns;
+  const int G1 = p.C >> 6, T1 = 9 * G1;
+
+  if (loader) {
+    // =============================== LOADER WAVES ===============================================
+    const rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    const int sub = lane >> 3;
+    const int cs = (lane & 7) ^ ((4 * (w4 & 1) + (sub >> 1)) & 7);      // source chunk of this lane (see k_igemm)
+    unsigned gw[BNP];
+    int ga[AXP], pp[TF_PATCH_PPW];
+#pragma unroll
+    for (int i = 0; i < BNP; ++i) {
+      int n = n0 + 8 * (w4 + 4 * i) + sub;
+      gw[i] = n < p.N ? (unsigned)(n * p.K + cs * 8) * 2u : TF_OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < AXP; ++i) ga[i] = m0 + 8 * (w4 + 4 * i) + sub;   // the 1x1 segment reads the output pixel itself
+    {
+      const int img = fast_div(m0, p.dv_howo_mul, p.dv_howo_shr);
+      const int y0 = (m0 - img * p.HoWo) >> p.pt_log2w;                 // first image row of the tile
+#pragma unroll
+      for (int i = 0; i < TF_PATCH_PPW; ++i) {
+        int q = 8 * (w4 + 4 * i) + sub;
+        int pr = q / PC, pc = q - pr * PC;
+        int y = y0 + pr - 1, x = pc - 1;
+        bool ok = q < p.pt_ppix && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        pp[i] = ok ? (img * p.H + y) * p.W + x : -1;
+      }
+    }
+    const int nv = PPC > w4 ? (PPC - w4 + 3) >> 2 : 0;     // pieces of a patch this wave issues (those with w4 + 4 i < PPC; <= TF_PATCH_PPW)
+    constexpr int PQ = 2, TAP0 = 4;                        // pieces of the next patch carried per stage, from tap TAP0 on (NS - 1 <= TAP0)
+    auto patch_count = [&](int lo, int hi) { return max(0, min(hi, nv) - min(lo, nv)); };
+    auto patch_pieces = [&](int G, int lo, int hi) {      // generic range (prologue only)
+      const int c0 = G << 6;
+      const bool second = c0 >= p.C1;
+      const int ld = second ? p.C2 : p.C1;
+      const int cc = (second ? c0 - p.C1 : c0) + cs * 8;
+      const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? p.x2 : p.x), 0, second ? p.x2_bytes : p.x_bytes, 0x00020000);
+      char* base = smem + (G & 1) * PB;
+#pragma unroll
+      for (int i = 0; i < TF_PATCH_PPW; ++i) {
+        const int pi = w4 + 4 * i;
+        if (i >= lo && i < hi && pi < PPC) {
+          unsigned off = pp[i] >= 0 ? (unsigned)(pp[i] * ld + cc) * 2u : TF_OOB;
+          bload_lds16(rs, off, base + pi * 1024);
+        }
+      }
+    };
+    auto patch_pair = [&](int G, int j) {                 // pieces 2 j and 2 j + 1 of patch(G): the stage of tap TAP0 + j carries them
+      const int c0 = G << 6;
+      const bool second = c0 >= p.C1;
+      const int ld = second ? p.C2 : p.C1;
+      const int cc = (second ? c0 - p.C1 : c0) + cs * 8;
+      const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? p.x2 : p.x), 0, second ? p.x2_bytes : p.x_bytes, 0x00020000);
+      char* base = smem + (G & 1) * PB + w4 * 1024;
+      auto one = [&](int v, int i) {
+        if (w4 + 4 * i < PPC) bload_lds16(rs, v >= 0 ? (unsigned)(v * ld + cc) * 2u : TF_OOB, base + i * 4096);
+      };
+      switch (j) {                                         // static register indices
+        case 0: one(pp[0], 0); one(pp[1], 1); break;
+        case 1: one(pp[2], 2); one(pp[3], 3); break;
+        case 2: one(pp[4], 4); one(pp[5], 5); break;
+        case 3: one(pp[6], 6); one(pp[7], 7); break;
+        default: one(pp[8], 8); break;
+      }
+    };
+    // does the stage of conv tile (g, tap) carry pieces of patch(g + 1)?  and how many loads does stage (g, tap) issue
+    auto carries = [&](int g, int tap) { return tap >= TAP0 && g + 1 < G1 && 9 * (g + 1) < kt_end; };
+    auto count = [&](int g, int tap) {                    // g >= G1: a K tile of the extra 1x1 segment
+      if (g >= G1) return BNP + AXP;
+      return BNP + (carries(g, tap) ? patch_count((tap - TAP0) * PQ, (tap - TAP0 + 1) * PQ) : 0);
+    };
+    int sg = G1, stap = 0;                                 // (group, tap) of the next tile to stage
+    auto stage = [&](int slot) -> int {                   // stages tile (sg, stap) into ring slot `slot`; returns its load count
+      char* base = ring + slot * STG;
+      const bool extra = sg >= G1;
+      const unsigned koff = extra ? (unsigned)(p.Kc + ((sg - G1) << 6)) : (unsigned)(stap * p.C + (sg << 6));
+#pragma unroll
+      for (int i = 0; i < BNP; ++i) {
+        unsigned off = gw[i] != TF_OOB ? gw[i] + koff * 2u : TF_OOB;
+        bload_lds16(rs_w, off, base + (w4 + 4 * i) * 1024);
+      }
+      const int n = count(sg, stap);
+      if (extra) {
+        const int c0 = (sg - G1) << 6;
+        const bool second = c0 >= p.C3;
+        const int ld = second ? p.C4 : p.C3;
+        const int cc = (second ? c0 - p.C3 : c0) + cs * 8;
+        const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? p.x4 : p.x3), 0, second ? p.x4_bytes : p.x3_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < AXP; ++i) bload_lds16(rs, (unsigned)(ga[i] * ld + cc) * 2u, base + BN * 128 + (w4 + 4 * i) * 1024);
+        ++sg;
+      } else {
+        if (carries(sg, stap)) patch_pair(sg + 1, stap - TAP0);
+        if (++stap == 9) { stap = 0; ++sg; }
+      }
+      return n;
+    };
+    if (kt_begin < T1) {
+      sg = kt_begin / 9; stap = kt_begin - 9 * sg;
+      patch_pieces(sg, 0, TF_PATCH_PPW);                   // the first patch of this split, whole
+      if (stap > TAP0 && carries(sg, stap - 1)) patch_pieces(sg + 1, 0, (stap - TAP0) * PQ);   // what the skipped stages carry
+    } else {
+      sg = G1 + (kt_begin - T1);
+    }
+    // W = loads issued after the stage of the tile the consumers need next; (ng, ntap) = that tile's successor
+    int ng = sg, ntap = stap, W = 0;
+    auto advance = [&]() { if (ng >= G1) ++ng; else if (++ntap == 9) { ntap = 0; ++ng; } };
+    advance();                                             // tile 1
+    {
+      int s_ = 0;
+      for (; s_ < NS && s_ < nt; ++s_) { int n = stage(s_); if (s_ > 0) W += n; }
+      wait_vm_dyn(W);                                      // tile 0 (and everything issued before it) landed
+    }
+    __builtin_amdgcn_s_barrier();                         // barrier P
+    asm volatile("" ::: "memory");
+    int slot = 0;
+    for (int it = 0; it < nt; ++it) {
+      if (it + 1 < nt) {
+        W -= count(ng, ntap);                              // tile it+1 must have landed: only newer stages may be in flight
+        advance();
+        wait_vm_dyn(W);
+      }
+      __builtin_amdgcn_s_barrier();                       // barrier(it)
+      asm volatile("" ::: "memory");
+      if (it + NS < nt) W += stage(slot);
+      if (++slot == NS) slot = 0;
+    }
+    __builtin_amdgcn_s_barrier();                         // barrier X
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // barrier Y: the consumers' tiles are in the LDS scratch
+    asm volatile("" ::: "memory");
+    igemm_epilogue<BM, BN>(p, smem, m0, n0, split, w4, 1, lane);
+    if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 1, lane);
+    return;
+  }
+
+  // ================================= CONSUMER WAVES ===============================================
+  const int wave_m = w4 & 1, wave_n = w4 >> 1;
+  const int lr = lane & 15, lg = lane >> 4;
+  f4 acc[NI][MJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+  f4 csum[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) csum[i] = (f4){0.f, 0.f, 0.f, 0.f};
+  int wa[NI], xe[MJ], q0[MJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    int row = wave_n * TN + i * 16 + lr;
+    wa[i] = row * 128 + ((lg ^ ((row >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+    int row = wave_m * TM + j * 16 + lr;
+    xe[j] = BN * 128 + row * 128 + ((lg ^ ((row >> 1) & 7)) << 4);
+    q0[j] = (row >> p.pt_log2w) * PC + (row & (p.W - 1));              // patch pixel of tap (0, 0) for this output row
+  }
+  int rt = kt_begin, rg = 0, rdy = 0, rdx = 0;             // next tile to read: index, group, tap
+  if (kt_begin < T1) { rg = kt_begin / 9; int tap = kt_begin - 9 * rg; rdy = tap / 3; rdx = tap - 3 * rdy; }
+  h8 wfA[2][NI], xfA[2][MJ], wfB[2][NI], xfB[2][MJ];
+  auto read_frags = [&](int slot, h8 (&wf)[2][NI], h8 (&xf)[2][MJ]) {
+    const char* sb = ring + slot * STG;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wf[0][i] = *reinterpret_cast<const h8*>(sb + wa[i]);
+    if (rt < T1) {
+      const char* pb = smem + (rg & 1) * PB;
+      const int dq = rdy * PC + rdx;
+      int a[MJ];
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) {
+        int q = q0[j] + dq;
+        a[j] = (q << 7) + ((lg ^ ((q >> 1) & 7)) << 4);
+        xf[0][j] = *reinterpret_cast<const h8*>(pb + a[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) wf[1][i] = *reinterpret_cast<const h8*>(sb + (wa[i] ^ 64));
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) xf[1][j] = *reinterpret_cast<const h8*>(pb + (a[j] ^ 64));
+      if (++rdx == 3) { rdx = 0; if (++rdy == 3) { rdy = 0; ++rg; } }
+    } else {
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) xf[0][j] = *reinterpret_cast<const h8*>(sb + xe[j]);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) wf[1][i] = *reinterpret_cast<const h8*>(sb + (wa[i] ^ 64));
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) xf[1][j] = *reinterpret_cast<const h8*>(sb + (xe[j] ^ 64));
+    }
+    ++rt;
+  };
+  auto mma = [&](h8 (&wf)[2][NI], h8 (&xf)[2][MJ]) {
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[k2][i], xf[k2][j], acc[i][j], 0, 0, 0);
+  };
+  __builtin_amdgcn_s_barrier();                           // barrier P: tile 0 (and its patch) landed
+  asm volatile("" ::: "memory");
+  int rslot = 0;
+  if (nt > 0) { read_frags(0, wfA, xfA); rslot = 1; }
+  for (int it = 0; it < nt; it += 2) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // barrier(it): tile it+1 landed
+    asm volatile("" ::: "memory");
+    if (it + 1 < nt) { read_frags(rslot, wfB, xfB); if (++rslot == NS) rslot = 0; }
+    __builtin_amdgcn_sched_barrier(0);
+    mma(wfA, xfA);
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + 1 >= nt) break;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // barrier(it+1)
+    asm volatile("" ::: "memory");
+    if (it + 2 < nt) { read_frags(rslot, wfA, xfA); if (++rslot == NS) rslot = 0; }
+    __builtin_amdgcn_sched_barrier(0);
+    mma(wfB, xfB);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_s_barrier();                           // barrier X: every consumer is done with the ring and the patches
+  asm volatile("" ::: "memory");
   igemm_scratch_write<BM, BN>(p, acc, csum, smem, w4, lane);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                           // barrier Y
@@ -835,7 +1237,7 @@ static int gn_chunks_for(const GemmP& p, TileCfg c, int splitk) {
 }
 static bool gn_tile_ok(const GemmP& p, int bm, int bn) { return p.HoWo % bm == 0 && gn_pieces(p, bn) * (p.HoWo / bm) <= TF_GN_MAX_CHUNKS; }
 
-template <int BM, int BN, bool GENERIC, bool WIDE>
+template <int BM, int BN, bool GENERIC, bool WIDE, bool ALL8 = false>
 static int launch_cfg3(const GemmP& p, hipStream_t st) {
   constexpr int TM = BM / 2, TN = BN / 2;
   constexpr int ring = (WIDE ? 2 : ring_slots(BM, BN)) * (BM + BN) * 128;
@@ -844,23 +1246,62 @@ static int launch_cfg3(const GemmP& p, hipStream_t st) {
   constexpr int smem = ring > scratch + tail ? ring : scratch + tail;
   static bool attr_set = false;
   if (!attr_set) {
-    TF_HIP(hipFuncSetAttribute((const void*)k_igemm<BM, BN, GENERIC, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    TF_HIP(hipFuncSetAttribute((const void*)k_igemm<BM, BN, GENERIC, WIDE, ALL8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_igemm<BM, BN, GENERIC, WIDE>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
+  hipLaunchKernelGGL((k_igemm<BM, BN, GENERIC, WIDE, ALL8>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
+// k_igemm_patch: eligibility + geometry for a (bm, bn) tile.  3x3 / stride 1 / pad 1, no up-sampling, every channel count a
+// multiple of 64, W a power of two that divides bm, m-tiles inside one image, and an LDS budget that leaves >= 3 ring slots.
+static bool patch_setup(GemmP& p, int bm, int bn) {
+  if (p.act || p.ln_colsum || p.S != 3 || p.Kc != 9 * p.C || p.stride != 1 || p.pad != 1 || p.ups) return false;
+  if ((p.C1 % 64) || (p.C2 % 64) || (p.C3 % 64) || (p.C4 % 64) || p.H != p.Ho || p.W != p.Wo) return false;
+  if (!((bm == 64 || bm == 128) && (bn == 128 || bn == 160))) return false;
+  if ((p.W & (p.W - 1)) || p.W < 8 || p.W > bm || p.HoWo % bm) return false;
+  int l2 = 0;
+  while ((1 << l2) < p.W) ++l2;
+  const int ppix = (bm / p.W + 2) * (p.W + 2), ppc = (ppix + 7) / 8;
+  if ((ppc + 3) / 4 > TF_PATCH_PPW) return false;
+  const int stage = bn * 128 + ((p.C3 + p.C4) ? bm * 128 : 0);
+  int ns = (163840 - 2 * ppc * 1024) / stage;
+  if (ns > 5) ns = 5;                                    // patch pieces ride from tap 4 on: needs ns - 1 <= 4 (k_igemm_patch TAP0)
+  if (ns < 3) return false;
+  p.pt_ppc = ppc; p.pt_ppix = ppix; p.pt_stage = stage; p.pt_ns = ns; p.pt_log2w = l2;
+  return true;
+}
+template <int BM, int BN>
+static int launch_patch(const GemmP& p, hipStream_t st) {
+  constexpr int TM = BM / 2, TN = BN / 2;
+  constexpr int scratch = 4 * TM * (TN + 4) * 4, tail = BM * 8 + 4 * BN * 8;
+  const int ring = 2 * p.pt_ppc * 1024 + p.pt_ns * p.pt_stage;
+  const int smem = ring > scratch + tail ? ring : scratch + tail;
+  static bool attr_set = false;
+  if (!attr_set) {
+    TF_HIP(hipFuncSetAttribute((const void*)k_igemm_patch<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_igemm_patch<BM, BN>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+
+static bool gemm_generic(const GemmP& p) { return (p.C1 % 64) != 0 || (p.C2 % 64) != 0 || (p.C3 % 64) != 0 || (p.C4 % 64) != 0; }
 template <int BM, int BN, bool WIDE_OK>
-static int launch_cfg(const GemmP& p, hipStream_t st, bool wide) {
-  bool generic = (p.C1 % 64) != 0 || (p.C2 % 64) != 0 || (p.C3 % 64) != 0 || (p.C4 % 64) != 0;
+static int launch_cfg(const GemmP& p, hipStream_t st, bool wide, bool all8 = false) {
+  bool generic = gemm_generic(p);
+  if (all8 && !generic) return launch_cfg3<BM, BN, false, false, true>(p, st);
   if (WIDE_OK && wide) return generic ? launch_cfg3<BM, BN, true, WIDE_OK>(p, st) : launch_cfg3<BM, BN, false, WIDE_OK>(p, st);
   return generic ? launch_cfg3<BM, BN, true, false>(p, st) : launch_cfg3<BM, BN, false, false>(p, st);
 }
 
 // one fully specified launch (tile, split-K, ring variant) of the kernel family (+ the split-K reduce)
-static int launch_one(GemmP p, TileCfg c, bool wide, int order, void* workspace, hipStream_t st) {
+// variant: 0 deep ring, 1 WIDE (two blocks per CU), 2 PATCH (k_igemm_patch; falls back to 0 when the shape is not eligible),
+// 3 ALL8 (deep ring, the consumer waves issue part of the weight pieces; falls back to 0 for channel counts off the 64 grid)
+static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspace, hipStream_t st) {
   int rc = 0;
+  const bool wide = variant == 1, all8 = variant == 3;
   p.order = order;
   p.ktiles_per_split = (p.ktiles + c.splitk - 1) / c.splitk;
   p.splitk = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
@@ -873,12 +1314,18 @@ static int launch_one(GemmP p, TileCfg c, bool wide, int order, void* workspace,
     if (p.splitk > 1) { p.gn_chunks = gn_reduce_chunks(p.HoWo); p.gn_part = nullptr; }
     else p.gn_chunks = gn_pieces(p, c.bn) * (p.HoWo / c.bm);
   }
-  if (c.bm == 128 && c.bn == 160) rc = launch_cfg<128, 160, false>(p, st, wide);     // scratch 86 KB: one block per CU only
-  else if (c.bm == 64 && c.bn == 160) rc = launch_cfg<64, 160, true>(p, st, wide);
-  else if (c.bm == 128 && c.bn == 128) rc = launch_cfg<128, 128, true>(p, st, wide);
-  else if (c.bm == 64 && c.bn == 128) rc = launch_cfg<64, 128, true>(p, st, wide);
-  else if (c.bm == 128 && c.bn == 64) rc = launch_cfg<128, 64, true>(p, st, wide);
-  else if (c.bm == 64 && c.bn == 64) rc = launch_cfg<64, 64, true>(p, st, wide);
+  if (variant == 2 && patch_setup(p, c.bm, c.bn)) {
+    if (c.bm == 128 && c.bn == 160) rc = launch_patch<128, 160>(p, st);
+    else if (c.bm == 64 && c.bn == 160) rc = launch_patch<64, 160>(p, st);
+    else if (c.bm == 128 && c.bn == 128) rc = launch_patch<128, 128>(p, st);
+    else rc = launch_patch<64, 128>(p, st);
+  }
+  else if (c.bm == 128 && c.bn == 160) rc = launch_cfg<128, 160, false>(p, st, wide, all8);     // scratch 86 KB: one block per CU only
+  else if (c.bm == 64 && c.bn == 160) rc = launch_cfg<64, 160, true>(p, st, wide, all8);
+  else if (c.bm == 128 && c.bn == 128) rc = launch_cfg<128, 128, true>(p, st, wide, all8);
+  else if (c.bm == 64 && c.bn == 128) rc = launch_cfg<64, 128, true>(p, st, wide, all8);
+  else if (c.bm == 128 && c.bn == 64) rc = launch_cfg<128, 64, true>(p, st, wide, all8);
+  else if (c.bm == 64 && c.bn == 64) rc = launch_cfg<64, 64, true>(p, st, wide, all8);
   else { tf_set_error("run_gemm: no kernel for tile %dx%d", c.bm, c.bn); return TF_E_UNSUPPORTED; }
   if (rc) return rc;
   p.gn_part = gn_part;
@@ -907,7 +1354,7 @@ static int launch_one(GemmP p, TileCfg c, bool wide, int order, void* workspace,
 // inside a stream capture (a captured shape that was never seen eagerly falls back to the cost model).
 #define TF_SPLITK_WS_CAP ((size_t)64 << 20)
 static bool g_autotune = true;
-struct TunedCfg { TileCfg c; bool wide; int order; };
+struct TunedCfg { TileCfg c; int variant; int order; };   // variant: see launch_one
 static std::map<std::array<int, 10>, TunedCfg> g_tuned;
 
 #define TF_FLUSH_BYTES ((size_t)384 << 20)
@@ -918,7 +1365,7 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
   hipEvent_t a, b;
   TF_HIP(hipEventCreate(&a)); TF_HIP(hipEventCreate(&b));
   float best = 1e30f;
-  TunedCfg bc = {choose_tiles(p.M, p.N, p.K, p.act, true), false, 0};
+  TunedCfg bc = {choose_tiles(p.M, p.N, p.K, p.act, true), 0, 0};
   for (int ci = 0; ci < 6; ++ci) {
     int bm = cand[ci][0], bn = cand[ci][1];
     if (p.act == 1 && (bn % 64) != 0) continue;
@@ -928,15 +1375,17 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
       if (sk > 1 && (p.act == 1 || p.ln_colsum || p.ktiles / sk < 4 || !workspace || (size_t)sk * p.M * p.N * 4 > workspace_bytes)) break;
       long long blocks = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * sk;
       if (sk > 1 && blocks > 1024) break;
-      for (int wide = 0; wide < 2; ++wide) {
-        if (wide && (bm == 128 && bn == 160)) continue;
-        if (wide && blocks <= 256) continue;               // two blocks per CU need more blocks than CUs
+      for (int wide = 0; wide < 4; ++wide) {                // the launch_one variants
+        if (wide == 3 && gemm_generic(p)) continue;
+        if (wide == 1 && (bm == 128 && bn == 160)) continue;
+        if (wide == 1 && blocks <= 256) continue;          // two blocks per CU need more blocks than CUs
+        if (wide == 2) { GemmP probe = p; if (!patch_setup(probe, bm, bn)) continue; }
         TileCfg c = {bm, bn, sk};
         for (int order = 0; order < 2; ++order) {
           if (order == 1 && (p.M + bm - 1) / bm == 1) continue;   // a single m tile: both orders coincide
           GemmP q = p;
           if (q.gn_part && sk == 1 && !gn_tile_ok(q, bm, bn)) q.gn_part = nullptr;
-          int rc = launch_one(q, c, wide != 0, order, workspace, st);   // warm-up
+          int rc = launch_one(q, c, wide, order, workspace, st);   // warm-up
           if (rc) return rc;
           // In the real step every layer's weights come from HBM (1.7 GB of weights per step never stay cached), so each
           // timed launch is preceded by a cache flush (a 384 MiB memset, outside the timed interval): median of 5.
@@ -944,7 +1393,7 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
           for (int r = 0; r < 5; ++r) {
             TF_HIP(hipMemsetAsync(g_flush, r, TF_FLUSH_BYTES, st));
             TF_HIP(hipEventRecord(a, st));
-            rc = launch_one(q, c, wide != 0, order, workspace, st);
+            rc = launch_one(q, c, wide, order, workspace, st);
             if (rc) return rc;
             TF_HIP(hipEventRecord(b, st));
             TF_HIP(hipEventSynchronize(b));
@@ -952,7 +1401,7 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
           }
           for (int i = 0; i < 5; ++i) for (int j = i + 1; j < 5; ++j) if (tv[j] < tv[i]) { float t = tv[i]; tv[i] = tv[j]; tv[j] = t; }
           float ms = tv[2];
-          if (ms < best) { best = ms; bc = {c, wide != 0, order}; }
+          if (ms < best) { best = ms; bc = {c, wide, order}; }
         }
       }
     }
@@ -967,7 +1416,7 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
   p.dbg = g_dbg;
   fast_div_magic((unsigned)p.HoWo, &p.dv_howo_mul, &p.dv_howo_shr);
   fast_div_magic((unsigned)p.Wo, &p.dv_wo_mul, &p.dv_wo_shr);
-  TunedCfg t = {choose_tiles(p.M, p.N, p.K, p.act, true), false, 0};
+  TunedCfg t = {choose_tiles(p.M, p.N, p.K, p.act, true), 0, 0};
   bool tuned = false;
   if (force_bm) {
     t.c = {force_bm, force_bn, force_split > 0 ? force_split : 1};
@@ -992,18 +1441,18 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     size_t need = (size_t)t.c.splitk * p.M * p.N * sizeof(float);
     if (!workspace || workspace_bytes < need) t.c.splitk = 1;   // degrade gracefully: correctness does not depend on split-K
   }
-  bool wide = t.wide;
+  int wide = t.variant;
   if (!tuned) {
     // cost-model fallback: WIDE (two blocks per CU) pays when a CU gets several tiles with a short K loop each
     long long blocks = (long long)((p.M + t.c.bm - 1) / t.c.bm) * ((p.N + t.c.bn - 1) / t.c.bn) * t.c.splitk;
-    wide = blocks > 256 && p.ktiles / t.c.splitk <= 24;
+    wide = (blocks > 256 && p.ktiles / t.c.splitk <= 24) ? 1 : 0;
   }
-  if (g_force_wide >= 0) wide = g_force_wide != 0;
+  if (g_force_wide >= 0) wide = g_force_wide;
   ProfRec rec;
   if (g_prof) {
     TF_HIP(hipEventCreate(&rec.a)); TF_HIP(hipEventCreate(&rec.b));
     rec.flops = 2.0 * p.M * (double)p.N * p.K;
-    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.taps = p.Kc / p.C; rec.bm = t.c.bm; rec.bn = t.c.bn; rec.splitk = t.c.splitk * (wide ? -1 : 1);
+    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.taps = p.Kc / p.C; rec.bm = t.c.bm; rec.bn = t.c.bn; rec.splitk = t.c.splitk * (wide == 1 ? -1 : 1);
     TF_HIP(hipEventRecord(rec.a, st));
   }
   if (g_force_order >= 0) t.order = g_force_order;
@@ -1036,7 +1485,7 @@ extern "C" {
 
 int tf_gemm_debug(int flags) {
   g_dbg = flags & 7;
-  g_force_wide = (flags & 16) ? 1 : (flags & 8) ? 0 : -1;
+  g_force_wide = (flags & 256) ? 3 : (flags & 128) ? 2 : (flags & 16) ? 1 : (flags & 8) ? 0 : -1;   // 128 / 256: the PATCH / ALL8 variants where eligible
   g_force_order = (flags & 64) ? 1 : (flags & 32) ? 0 : -1;
   return TF_OK;
 }
@@ -1048,7 +1497,7 @@ int tf_gemm_tune_save(const char* path) {
   TF_REQUIRE(f, "tf_gemm_tune_save: cannot open %s", path);
   for (auto& kv : g_tuned) {
     for (int i = 0; i < 10; ++i) fprintf(f, "%d ", kv.first[i]);
-    fprintf(f, "%d %d %d %d %d\n", kv.second.c.bm, kv.second.c.bn, kv.second.c.splitk, kv.second.wide ? 1 : 0, kv.second.order);
+    fprintf(f, "%d %d %d %d %d\n", kv.second.c.bm, kv.second.c.bn, kv.second.c.splitk, kv.second.variant, kv.second.order);
   }
   fclose(f);
   return TF_OK;
@@ -1064,7 +1513,7 @@ int tf_gemm_tune_load(const char* path) {
     n += fscanf(f, "%d %d %d %d %d", &bm, &bn, &sk, &wide, &order);
     if (n != 15) break;
     bool ok = (bm == 64 || bm == 128) && (bn == 64 || bn == 128 || bn == 160) && sk >= 1 && sk <= 32;
-    if (ok) g_tuned[k] = {{bm, bn, sk}, wide != 0, order != 0 ? 1 : 0};
+    if (ok) g_tuned[k] = {{bm, bn, sk}, wide < 0 || wide > 3 ? 0 : wide, order != 0 ? 1 : 0};
   }
   fclose(f);
   return TF_OK;

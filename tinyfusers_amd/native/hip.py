@@ -84,6 +84,7 @@ hip = _Hip()
 
 # per-shape GEMM configurations measured on MI355X for the SD-1.x step (tools/tune_best.sh); shapes that are not in the
 # table are autotuned on their first eager call
-_TUNE = os.path.join(os.path.dirname(_HERE), "gemm_tune_gfx950.txt")
-if os.path.exists(_TUNE):
+# TF_GEMM_TUNE_TABLE=<path> uses another table, TF_GEMM_TUNE_TABLE= (empty) none: every shape is tuned afresh (tools/tune_best.sh)
+_TUNE = os.environ.get("TF_GEMM_TUNE_TABLE", os.path.join(os.path.dirname(_HERE), "gemm_tune_gfx950.txt"))
+if _TUNE and os.path.exists(_TUNE):
     lib.tf_gemm_tune_load(_TUNE.encode())
