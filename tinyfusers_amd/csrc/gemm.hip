@@ -1190,10 +1190,10 @@ __global__ void __launch_bounds__(256) k_ln_fold(half_t* __restrict__ wo, half_t
 static bool g_prof = false;
 static double g_prof_ms = 0.0, g_prof_flops = 0.0;
 static long long g_prof_launches = 0;
-struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, taps, bm, bn, splitk; };
+struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, taps, bm, bn, splitk, variant; };
 #include <map>
 #include <array>
-static std::map<std::array<int, 7>, std::pair<long long, double>> g_prof_shapes;
+static std::map<std::array<int, 8>, std::pair<long long, double>> g_prof_shapes;
 static std::vector<ProfRec> g_prof_pending;
 
 static int g_dbg = 0, g_force_wide = -1, g_force_order = -1;
@@ -1452,7 +1452,7 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
   if (g_prof) {
     TF_HIP(hipEventCreate(&rec.a)); TF_HIP(hipEventCreate(&rec.b));
     rec.flops = 2.0 * p.M * (double)p.N * p.K;
-    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.taps = p.Kc / p.C; rec.bm = t.c.bm; rec.bn = t.c.bn; rec.splitk = t.c.splitk * (wide == 1 ? -1 : 1);
+    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.taps = p.Kc / p.C; rec.bm = t.c.bm; rec.bn = t.c.bn; rec.splitk = t.c.splitk; rec.variant = wide;
     TF_HIP(hipEventRecord(rec.a, st));
   }
   if (g_force_order >= 0) t.order = g_force_order;
@@ -1547,7 +1547,7 @@ int tf_prof_read(double* ms, double* flops, long long* launches) {
     t -= g_prof_overhead_ms;
     if (t < 0.f) t = 0.f;
     g_prof_ms += t; g_prof_flops += r.flops; g_prof_launches += 1;
-    auto& e = g_prof_shapes[{r.M, r.N, r.K, r.taps, r.bm, r.bn, r.splitk}];
+    auto& e = g_prof_shapes[{r.M, r.N, r.K, r.taps, r.bm, r.bn, r.splitk, r.variant}];
     e.first += 1; e.second += t;
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
@@ -1564,12 +1564,12 @@ int tf_prof_dump(const char* path) {
   if (rc) return rc;
   FILE* f = fopen(path, "w");
   TF_REQUIRE(f, "tf_prof_dump: cannot open %s", path);
-  fprintf(f, "M,N,K,taps,bm,bn,splitk,launches,total_ms,avg_us,tflops\n");
+  fprintf(f, "M,N,K,taps,bm,bn,splitk,variant,launches,total_ms,avg_us,tflops\n");   // variant: 0 deep ring, 1 wide, 2 patch, 3 all8
   for (auto& kv : g_prof_shapes) {
     const auto& k = kv.first;
     double ms = kv.second.second; long long n = kv.second.first;
     double tf = 2.0 * k[0] * (double)k[1] * k[2] * n / (ms * 1e-3) / 1e12;
-    fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%lld,%.4f,%.2f,%.1f\n", k[0], k[1], k[2], k[3], k[4], k[5], k[6], n, ms, ms * 1e3 / n, tf);
+    fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%lld,%.4f,%.2f,%.1f\n", k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], n, ms, ms * 1e3 / n, tf);
   }
   fclose(f);
   return TF_OK;

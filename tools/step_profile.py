@@ -24,9 +24,9 @@ for i in range(5):
 sd.synchronize()
 hip.tf_prof_dump(out.encode())
 rows = [l.strip().split(",") for l in open(out)][1:]
-rows.sort(key=lambda r: -float(r[8]))
-tot = sum(float(r[8]) for r in rows)
+rows.sort(key=lambda r: -float(r[9]))
+tot = sum(float(r[9]) for r in rows)
 print("total gemm ms/step: %.3f" % (tot / 5))
-print("%6s %6s %6s %4s %8s %3s %5s %9s %8s %7s" % ("M", "N", "K", "taps", "tile", "sk", "n/st", "ms/step", "avg_us", "TF/s"))
+print("%6s %6s %6s %4s %8s %3s %3s %5s %9s %8s %7s" % ("M", "N", "K", "taps", "tile", "sk", "var", "n/st", "ms/step", "avg_us", "TF/s"))
 for r in rows:
-    print("%6s %6s %6s %4s %8s %3s %5d %9.3f %8s %7s" % (r[0], r[1], r[2], r[3], r[4] + "x" + r[5], r[6], int(r[7]) // 5, float(r[8]) / 5, r[9], r[10]))
+    print("%6s %6s %6s %4s %8s %3s %3s %5d %9.3f %8s %7s" % (r[0], r[1], r[2], r[3], r[4] + "x" + r[5], r[6], r[7], int(r[8]) // 5, float(r[9]) / 5, r[10], r[11]))
