@@ -261,7 +261,7 @@ __device__ __forceinline__ void igemm_gn_stats(const GemmP& p, char* smem, int m
 // WIDE = false is the deep variant: 4-slot ring, fragments of tile t+1 prefetched during tile t, one block per CU.
 // ALL8 = true (deep variant only): the consumer waves issue LPC of the WEIGHT pieces of every stage themselves.  Data that is
 // not L2 resident (each layer's weights arrive cold from HBM / Infinity Cache) streams at a rate set by the number of waves
-// that have loads outstanding, not by the pieces each keeps in flight (tools/micro/ingest.hip: 28 GB/s per CU with 4
+// that have loads outstanding, not by the pieces each keeps in flight (tools/ingest_waves.hip: 28 GB/s per CU with 4
 // issuing waves, 44-52 GB/s with 8), so the weight-bound shapes gain from eight issuing waves what the L2-resident ones
 // lose in MFMA issue slots; one of the autotuned variants.
 template <int BM, int BN, bool GENERIC, bool WIDE, bool ALL8 = false>

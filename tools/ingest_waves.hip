@@ -1,4 +1,4 @@
-// Ingest micro-benchmark: how fast can ONE CU pull L2-resident data, as a function of the landing place and of the bytes in flight?
+// Ingest micro-benchmark (hipcc --offload-arch=gfx950 -O3 tools/ingest_waves.hip -o tools/ingest_waves): how fast can ONE CU pull L2-resident data, as a function of the landing place and of the bytes in flight?
 //   mode 0: LDS-DMA (buffer_load ... lds), W waves, D 1-KiB pieces in flight per wave (ring in LDS)
 //   mode 1: global_load_dwordx4 into VGPRs, W waves, D loads (1 KiB per wave each) in flight per wave, data xor-ed away
 //   mode 2: as mode 1 but every landed piece is also written to LDS (ds_write_b128), the cost a register-staged loader pays
