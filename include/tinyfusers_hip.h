@@ -27,6 +27,7 @@ extern "C" {
 typedef struct tfStream_st* tfStream_t;
 typedef struct tfEvent_st* tfEvent_t;
 typedef struct tfGraph_st* tfGraph_t;
+typedef struct tfComm_st* tfComm_t;
 
 #define TF_OK 0
 #define TF_E_ARG 10001
@@ -82,6 +83,16 @@ int tf_graph_begin_capture(tfStream_t s);
 int tf_graph_end_capture(tfStream_t s, tfGraph_t* out);
 int tf_graph_launch(tfGraph_t g, tfStream_t s);
 int tf_graph_destroy(tfGraph_t g);
+
+/* ---- multi-GPU: one process per GPU, the path shards by image, and the only exchange is the one-off broadcast of
+ * the packed weight arena.  The reference has no communication (device_id = 0, storage/device.py:23).  RCCL over xGMI, opened on
+ * first use.  tf_comm_unique_id: rank 0 fills 128 bytes and hands them to the other ranks over any host channel; every rank then
+ * calls tf_comm_init_rank on its own device (tf_init first); tf_bcast is stream-ordered and in place. */
+#define TF_COMM_UNIQUE_ID_BYTES 128
+int tf_comm_unique_id(void* id_out);
+int tf_comm_init_rank(tfComm_t* out, const void* unique_id, int nranks, int rank);
+int tf_bcast(tfComm_t comm, void* ptr, size_t nbytes, int root, tfStream_t s);
+int tf_comm_destroy(tfComm_t comm);
 /* per-launch profiling of the GEMM/conv kernel family with HIP events on the launch stream
  * (bench.py roofline leg): enable, run eagerly, then read back accumulated ms / flops / launches. */
 int tf_prof_enable(int on);

@@ -561,3 +561,25 @@ def test_gemm_all8_variant_is_bit_identical(tf, kind, dims, force):
             lib.tf_gemm_force_config(0, 0, 0); lib.tf_gemm_debug(0)
     close(got[256], want)
     np.testing.assert_array_equal(got[256], got[8])
+
+
+def test_comm_single_rank_broadcast(tf):
+    """tf_comm_unique_id / tf_comm_init_rank / tf_bcast / tf_comm_destroy (RCCL) with a world of one rank: the
+    weight-arena broadcast a non-Python host would issue; in place, stream-ordered, the payload comes back unchanged."""
+    import ctypes
+    hip = tf.hip
+    uid = (ctypes.c_char * 128)()
+    hip.tf_comm_unique_id(uid)
+    assert any(bytes(uid)), "empty unique id"
+    comm = ctypes.c_void_p()
+    hip.tf_comm_init_rank(ctypes.byref(comm), uid, 1, 0)
+    try:
+        x = np.arange(1 << 20, dtype=np.float32)
+        d = tf.DeviceArray.from_numpy(x, np.float32, "row")
+        hip.tf_bcast(comm, d.ptr, d.nbytes, 0, None)
+        hip.tf_stream_sync(None)
+        np.testing.assert_array_equal(d.numpy(), x)
+        with pytest.raises(RuntimeError):
+            hip.tf_bcast(comm, d.ptr, d.nbytes, 1, None)        # root outside the world
+    finally:
+        hip.tf_comm_destroy(comm)

@@ -12,7 +12,8 @@ _CT = {
     "void**": ctypes.POINTER(ctypes.c_void_p), "const void*const*": ctypes.c_void_p, "void*const*": ctypes.c_void_p, "int*": ctypes.POINTER(ctypes.c_int), "const int*": ctypes.POINTER(ctypes.c_int),
     "float*": ctypes.POINTER(ctypes.c_float), "double*": ctypes.POINTER(ctypes.c_double),
     "long long*": ctypes.POINTER(ctypes.c_longlong), "char*": ctypes.c_char_p, "const char*": ctypes.c_char_p,
-    "tfStream_t": ctypes.c_void_p, "tfEvent_t": ctypes.c_void_p, "tfGraph_t": ctypes.c_void_p,
+    "tfStream_t": ctypes.c_void_p, "tfEvent_t": ctypes.c_void_p, "tfGraph_t": ctypes.c_void_p, "tfComm_t": ctypes.c_void_p,
+    "tfComm_t*": ctypes.POINTER(ctypes.c_void_p),
     "tfStream_t*": ctypes.POINTER(ctypes.c_void_p), "tfEvent_t*": ctypes.POINTER(ctypes.c_void_p),
     "tfGraph_t*": ctypes.POINTER(ctypes.c_void_p), "void": None,
 }
