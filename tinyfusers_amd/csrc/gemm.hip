@@ -268,7 +268,8 @@ template <int BM, int BN, bool GENERIC, bool WIDE, bool ALL8 = false>
 __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   constexpr int TM = BM / 2, TN = BN / 2, MJ = TM / 16, NI = TN / 16;
   constexpr int NG = (BM + BN) / 8;                       // 8-row staging groups: activation rows first, then weight rows
-  constexpr int LPC = ALL8 ? (BN >= 128 ? (BM + BN >= 256 ? 3 : 2) : 1) : 0;   // weight pieces per CONSUMER wave per stage (the last 4 LPC groups)
+  // weight pieces per CONSUMER wave per stage (the last 4 LPC groups); one more per wave measured 1-3 % slower on every shape
+  constexpr int LPC = ALL8 ? (BN >= 128 ? (BM + BN >= 256 ? 3 : 2) : 1) : 0;
   constexpr int LPS = NG / 4 - LPC;                       // LDS-DMA pieces per loader wave per stage
   static_assert(!(ALL8 && (WIDE || GENERIC)), "ALL8 is a deep-ring, 64-channel-aligned variant");
   static_assert(4 * LPC <= BN / 8, "the consumers take weight groups only");
