@@ -3,7 +3,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libtinyfusers_hip.so")
+LIB_PATH = os.environ.get("TF_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libtinyfusers_hip.so")   # TF_LIB_PATH: an experimental build
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "tinyfusers_hip.h")
 
 _CT = {
