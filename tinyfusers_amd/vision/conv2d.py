@@ -59,8 +59,9 @@ def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, up
     return y
 
 
-def _conv_small_c(x, w, bias, padding, stride, cache):
-    """Cin % 8 != 0 (the 4-channel conv_in): im2col to K padded to 64, then the same GEMM kernel."""
+def _conv_small_c(x, w, bias, padding, stride, cache, gn=0):
+    """Cin % 8 != 0 (the 4-channel conv_in): im2col to K padded to 64, then the same GEMM kernel -- as a 1x1 convolution over the
+    (n, ho, wo, kpad) patch image, so that the GroupNorm statistics of the output can ride along (gn) like for any other conv."""
     n, c, h, wd = x.shape
     k, _, r, s = w.shape
     kk = r * s * c
@@ -74,8 +75,7 @@ def _conv_small_c(x, w, bias, padding, stride, cache):
         cache["key"], cache["w"] = key, wp
     col = DeviceArray.empty((n * ho * wo, kpad), np.float16, "row")
     hip.tf_im2col_nhwc_f16(col.ptr, x.ptr, n, h, wd, c, r, s, stride[0], padding[0], kpad, _sh())
-    y = linear_f16(col, cache["w"], bias)
-    return y.view((n, k, ho, wo), "nhwc")
+    return _conv(col.view((n, kpad, ho, wo), "nhwc"), cache["w"].view((k, kpad, 1, 1), "nhwc"), bias, [0, 0], [1, 1], [1, 1], gn=gn)
 
 
 def conv_2d(X_gpu, W_gpu, padding, stride, dilation):
@@ -129,5 +129,5 @@ class Conv2d:
         cin = (x[0].shape[1] + x[1].shape[1]) if isinstance(x, (tuple, list)) else x.shape[1]
         if cin % 8 != 0:
             assert bias_nc is None and residual is None and not upsample
-            return _conv_small_c(x, self.weight, self.bias, self.padding, self.stride, self._cache)
+            return _conv_small_c(x, self.weight, self.bias, self.padding, self.stride, self._cache, gn)
         return _conv(x, self.weight, self.bias, self.padding, self.stride, self.dilation, bias_nc, residual, upsample, gn)

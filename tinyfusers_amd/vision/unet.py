@@ -182,6 +182,8 @@ class UNetModel:
                 return bb(x, context, kv=KVSlice(kv_all, bt["kv_off"][id(bb)], c, bt["kv_n"]), out_gn=gn)
             if isinstance(bb, (Downsample, Upsample)):
                 return bb(x, out_gn=gn)
+            if isinstance(bb, Conv2d):
+                return bb(x, gn=gn)                            # conv_in: its output feeds the first ResBlock's GroupNorm and the last skip concat
             return bb(x)
 
         saved_inputs = []
