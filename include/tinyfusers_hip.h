@@ -226,6 +226,12 @@ int tf_group_norm_apply_f16(void* y, const void* x, const void* gamma, const voi
 int tf_group_norm_apply2_f16(void* y, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial,
                              int chunks, const void* partial2, int chunks2, int N, int HW, int C1, int G, float eps, int silu,
                              tfStream_t s);
+/* General form: the producers' partials have groups1 / groups2 sub-groups of equal width (C1/groups1 == C2/groups2) that tile the groups of
+ * the concat ((C1+C2)/G = m * width, m <= 8); a group may straddle the two sources (1280 + 640 channels, 32 groups: partials with 64 and
+ * 32 sub-groups of 20 channels).  tf_group_norm_apply2_f16 is the equal-split case groups1 = groups2 = G. */
+int tf_group_norm_apply_cat_f16(void* y, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial, int chunks,
+                                int groups1, const void* partial2, int chunks2, int groups2, int N, int HW, int C1, int C2, int G, float eps,
+                                int silu, tfStream_t s);
 /* LayerNorm over the last dim (ff/layer_norm.py:8-32, :34-49; semantics = F.layer_norm, tests/layer_norm.py:38) */
 int tf_layer_norm_f16(void* y, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s);
 

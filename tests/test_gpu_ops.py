@@ -421,33 +421,39 @@ def test_linear_cublas_and_gemm_batch_fp32(tf):
         hip.tf_sgemm_f32(0, 0, 4, 4, 4, 1.0, da.dt_ptr, 2, db.dt_ptr, 4, 0.0, dc.dt_ptr, 4, None)          # lda < m
 
 
-@pytest.mark.parametrize("c,hw,force", [(128, 16, (64, 64, 1)), (320, 16, None), (1280, 8, None), (128, 8, (64, 160, 4))])
-def test_group_norm_of_equal_split_concat_from_producer_statistics(tf, c, hw, force):
-    """GroupNorm(32) over concat(x, skip) of two equally wide conv outputs (vision/unet.py:72 into resnet.py:8) with the statistics
-    merged from the two producers' 32-group partials (tf_group_norm_apply2_f16) vs the oracle's group_norm of the concat."""
+@pytest.mark.parametrize("c1,c2,hw,force", [(128, 128, 16, (64, 64, 1)), (320, 320, 16, None), (1280, 1280, 8, None), (128, 128, 8, (64, 160, 4)),
+                                            (256, 128, 16, None), (1280, 640, 16, None), (640, 320, 32, (128, 160, 2)), (1280, 640, 8, (64, 160, 4))])
+def test_group_norm_of_concat_from_producer_statistics(tf, c1, c2, hw, force):
+    """GroupNorm(32) over concat(x, skip) of two conv outputs (vision/unet.py:72 into resnet.py:8) with the statistics merged from the
+    two producers' partials (tf_group_norm_apply_cat_f16) vs the oracle's group_norm of the concat: equal splits (32 + 32 sub-groups,
+    two per group) and the 2:1 splits of the output path (64 + 32 sub-groups, three per group, one group straddling the sources)."""
     from oracle import ops as O
     from tinyfusers_amd.native import lib
     from tinyfusers_amd.ff.group_norm import GroupNorm
     from tinyfusers_amd.vision.conv2d import Conv2d
+    sub = c2 // 32
     ys = []
-    for tag in ("a", "b"):
+    for tag, c in (("a", c1), ("b", c2)):
         x = rnd("cs.x" + tag, (2, 64, hw, hw)); w = rnd("cs.w" + tag, (c, 64, 3, 3), (64 * 9) ** -0.5); b = rnd("cs.b" + tag, (c,), 0.3)
         m = Conv2d(64, c, [3, 3], padding=[1, 1], init=False); m.weight = dev(tf, w); m.bias = dev(tf, b)
         if force:
             lib.tf_gemm_force_config(*force)
         try:
-            ys.append(m(dev(tf, x), gn=32))
+            ys.append(m(dev(tf, x), gn=c // sub))
         finally:
             lib.tf_gemm_force_config(0, 0, 0)
-        assert ys[-1].gn is not None
-    gam = 1.0 + rnd("cs.g", (2 * c,), 0.1); bet = rnd("cs.bt", (2 * c,), 0.1)
-    g = GroupNorm(32, 2 * c, init=False); g.weight = dev(tf, gam, "row"); g.bias = dev(tf, bet, "row")
+        assert ys[-1].gn is not None and ys[-1].gn[2] == c // sub
+    gam = 1.0 + rnd("cs.g", (c1 + c2,), 0.1); bet = rnd("cs.bt", (c1 + c2,), 0.1)
+    g = GroupNorm(32, c1 + c2, init=False); g.weight = dev(tf, gam, "row"); g.bias = dev(tf, bet, "row")
     got = g((ys[0], ys[1]), silu=True).numpy()
     cat = torch.from_numpy(np.concatenate((ys[0].numpy(), ys[1].numpy()), 1))
     close(got, O.silu(O.group_norm_affine(cat, 32, gam, bet, 1e-5)).numpy())
     ys[0].gn = None
     plain = g((ys[0], ys[1]), silu=True).numpy()          # statistics pass over the concat
     np.testing.assert_allclose(got, plain, atol=2e-3, rtol=2e-3)
+    with pytest.raises(RuntimeError):                      # sub-groups of different widths cannot be merged
+        tf.hip.tf_group_norm_apply_cat_f16(ys[0].ptr, ys[0].ptr, ys[1].ptr, None, None, ys[1].gn[0].ptr, 1, 32, ys[1].gn[0].ptr, 1, 16, 2, hw * hw,
+                                           c1, c2, 32, 1e-5, 0, None)
 
 
 @pytest.mark.parametrize("vocab,dim,b,n,pos", [(10, 8, 1, 10, False), (10, 8, 1, 10, True), (49408, 768, 2, 77, True), (77, 1280, 3, 5, False)])

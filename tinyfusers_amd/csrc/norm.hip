@@ -70,7 +70,8 @@ __global__ void k_gn_stats(float* __restrict__ partial, const half_t* __restrict
 #define GN_APPLY_PPT 4
 __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ x2, const half_t* __restrict__ gamma,
                            const half_t* __restrict__ beta, const float* __restrict__ partial, int HW, int C1, int C2, int G, float eps,
-                           int do_silu, int chunks, int pix_per_block, int CV, int RPB, const float* __restrict__ partial2, int chunks2) {
+                           int do_silu, int chunks, int pix_per_block, int CV, int RPB, const float* __restrict__ partial2, int chunks2,
+                           int G1, int G2, int mr) {
   extern __shared__ float st[];  // [G][2] : mean, rstd
   int n = blockIdx.y;
   int C = C1 + C2, cpg = C / G;
@@ -103,31 +104,31 @@ __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x,
       int g = g0 + (t >> 3);
       double S = 0.0, SS = 0.0;
       if (g < G) {
-        // this lane's chunks k = sub, sub + 8, ...: 8 independent loads in flight per round, summed in k order
-        const float* pp = partial + (long long)n * chunks * G * 2 + g * 2;
-        int nch = chunks;
-        const int gstride = G * 2;
-        bool pair = false;
-        if (partial2) {
-          // concat of two equal halves whose statistics came as G-group partials of EACH half (tf_group_norm_apply2_f16):
-          // group g of the concat = groups (2g', 2g'+1) of one half, g' = g mod G/2
-          const int hg = G >> 1, gl = g < hg ? g : g - hg;
-          const float* src = g < hg ? partial : partial2;
-          nch = g < hg ? chunks : chunks2;
-          pp = src + (long long)n * nch * G * 2 + (2 * gl) * 2;
-          pair = true;
-        }
-        for (int k0 = sub; k0 < nch; k0 += 64) {
-          f4 v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            int k = k0 + 8 * u;
-            if (k >= nch) v[u] = (f4){0.f, 0.f, 0.f, 0.f};
-            else if (pair) v[u] = *reinterpret_cast<const f4*>(pp + (long long)k * gstride);        // (S, SS) of both groups
-            else { f2 w = *reinterpret_cast<const f2*>(pp + (long long)k * gstride); v[u] = (f4){w[0], w[1], 0.f, 0.f}; }
+        // this lane's chunks k = sub, sub + 8, ...: 8 independent loads in flight per round, summed in k order.
+        // partial2 != NULL (tf_group_norm_apply_cat_f16): the statistics came as partials of EACH source, G1 sub-groups for x and
+        // G2 for x2, all of the same width; group g of the concat = the mr adjacent sub-groups [mr g, mr g + mr) of the list
+        // [x's G1 | x2's G2] (it may straddle the two tables: 1280 + 640 channels in 32 groups = 3 sub-groups of 20 channels)
+        const int nsub = partial2 ? mr : 1;
+        for (int j = 0; j < nsub; ++j) {
+          const float* pp = partial + (long long)n * chunks * G * 2 + g * 2;
+          int nch = chunks, gstride = G * 2;
+          if (partial2) {
+            const int sg = mr * g + j;
+            const bool first = sg < G1;
+            nch = first ? chunks : chunks2;
+            gstride = (first ? G1 : G2) * 2;
+            pp = (first ? partial : partial2) + (long long)n * nch * gstride + (first ? sg : sg - G1) * 2;
           }
+          for (int k0 = sub; k0 < nch; k0 += 64) {
+            f2 v[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { S += (double)v[u][0]; SS += (double)v[u][1]; S += (double)v[u][2]; SS += (double)v[u][3]; }
+            for (int u = 0; u < 8; ++u) {
+              int k = k0 + 8 * u;
+              v[u] = k < nch ? *reinterpret_cast<const f2*>(pp + (long long)k * gstride) : (f2){0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { S += (double)v[u][0]; SS += (double)v[u][1]; }
+          }
         }
       }
 #pragma unroll
@@ -271,7 +272,7 @@ int tf_group_norm_f16(void* y, const void* x, const void* x2, const void* gamma,
                      (const half_t*)x2, HW, C1, C2, G, chunks, ppc, CV, RPB);
   TF_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
-                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0);
+                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
@@ -288,28 +289,39 @@ int tf_group_norm_apply_f16(void* y, const void* x, const void* gamma, const voi
   gn_geometry(HW, C, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
   int tl = (threads + 7) & ~7;
   hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)nullptr,
-                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0);
+                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+
+int tf_group_norm_apply_cat_f16(void* y, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial, int chunks,
+                                int groups1, const void* partial2, int chunks2, int groups2, int N, int HW, int C1, int C2, int G, float eps, int silu,
+                                tfStream_t s) {
+  TF_REQUIRE(y && x && x2 && partial && partial2, "tf_group_norm_apply_cat_f16: null tensor");
+  TF_REQUIRE((gamma == nullptr) == (beta == nullptr), "tf_group_norm_apply_cat_f16: gamma and beta must both be given or both NULL");
+  const int C = C1 + C2;
+  TF_REQUIRE(N >= 0 && HW >= 0 && G >= 1 && C1 > 0 && C2 > 0 && C % G == 0 && groups1 >= 1 && groups2 >= 1 && C1 % groups1 == 0 && C2 % groups2 == 0,
+             "tf_group_norm_apply_cat_f16: C1=%d C2=%d G=%d groups1=%d groups2=%d", C1, C2, G, groups1, groups2);
+  const int sub = C1 / groups1, cpg = C / G;
+  TF_REQUIRE(C2 / groups2 == sub && cpg % sub == 0 && cpg / sub <= 8,
+             "tf_group_norm_apply_cat_f16: the partials' sub-groups (%d and %d channels) do not tile the %d-channel groups of the concat", sub, C2 / groups2, cpg);
+  TF_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && C / 8 <= 1024 && G <= 1024 && N <= 65535, "tf_group_norm_apply_cat_f16: C1=%d C2=%d G=%d N=%d out of range", C1, C2, G, N);
+  TF_REQUIRE(chunks >= 1 && chunks <= 4096 && chunks2 >= 1 && chunks2 <= 4096, "tf_group_norm_apply_cat_f16: chunks=%d chunks2=%d", chunks, chunks2);
+  if (N == 0 || HW == 0) return TF_OK;
+  int CV, RPB, threads, sc, ppc, ablocks, appb;
+  gn_geometry(HW, C, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
+  int tl = (threads + 7) & ~7;
+  hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
+                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB,
+                     (const float*)partial2, chunks2, groups1, groups2, cpg / sub);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
 
 int tf_group_norm_apply2_f16(void* y, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial, int chunks,
                              const void* partial2, int chunks2, int N, int HW, int C1, int G, float eps, int silu, tfStream_t s) {
-  TF_REQUIRE(y && x && x2 && partial && partial2, "tf_group_norm_apply2_f16: null tensor");
-  TF_REQUIRE((gamma == nullptr) == (beta == nullptr), "tf_group_norm_apply2_f16: gamma and beta must both be given or both NULL");
-  int C = 2 * C1;
-  TF_REQUIRE(N >= 0 && HW >= 0 && G >= 2 && G % 2 == 0 && C1 > 0 && C1 % G == 0, "tf_group_norm_apply2_f16: C1=%d must be divisible by the even G=%d", C1, G);
-  TF_REQUIRE(C1 % 8 == 0 && C / 8 <= 1024 && G <= 1024 && N <= 65535, "tf_group_norm_apply2_f16: C1=%d G=%d N=%d out of range", C1, G, N);
-  TF_REQUIRE(chunks >= 1 && chunks <= 4096 && chunks2 >= 1 && chunks2 <= 4096, "tf_group_norm_apply2_f16: chunks=%d chunks2=%d", chunks, chunks2);
-  if (N == 0 || HW == 0) return TF_OK;
-  int CV, RPB, threads, sc, ppc, ablocks, appb;
-  gn_geometry(HW, C, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
-  int tl = (threads + 7) & ~7;
-  hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
-                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C1, G, eps, silu, chunks, appb, CV, RPB,
-                     (const float*)partial2, chunks2);
-  TF_LAUNCH_CHECK();
-  return TF_OK;
+  TF_REQUIRE(G >= 2 && G % 2 == 0, "tf_group_norm_apply2_f16: G=%d must be even", G);
+  return tf_group_norm_apply_cat_f16(y, x, x2, gamma, beta, partial, chunks, G, partial2, chunks2, G, N, HW, C1, C1, G, eps, silu, s);
 }
 
 int tf_layer_norm_f16(void* y, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s) {

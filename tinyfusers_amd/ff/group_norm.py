@@ -21,12 +21,16 @@ def _gn(x, num_groups, eps, gamma, beta, silu):
         hip.tf_group_norm_apply_f16(y.ptr, x.ptr, gamma.ptr if gamma is not None else None, beta.ptr if beta is not None else None,
                                     part.ptr, chunks, n, h * w, c1, num_groups, float(eps), 1 if silu else 0, _sh())
         return y
-    if config.concat_stats and x2 is not None and c1 == c2 and num_groups % 2 == 0 and x.gn is not None and x2.gn is not None \
-            and x.gn[2] == num_groups and x2.gn[2] == num_groups:
-        # equal-split concat: a group of the concat is two adjacent groups of one half -> merge the producers' partials
-        hip.tf_group_norm_apply2_f16(y.ptr, x.ptr, x2.ptr, gamma.ptr if gamma is not None else None, beta.ptr if beta is not None else None,
-                                     x.gn[0].ptr, x.gn[1], x2.gn[0].ptr, x2.gn[1], n, h * w, c1, num_groups, float(eps), 1 if silu else 0, _sh())
-        return y
+    if config.concat_stats and x2 is not None and x.gn is not None and x2.gn is not None:
+        # concat whose statistics came with its two sources: their partials' sub-groups (equal width) tile the concat's groups --
+        # 32 + 32 sub-groups for an equal split, 64 + 32 for the 2:1 splits of the UNet's output path
+        g1, g2 = x.gn[2], x2.gn[2]
+        cpg = (c1 + c2) // num_groups
+        if c1 % g1 == 0 and c2 % g2 == 0 and c1 // g1 == c2 // g2 and cpg % (c1 // g1) == 0 and cpg // (c1 // g1) <= 8:
+            hip.tf_group_norm_apply_cat_f16(y.ptr, x.ptr, x2.ptr, gamma.ptr if gamma is not None else None, beta.ptr if beta is not None else None,
+                                            x.gn[0].ptr, x.gn[1], g1, x2.gn[0].ptr, x2.gn[1], g2, n, h * w, c1, c2, num_groups, float(eps),
+                                            1 if silu else 0, _sh())
+            return y
     nb = hip.tf_group_norm_workspace(n, h * w, c1 + c2, num_groups)
     ws = workspace(nb)
     hip.tf_group_norm_f16(y.ptr, x.ptr, x2.ptr if x2 is not None else None, gamma.ptr if gamma is not None else None,

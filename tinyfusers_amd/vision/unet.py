@@ -211,8 +211,15 @@ class UNetModel:
                 last = bi == len(self.output_blocks) - 1 and j == len(b) - 1
                 nxt = b[j + 1] if j + 1 < len(b) else (self.out[0] if last else None)
                 cout = bb.conv.weight.shape[0] if isinstance(bb, Upsample) else (bb.out_layers[3].weight.shape[0] if isinstance(bb, ResBlock) else bb.proj_out.weight.shape[0])
-                want = config.concat_stats and nxt is None and bool(saved_inputs) and cout == saved_inputs[-1].shape[1]
-                x = run(x, bb, nxt, force_gn=32 if want else 0)
+                # the output enters the next concat: emit its statistics in sub-groups as wide as the 32 groups of the saved partner
+                # (32 sub-groups for an equal split, 64 for the 2:1 splits), so that the concat's GroupNorm is apply-only
+                fg = 0
+                if config.concat_stats and nxt is None and saved_inputs:
+                    c2 = saved_inputs[-1].shape[1]
+                    sub = c2 // 32
+                    if c2 % 32 == 0 and sub >= 4 and cout % sub == 0 and ((cout + c2) // 32) % sub == 0 and cout // sub <= 256:
+                        fg = cout // sub
+                x = run(x, bb, nxt, force_gn=fg)
         return self.out[2](self.out[0](x, silu=True))
 
 
