@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
-"""UNet denoising steps/sec, SD1.5 512x512 (64x64x4 latent), one image per GPU, CFG batch 2, fp16.
+"""UNet denoising steps/sec, SD1.5 512x512 (64x64x4 latent), one image per GPU, CFG batch 2.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W           # starts its N ranks itself (one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+``python bench.py --gpus N`` with N > 1 and no RANK in the environment is a LAUNCHER: it makes no GPU call, starts
+``python -m torch.distributed.run --nproc-per-node N bench.py ...`` as a child, relays rank 0's single JSON line and exits
+with the child's status.  Under torch.distributed.run, WORLD_SIZE must equal --gpus (anything else is an error, not a
+silent 1-GPU run).
 
 One process per GPU.  Rank 0 generates the synthetic weights and broadcasts the packed fp16 weight arena once
 over RCCL (torch.distributed "nccl"); there is NO per-step collective: every rank runs its own image's DDIM
@@ -11,12 +16,18 @@ trajectory (weak scaling, value = all images' steps / max-over-ranks time).
 A "step" = one StableDiffusion.__call__ of the reference (variants/sd.py:56-59): CFG duplicate, one UNet forward
 at batch 2, CFG combine + DDIM update, replayed as one HIP graph.  Inputs are resident in HBM before timing.
 Extra objects on the JSON line: "roofline" (the implicit-GEMM conv/linear kernel family, timed per launch with
-HIP events on its own stream in an instrumented eager pass) and "cpu_baseline" (the CPU oracle = the torch-CPU op
-path the reference's tests compare against, timed on this box's host cores; rank 0, N=1 only).
+HIP events on its own stream in an instrumented eager pass), "cpu_baseline" (the CPU oracle = the torch-CPU op
+path the reference's tests compare against, timed on this box's host cores; rank 0, N=1 only) and "e2e" (BASELINE config 3:
+CLIP text encoder x2 -> 50 graph-replayed steps -> VAE decode, img/s with the three segment times; N=1 only).
+
+``--dry-run`` rehearses the N>1 plumbing on CPU (gloo): arena broadcast + image shard + max-over-ranks, no kernels.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,25 +37,136 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_STEP = 1.6088e12          # algorithmic FLOPs of one step (conv 887.89 G + linear 466.49 G + SDPA 252.10 G + 2.28 G)
-PEAK_MFMA_TFLOPS = 2500.0          # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_MFMA_TFLOPS = {"fp16": 2500.0, "fp8": 5000.0}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+TRAFFIC_PROFILE = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the config-3 end-to-end leg (CLIP x2 -> 50 steps -> VAE decode)")
+    ap.add_argument("--e2e-images", type=int, default=3)
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of the HIP-graph replay")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--tune-cache", default="", help="file to load/save the GEMM autotuner's per-shape choices (optional)")
     ap.add_argument("--images", type=int, default=1, help="images per GPU (UNet batch = 2x); default 1 = BASELINE config 2")
     ap.add_argument("--latent", type=int, default=64, help="latent height = width; default 64 (512x512 images); 96 = 768x768 (config 5)")
-    return ap.parse_args()
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp8"], help="conv/linear operand type (fp8 = config 5: OCP e4m3 weights + activations, fp32 accumulate, fp16 residual stream)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank plumbing (gloo): no GPU, no kernels")
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: the parent of an N-rank run.  Never touches the GPU (no torch import, no HIP call).
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, text=True)
+    line = None
+    for ln in p.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln.strip()                       # rank 0's single result line
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if rc != 0:
+        sys.stderr.write(f"bench.py: a rank failed (torch.distributed.run exit status {rc})\n")
+        return rc
+    if line is None:
+        sys.stderr.write("bench.py: the ranks finished without a result line\n")
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+def csrc_hash():
+    """Hash of the kernel sources the loaded library was built from (profiles are stamped with it)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "tinyfusers_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def dry_run(args):
+    """World-size-N rehearsal on CPU (gloo): rank 0 fills the packed weight arena of the TINY UNet, ONE broadcast, every rank
+    checks the bytes, takes its image shard and seeds, and the timing is the max over ranks.  No kernels, no GPU."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch
+    import torch.distributed as dist
+    import oracle
+    from tinyfusers_amd.dist import broadcast_arena, max_over_ranks, pack_tensor, plan_arena, shard_range
+    from tinyfusers_amd.storage.synth import synth_normal, synth_tensor
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    shapes = oracle.unet_param_shapes(oracle.TINY)
+    offs, total = plan_arena(shapes)
+    arena = torch.zeros(total, dtype=torch.uint8)
+    t0 = time.time()
+    if rank == 0:
+        for k, s in shapes.items():
+            w = pack_tensor(synth_tensor(5, k, s))
+            arena[offs[k]:offs[k] + w.nbytes] = torch.from_numpy(w.view(np.uint8).reshape(-1))
+    t_gen = time.time() - t0
+    t1 = time.time()
+    broadcast_arena(arena, src=0)
+    t_bcast = time.time() - t1
+    k = next(iter(shapes))
+    got = arena[offs[k]:offs[k] + int(np.prod(shapes[k])) * 2].numpy().view(np.float16)
+    assert np.array_equal(got, pack_tensor(synth_tensor(5, k, shapes[k])).reshape(-1)), "arena differs after the broadcast"
+    lo, hi = shard_range(world * args.images, rank, world)
+    assert hi - lo == args.images
+    lat = synth_normal(1234 + rank, "sd.latent", (args.images, 4, 8, 8))
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))                      # stands in for the K replayed steps; the slowest rank sets the time
+    if world > 1:
+        dist.barrier()
+    wall = max_over_ranks(time.perf_counter() - t0)
+    checks = torch.tensor([float(arena.to(torch.int64).sum()), float(lat.reshape(-1)[0])], dtype=torch.float64)
+    allc = [torch.zeros_like(checks) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(allc, checks)
+    else:
+        allc = [checks]
+    if rank == 0:
+        assert all(float(c[0]) == float(allc[0][0]) for c in allc), "ranks hold different arenas"
+        assert len({float(c[1]) for c in allc}) == world, "ranks must draw distinct latents"
+        print(json.dumps({"metric": "unet_denoise_steps_per_sec", "value": round(world * args.images * args.steps / wall, 2), "unit": "steps/s",
+                          "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(wall * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "none", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "dry run: arena broadcast + image shard + max-over-ranks on CPU (gloo), no kernels",
+                                     "global_batch": world * args.images, "parallelism": f"dp{world}"},
+                          "weights": {"bytes": total, "synth_s": round(t_gen, 3), "bcast_s": round(t_bcast, 4)}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def build_weight_arena(unet, rank, world, device_index):
     """Pack every UNet tensor into ONE fp16 device arena (torch owns the memory: plumbing), filled on rank 0 and
     broadcast once over RCCL; every module leaf becomes a view into it."""
@@ -82,13 +204,27 @@ def build_weight_arena(unet, rank, world, device_index):
     return arena, off, t_gen, t_bcast
 
 
+def host_cores():
+    """Host cores this process may actually use: the affinity mask, cut down to the cgroup CPU quota where one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(steps):
     """The reference's CPU op path (F.conv2d / GroupNorm / F.layer_norm / F.linear / SDPA, fp32) = oracle.sd_step,
-    on a bounded sample: `steps` full denoising steps of the same workload after one warm-up."""
+    on a bounded sample: `steps` full denoising steps of the same workload after one warm-up; plus the two single ops of
+    BASELINE config 1 (tests/conv2d.py, tests/group_norm.py of the reference) at a bounded size."""
     import torch
+    import torch.nn.functional as F
     import oracle
     from tinyfusers_amd.storage.synth import synth_normal, synth_state_dict
-    cores = min(os.cpu_count() or 1, 16)
+    cores = host_cores()
     torch.set_num_threads(cores)
     W = {k: torch.from_numpy(v.astype(np.float32)) for k, v in synth_state_dict(oracle.unet_param_shapes(oracle.SD15), 0).items()}
     lat = synth_normal(1234, "sd.latent", (1, 4, 64, 64))
@@ -102,33 +238,108 @@ def cpu_baseline(steps):
         x = oracle.sd_step(unc, ctx, x, np.array([ts[i]], np.float32), al[i:i + 1], ap[i:i + 1], np.array([7.5]), W)
         times.append(time.time() - t0)
     sec = float(np.median(times[1:]))
+    # config 1: the reference's own single-op tests on CPU.  tests/conv2d.py:13-33: X (1,2,10000,10000) fp32, W (1,2,2,2), pad 0,
+    # stride 1 (bounded here to 4000 x 4000: same arithmetic per output, 16 % of the pixels); tests/group_norm.py:22-41:
+    # (2048, C, 2, 2) with 2 groups, C = 1600 (the largest of its parametrisation).
+    xc = torch.from_numpy(synth_normal(7, "cfg1.conv.x", (1, 2, 4000, 4000))); wc = torch.from_numpy(synth_normal(7, "cfg1.conv.w", (1, 2, 2, 2)))
+    F.conv2d(xc, wc)
+    t0 = time.time(); yc = F.conv2d(xc, wc); t_conv = time.time() - t0
+    xg = torch.from_numpy(synth_normal(7, "cfg1.gn.x", (2048, 1600, 2, 2)))
+    oracle.group_norm(xg, 2, 1e-5)
+    t0 = time.time(); oracle.group_norm(xg, 2, 1e-5); t_gn = time.time() - t0
     return {"value": 1.0 / sec, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} full SD1.5 denoising steps (CFG batch 2, 64x64 latent) after 1 warm-up, torch-CPU fp32 oracle, median {sec:.2f} s/step"}
+            "sample": f"{steps} full SD1.5 denoising steps (CFG batch 2, 64x64 latent) after 1 warm-up, torch-CPU fp32 oracle, median {sec:.2f} s/step",
+            "single_ops": {"conv2d_tests_conv2d_py": {"shape": "x(1,2,4000,4000) w(1,2,2,2) pad 0 stride 1 fp32 (16 % of the reference test's 10000^2 pixels)",
+                                                      "ms": round(t_conv * 1e3, 2), "gpixel_per_s": round(yc.numel() / t_conv / 1e9, 3)},
+                           "group_norm_tests_group_norm_py": {"shape": "x(2048,1600,2,2) 2 groups fp32", "ms": round(t_gn * 1e3, 2),
+                                                              "gb_per_s": round(2 * xg.numel() * 4 / t_gn / 1e9, 2)}}}
 
 
-def main():
-    args = parse()
+def e2e_leg(sd, n_images, seed):
+    """BASELINE config 3 (example/sd1.py:44-79 of the reference): both prompts through the CLIP text encoder, the full
+    50-step schedule as graph replays, VAE decode to a uint8 image.  Returns img/s and the three segment times (medians)."""
+    import tinyfusers_amd.storage.tensor as T
+    from tinyfusers_amd.storage.state import param_shapes, update_state
+    from tinyfusers_amd.storage.synth import synth_normal, synth_state_dict
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        for name, sub in (("first_stage_model", sd.first_stage_model), ("cond_stage_model", sd.cond_stage_model)):
+            update_state(sub, synth_state_dict(param_shapes(sub, name), 0), name)
+    rng = np.random.default_rng(seed)
+    prompt = np.full((1, 77), 49407, dtype=np.int64); prompt[0, 0] = 49406; prompt[0, 1:10] = rng.integers(0, 49406, 9)
+    empty = np.full((1, 77), 49407, dtype=np.int64); empty[0, 0] = 49406
+    text_model = sd.cond_stage_model.transformer.text_model
+    text_model(prompt)                                 # first call folds the LayerNorms / fuses q|k|v once
+    T.hip.tf_stream_sync(None)
+    timesteps = list(range(1, 1000, 20))
+    alphas = sd.alphas_cumprod[timesteps]
+    alphas_prev = np.concatenate((np.array([1.0]), alphas[:-1])).astype(np.float32)
+    latent = sd.latent_from_numpy(synth_normal(seed, "sd.latent", (1, 4, 64, 64)))
+    recs = []
+    for n in range(n_images + 1):                      # image 0 = compile + warm-up
+        t0 = time.perf_counter()
+        context = text_model(prompt)
+        unconditional_context = text_model(empty)
+        T.hip.tf_stream_sync(None)
+        t1 = time.perf_counter()
+        if n == 0:
+            sd.compile(unconditional_context, context, latent)
+        t2 = time.perf_counter()
+        if n > 0:
+            # same buffers as the captured graph: refresh the stacked context in place
+            T.hip.tf_memcpy_async(sd._ctx2.ptr, unconditional_context.ptr, context.nbytes, 3, sd._stream.handle)
+            T.hip.tf_memcpy_async(sd._ctx2.ptr + context.nbytes, context.ptr, context.nbytes, 3, sd._stream.handle)
+        sd.set_latent(synth_normal(seed + n, "sd.latent", (1, 4, 64, 64)))
+        for index, timestep in list(enumerate(timesteps))[::-1]:
+            sd.step(timestep, alphas[index], alphas_prev[index], 7.5)
+        sd.synchronize()
+        t3 = time.perf_counter()
+        assert np.isfinite(latent.numpy()).all(), f"e2e image {n}: non-finite latent"
+        t4 = time.perf_counter()
+        with T.use_stream(sd._stream):
+            img = sd.decode(latent)
+        t5 = time.perf_counter()
+        assert img.shape == (512, 512, 3) and img.dtype == np.uint8
+        recs.append((t1 - t0, t3 - t2, t5 - t4))
+    c, s, d = (float(np.median([r[i] for r in recs[1:]])) for i in range(3))
+    return {"metric": "sd15_end_to_end_images_per_sec", "value": round(1.0 / (c + s + d), 3), "unit": "img/s", "images_timed": n_images,
+            "clip_ms": round(c * 1e3, 2), "sampler_ms": round(s * 1e3, 2), "decode_ms": round(d * 1e3, 2), "steps": 50,
+            "workload": "CLIP text encoder x2 -> 50 DDIM steps (CFG, one HIP-graph replay each) -> VAE decode to 512x512x3 uint8, batch 1, fp16"}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    in_group = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # started by torch.distributed.run (or by our launcher through it)
+    if args.gpus > 1 and not in_group:
+        return launch_ranks(args, argv)           # parent: no GPU call before or after
+    if args.dry_run:
+        return dry_run(args)
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if in_group else 1
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if in_group else 0
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` or give torch.distributed.run the same N")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
-    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # launched by torch.distributed.run
+    use_dist = in_group and world > 1
     if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    assert world == args.gpus or not use_dist, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
 
     import tinyfusers_amd.storage.tensor as T
+    from tinyfusers_amd import config
     from tinyfusers_amd.native import hip, lib
     from tinyfusers_amd.storage.synth import synth_normal
     from tinyfusers_amd.variants.sd import StableDiffusion
     import ctypes
     T.ensure_init(local_rank)
+    config.set_dtype(args.dtype)
 
     sd = StableDiffusion()
     arena, arena_bytes, t_gen, t_bcast = build_weight_arena(sd.model.diffusion_model, rank, world, local_rank)
@@ -183,6 +394,7 @@ def main():
     final = lat.numpy()
     assert np.isfinite(final).all(), "non-finite latent after the timed steps"
 
+    peak = PEAK_MFMA_TFLOPS[args.dtype]
     roofline = None
     if not args.no_roofline and rank == 0:
         # dominant kernel family = k_igemm (conv2d + linear, 84 % of the step's FLOPs): per-launch HIP events
@@ -194,16 +406,21 @@ def main():
         hip.tf_prof_read(ctypes.byref(gms), ctypes.byref(gfl), ctypes.byref(gl))
         lib.tf_prof_enable(0)
         ach = gfl.value / (gms.value * 1e-3) / 1e12 if gms.value > 0 else 0.0
-        # HBM bytes per launch of this kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the
-        # gfx950 correction + WRITE_SIZE, separate runs of this same command; tools/pmc_summary.py): cannot be sampled live
-        traffic = None
+        # HBM bytes per launch of this kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950
+        # correction + WRITE_SIZE, separate runs of this same command; tools/pmc_summary.py): they cannot be sampled live, so the
+        # profile is stamped with the hash of the kernel sources it was taken on and is reported only while that still matches
+        traffic, tnote = None, f"no {TRAFFIC_PROFILE}"
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = round(pj["k_igemm"]["hbm_bytes_per_launch"])
+            pj = json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))
+            if pj.get("csrc_sha16") == csrc_hash() and (B, S, args.dtype) == (1, 64, "fp16"):
+                traffic = round(pj["k_igemm"]["hbm_bytes_per_launch"])
+                tnote = f"HBM bytes per launch ({TRAFFIC_PROFILE}, kernel sources {pj['csrc_sha16']})"
+            else:
+                tnote = f"{TRAFFIC_PROFILE} was taken on other kernel sources or another workload ({pj.get('csrc_sha16')} vs {csrc_hash()}): not reported"
         except Exception:
             pass
-        roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4),
-                    "traffic": traffic, "traffic_unit": "HBM bytes per launch (profiles/r01_pmc_traffic.json)",
+        roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": traffic, "traffic_unit": tnote,
                     "kernel": "k_igemm<BM,BN> (implicit-GEMM conv2d + linear)",
                     "launches_per_step": gl.value / n_inst, "avg_launch_us": round(gms.value * 1e3 / max(1, gl.value), 2),
                     "gemm_ms_per_step": round(gms.value / n_inst, 4), "gemm_flop_per_step": gfl.value / n_inst}
@@ -211,19 +428,26 @@ def main():
     if rank == 0:
         steps_per_s = world * B * args.steps / wall      # image-steps per second (one unit = one denoising step of one image)
         flop_unit = {64: FLOP_PER_STEP, 96: 4.30e12}.get(S)       # algorithmic FLOP per image-step
+        rccl_ranks = 1
+        if use_dist:
+            import torch.distributed as dist
+            rccl_ranks = dist.get_world_size()
+        dt = {"fp16": "f16", "fp8": "f8e4m3"}[args.dtype]
         out = {
-            "metric": "unet_denoise_steps_per_sec", "value": round(steps_per_s, 2), "unit": "steps/s", "n_gpus": world,
+            "metric": "unet_denoise_steps_per_sec", "value": round(steps_per_s, 2), "unit": "steps/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"SD1.5 UNet single denoise step (CFG batch 2 + DDIM update), {S}x{S}x4 latent, {B} image{'s' if B > 1 else ''} per GPU, fp16, 50-step DDIM schedule",
+            "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
+            "config": {"workload": f"SD1.5 UNet single denoise step (CFG batch 2 + DDIM update), {S}x{S}x4 latent, {B} image{'s' if B > 1 else ''} per GPU, {args.dtype} conv/linear, 50-step DDIM schedule",
                        "global_batch": world * B, "latent": [4, S, S], "parallelism": f"dp{world} (batch-sharded, RCCL weight broadcast only, no per-step collective)",
                        "launch": "eager" if args.eager else "hipGraph"},
             "device_ms_per_step": round(ms.value / args.steps, 4),
             "step_tflops": round(flop_unit * B * args.steps / (ms.value * 1e-3) / 1e12, 1) if flop_unit else None,
-            "step_mfma_frac": round(flop_unit * B * args.steps / (ms.value * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4) if flop_unit else None,
+            "step_mfma_frac": round(flop_unit * B * args.steps / (ms.value * 1e-3) / 1e12 / peak, 4) if flop_unit else None,
             "weights": {"bytes": arena_bytes, "synth_s": round(t_gen, 2), "bcast_s": round(t_bcast, 4)},
             "roofline": roofline,
         }
+        if world == 1 and (B, S, args.dtype) == (1, 64, "fp16") and not args.no_e2e:
+            out["e2e"] = e2e_leg(sd, args.e2e_images, seed)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
         print(json.dumps(out), flush=True)
@@ -231,7 +455,8 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

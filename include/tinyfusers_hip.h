@@ -81,6 +81,9 @@ int tf_stream_wait_event(tfStream_t s, tfEvent_t e);
 int tf_event_elapsed_ms(float* ms, tfEvent_t start, tfEvent_t stop);
 int tf_graph_begin_capture(tfStream_t s);
 int tf_graph_end_capture(tfStream_t s, tfGraph_t* out);
+/* after a failed capture (an op raised between begin and end): leave capture mode and discard what was recorded, so that the
+ * stream is usable again; no-op on a stream that is not capturing */
+int tf_graph_abort_capture(tfStream_t s);
 int tf_graph_launch(tfGraph_t g, tfStream_t s);
 int tf_graph_destroy(tfGraph_t g);
 
@@ -255,6 +258,10 @@ int tf_upsample2x_nhwc_f16(void* y, const void* x, int N, int H, int W, int C, t
 int tf_concat_channels_f16(void* y, const void* a, const void* b, long long rows, int Ca, int Cb, tfStream_t s);
 /* im2col for the 4-channel conv_in (K = R*S*C padded to Kpad): y (N*Ho*Wo, Kpad) */
 int tf_im2col_nhwc_f16(void* y, const void* x, int N, int H, int W, int C, int R, int S, int stride, int pad, int Kpad, tfStream_t s);
+/* the same for output rows [ho_begin, ho_end) of every image: y (N*(ho_end-ho_begin)*Wo, Kpad).  The 10000 x 10000 input of the
+ * reference's own conv test (tests/conv2d.py:13-33) runs as row bands, each band's patch matrix below the 2 GiB a buffer descriptor spans */
+int tf_im2col_rows_nhwc_f16(void* y, const void* x, int N, int H, int W, int C, int R, int S, int stride, int pad, int Kpad, int ho_begin, int ho_end,
+                            tfStream_t s);
 /* own-runtime kernels of the reference (native/cuda kernels via storage/device.py:79-233), fp32 */
 int tf_scale_f32(void* x, float scale, long long n, tfStream_t s);                        /* scale_tensor_func.cu:5-10 */
 int tf_add_bias_colmajor_f32(void* out, const void* bias, int BT, int OC, tfStream_t s);  /* add_bias_func.cu:1-9 */

@@ -68,6 +68,13 @@ def layer_norm(x, weight, bias, eps=1e-5):
     test pins torch.nn.functional.layer_norm as the truth (tests/layer_norm.py:38-41), so the
     standard last-dim LayerNorm is the semantics restated here."""
     x = as_t(x)
+    if weight is not None and as_t(weight).ndim > 1:
+        # tests/layer_norm.py:22-41: a (1, C, H, W) scale normalises over [C, H, W]; :44-71: a (1, 1, 1, W) scale over [W]
+        w, b = as_t(weight), as_t(bias)
+        shape = tuple(w.shape)
+        while len(shape) > 1 and shape[0] == 1:
+            shape = shape[1:]
+        return F.layer_norm(x, shape, w.reshape(shape), b.reshape(shape), float(eps))
     return F.layer_norm(x, (x.shape[-1],), as_t(weight), as_t(bias), float(eps))
 
 

@@ -1,0 +1,55 @@
+"""bench.py as the driver calls it: `python bench.py --gpus N` must start its N ranks itself (the parent makes no GPU call) and
+relay rank 0's single JSON line; a WORLD_SIZE that disagrees with --gpus is an error.  Rehearsed on CPU through --dry-run
+(gloo: arena broadcast + image shard + max-over-ranks, no kernels)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None, timeout=300):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=e, timeout=timeout)
+
+
+def test_bench_gpus2_launches_two_ranks_dry_run():
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["dry_run"] is True
+    assert out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 2
+    # max over ranks: rank 1 sleeps 20 ms, rank 0 10 ms
+    assert out["ms_per_step"] * 3 >= 19.0
+    assert out["weights"]["bytes"] > 0 and "bcast_s" in out["weights"]
+
+
+def test_bench_dry_run_single_rank():
+    r = _run(["--gpus", "1", "--steps", "2", "--warmup", "0", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1
+
+
+def test_bench_world_size_mismatch_is_an_error():
+    # started "by torch.distributed.run" with 2 ranks but told --gpus 4: must fail loudly, not print an n_gpus=1 line
+    r = _run(["--gpus", "4", "--dry-run"], env={"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "1"})
+    assert r.returncode != 0
+    assert "WORLD_SIZE=2" in (r.stderr + r.stdout)
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+
+
+def test_launcher_parent_never_imports_torch():
+    """The parent of an N-rank run may not touch the GPU: it must not even import torch before starting the ranks."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("def dry_run")]
+    assert "import torch" not in head
+    body = src[src.index("def main"):]
+    assert body.index("launch_ranks(args, argv)") < body.index("import torch")

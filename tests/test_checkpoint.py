@@ -118,3 +118,52 @@ def test_update_state_key_walk_matches_checkpoint_names():
     shapes.update({k: tuple(v) for k, v in oracle.vae_decoder_param_shapes().items()})
     shapes.update({k: tuple(v) for k, v in oracle.clip_param_shapes().items()})
     assert param_shapes(StableDiffusion(init=False)) == shapes
+
+
+def _malformed_zip(path, size, stride, offset=0, numel=4, payload=16):
+    """A torch-zip whose pickle describes a tensor view reaching outside its 4-element storage (what torch.save never writes)."""
+    import io
+    import pickle
+    import zipfile
+
+    class Ref:
+        pass
+
+    class Evil:
+        def __reduce__(self):
+            return (torch._utils._rebuild_tensor_v2, (Ref(), offset, tuple(size), tuple(stride), False, collections.OrderedDict()))
+
+    class P(pickle.Pickler):
+        def persistent_id(self, obj):
+            if isinstance(obj, Ref):
+                return ("storage", torch.FloatStorage, "0", "cpu", numel)
+            return None
+    buf = io.BytesIO()
+    P(buf, protocol=2).dump({"state_dict": {"w": Evil()}})
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_STORED) as zf:
+        zf.writestr("archive/data.pkl", buf.getvalue())
+        zf.writestr("archive/data/0", b"\x00" * payload)
+        zf.writestr("archive/version", "3\n")
+
+
+@pytest.mark.parametrize("size,stride,offset,numel,payload", [
+    ((65536,), (4096,), 0, 4, 16),        # ADVICE r1: the first touch of this view used to segfault
+    ((4,), (2,), 0, 4, 16),               # small stride: reads past the storage, inside the file
+    ((2, 2), (2, 1), 1, 4, 16),           # offset pushes the last element out
+    ((4,), (1,), -1, 4, 16),              # negative offset
+    ((4,), (-1,), 3, 4, 16),              # negative stride
+    ((4,), (1,), 0, 8, 16),               # the pickle claims more elements than the zip entry holds
+])
+def test_malformed_tensor_geometry_is_refused(tmp_path, size, stride, offset, numel, payload):
+    import pickle
+    p = str(tmp_path / "evil.ckpt")
+    _malformed_zip(p, size, stride, offset, numel, payload)
+    with pytest.raises(pickle.UnpicklingError):
+        load_checkpoint(p)
+
+
+def test_inbounds_strided_view_still_loads(tmp_path):
+    p = str(tmp_path / "ok.ckpt")
+    _malformed_zip(p, (2, 2), (1, 2), 0, 4, 16)       # a transposed 2x2 view of the 4-element storage: legal
+    w = load_checkpoint(p)["w"]
+    assert w.shape == (2, 2) and float(np.asarray(w).sum()) == 0.0

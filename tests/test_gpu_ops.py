@@ -589,3 +589,50 @@ def test_comm_single_rank_broadcast(tf):
             hip.tf_bcast(comm, d.ptr, d.nbytes, 1, None)        # root outside the world
     finally:
         hip.tf_comm_destroy(comm)
+
+
+# ---- BASELINE config 1: the reference's own single-op tests, at their own shapes ----------------------------------------------
+# tests/conv2d.py:13-33 (test_conv_fp16): X (1, 2, 10000, 10000), W (1, 2, 2, 2), pad 0, stride 1 vs F.conv2d, atol = rtol = 1e-2;
+# tests/conv2d.py:35-58 (test_conv_vs_tinygrad): the Conv2d module with an all-ones (1, 2, 2, 2) kernel on U[0, 1) input.
+# Cin = 2 runs through the small-C path (im2col bands + the MFMA GEMM); the full 10000 x 10000 case is the reference's exact size.
+@pytest.mark.parametrize("hw", [(33, 47), (1000, 1000), (10000, 10000)])
+def test_conv2d_reference_test_family(tf, hw):
+    from oracle import ops as O
+    from tinyfusers_amd.storage.synth import synth_normal
+    from tinyfusers_amd.vision.conv2d import Conv2d, conv_2d
+    h, w = hw
+    x = synth_normal(3, "cfg1.x", (1, 2, h, w)).astype(np.float16)
+    wt = rnd("cfg1.w", (1, 2, 2, 2))
+    got = conv_2d(dev(tf, x), dev(tf, wt), [0, 0], [1, 1], [1, 1]).numpy()
+    want = O.conv_2d(x.astype(np.float32), wt, (0, 0), (1, 1), (1, 1)).numpy()
+    close(got, want)
+    del got, want
+    # module form, ones kernel, non-negative input (tinygrad's Tensor.rand), bias present (the reference's Conv2d always has one)
+    xu = np.abs(x) % 1.0
+    m = Conv2d(2, 1, [2, 2], init=False)
+    m.weight = dev(tf, np.ones((1, 2, 2, 2), np.float32)); m.bias = dev(tf, np.zeros((1,), np.float32))
+    close(m(dev(tf, xu)).numpy(), O.conv_2d(xu.astype(np.float32), np.ones((1, 2, 2, 2), np.float32), (0, 0), (1, 1), (1, 1)).numpy())
+
+
+# tests/layer_norm.py:22-41 (test_layernorm): x (2048, C, 10, 10), scale / bias (1, C, 10, 10), normalised over [C, H, W], eps 1e-3
+@pytest.mark.parametrize("n,c", [(4, 16), (64, 768), (2048, 768), (2048, 1600)])
+def test_layer_norm_reference_slab(tf, n, c):
+    from oracle import ops as O
+    from tinyfusers_amd.ff.layer_norm import layer_norm
+    x = rnd("lnr.x", (n, c, 10, 10), 1.5) + 0.25
+    sc, bs = rnd("lnr.s", (1, c, 10, 10)), rnd("lnr.b", (1, c, 10, 10))
+    got = layer_norm(dev(tf, x), dev(tf, sc), dev(tf, bs), np.full((1, 1, 1, 1), 1e-3, np.float32)).numpy()
+    close(got, O.layer_norm(x, sc, bs, 1e-3).numpy())
+
+
+# tests/layer_norm.py:44-71 (test_layernorm_tinygrad): x (10, 32, 10, 10), LayerNorm over the last dim W = 10 (not a multiple of 8), eps 1e-3
+@pytest.mark.parametrize("shape", [(10, 32, 10, 10), (3, 5, 7, 13), (2, 77, 4100)])
+def test_layer_norm_last_dim_any_width(tf, shape):
+    from oracle import ops as O
+    from tinyfusers_amd.ff.layer_norm import LayerNorm
+    wd = shape[-1]
+    x = rnd("lnt.x", shape, 1.5) + 0.25
+    m = LayerNorm(wd, eps=1e-3)
+    m.weight = dev(tf, rnd("lnt.s", (wd,)), "row"); m.bias = dev(tf, rnd("lnt.b", (wd,)), "row")
+    got = m(dev(tf, x, "row")).numpy()
+    close(got, O.layer_norm(x, m.weight.numpy(), m.bias.numpy(), 1e-3).numpy())

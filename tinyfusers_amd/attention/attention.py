@@ -76,7 +76,7 @@ class CrossAttention:
         self._fused = None
 
     def _fused_weights(self, self_attn):
-        key = (self.to_q.weight.ptr, self.to_k.weight.ptr, self.to_v.weight.ptr, self_attn)
+        key = (self.to_q.weight.wkey, self.to_k.weight.wkey, self.to_v.weight.wkey, self_attn)
         if self._fused is None or self._fused[0] != key:
             ws = [self.to_q.weight, self.to_k.weight, self.to_v.weight] if self_attn else [self.to_k.weight, self.to_v.weight]
             self._fused = (key, _concat_rows(ws))
@@ -85,7 +85,7 @@ class CrossAttention:
     def _folded(self, ln, self_attn):
         """LayerNorm folded into the fused q|k|v weight (self-attention) or into to_q (cross-attention)."""
         w = self._fused_weights(True) if self_attn else self.to_q.weight
-        key = (w.ptr, ln.weight.ptr, ln.bias.ptr)
+        key = (w.wkey, ln.weight.wkey, ln.bias.wkey)
         if getattr(self, "_ln_fold", None) is None or self._ln_fold[0] != key:
             self._ln_fold = (key, fold_layer_norm(w, None, ln))
         return self._ln_fold[1]
@@ -168,7 +168,7 @@ class SpatialTransformer:
         the same FLOPs as the two it replaces, one launch and one activation round trip less.  Folded once per weight set
         on the host in fp32 (first eager call; cached by weight pointers)."""
         ff2, po = self.transformer_blocks[-1].ff.net[2], self.proj_out
-        key = (ff2.weight.ptr, ff2.bias.ptr, po.weight.ptr, po.bias.ptr)
+        key = (ff2.weight.wkey, ff2.bias.wkey, po.weight.wkey, po.bias.wkey)
         if self._fold is None or self._fold[0] != key:
             c = po.weight.shape[0]
             w2, b2 = ff2.weight.numpy(), ff2.bias.numpy()
@@ -214,7 +214,7 @@ class CLIPAttention:
 
     def _qkv(self, ln):
         ps = [self.q_proj, self.k_proj, self.v_proj]
-        key = tuple(p.weight.ptr for p in ps) + tuple(p.bias.ptr for p in ps) + ((ln.weight.ptr, ln.bias.ptr) if ln is not None else ())
+        key = tuple(p.weight.wkey for p in ps) + tuple(p.bias.wkey for p in ps) + ((ln.weight.wkey, ln.bias.wkey) if ln is not None else ())
         if self._fused is None or self._fused[0] != key:
             w = _concat_rows([p.weight for p in ps])
             b = _concat_rows([p.bias.view((p.bias.shape[0], 1), "row") for p in ps]).view((3 * self.embed_dim,), "row")

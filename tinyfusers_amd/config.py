@@ -39,3 +39,15 @@ fold_proj_out = _flag("TF_FOLD_PROJ_OUT", True)
 # GroupNorm over an equal-split channel concat (output path of the UNet) from the 32-group partials of the two producers
 # (pairs of groups merge) instead of a statistics pass over the concat.
 concat_stats = _flag("TF_CONCAT_STATS", True)
+
+# Operand type of the conv / linear GEMMs: "fp16" (default; BASELINE configs 2-4) or "fp8" (config 5: OCP e4m3 weights with
+# per-output-channel scales packed once, e4m3 activations with a per-tensor scale quantised by the loader side, fp32 accumulate,
+# fp16 residual stream).  Set through set_dtype() before the first forward.
+dtype = "fp16"
+
+
+def set_dtype(name):
+    global dtype
+    if name not in ("fp16", "fp8"):
+        raise ValueError(f"config.set_dtype: unknown dtype {name!r}")
+    dtype = name

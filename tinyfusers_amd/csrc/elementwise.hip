@@ -114,10 +114,11 @@ __global__ void __launch_bounds__(EW_BLOCK) k_concat(half_t* __restrict__ y, con
   }
 }
 
-// im2col for tiny channel counts (conv_in, C = 4): y (N*Ho*Wo, Kpad), k = (r*S + s)*C + c, zero padded
+// im2col for tiny channel counts (conv_in, C = 4): y (N*Hb*Wo, Kpad), k = (r*S + s)*C + c, zero padded; output rows
+// [ho0, ho0 + Hb) of every image (a row band: the 10000 x 10000 input of the reference's tests/conv2d.py runs in bands)
 __global__ void __launch_bounds__(EW_BLOCK) k_im2col(half_t* __restrict__ y, const half_t* __restrict__ x, int N, int H, int W, int C, int R, int S,
-                                                     int stride, int pad, int Ho, int Wo, int Kpad) {
-  long long total = (long long)N * Ho * Wo * Kpad;
+                                                     int stride, int pad, int ho0, int Hb, int Wo, int Kpad) {
+  long long total = (long long)N * Hb * Wo * Kpad;
   long long gs = (long long)gridDim.x * EW_BLOCK;
   int K = R * S * C;
   for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += gs) {
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(EW_BLOCK) k_im2col(half_t* __restrict__ y, con
       int c = k % C, t = k / C, s = t % S, r = t / S;
       int wo = (int)(m % Wo);
       long long q = m / Wo;
-      int ho = (int)(q % Ho), n = (int)(q / Ho);
+      int ho = ho0 + (int)(q % Hb), n = (int)(q / Hb);
       int hi = ho * stride - pad + r, wi = wo * stride - pad + s;
       if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = x[(((long long)n * H + hi) * W + wi) * C + c];
     }
@@ -222,8 +223,9 @@ __global__ void __launch_bounds__(EW_BLOCK) k_permute_f32(float* __restrict__ ou
   }
 }
 
-// numerically stable row softmax (N, C) fp32: one 256-thread block per row, row cached in registers when
-// C <= 256*16, single pass over HBM (the reference's softmax.cu:24-112 makes three passes).
+// numerically stable row softmax (N, C) fp32: one 256-thread block per row, three sweeps over the row (max, sum, normalise; the
+// second and third hit L2) like the reference's softmax.cu:24-112, with wave64 shuffles instead of its 32-lane ones.  Own-runtime
+// API only (Device.softmax): the UNet's attention never materialises scores (k_sdpa*).
 __global__ void __launch_bounds__(256) k_softmax_rows(float* __restrict__ out, const float* __restrict__ inp, int C) {
   __shared__ float red[8];
   const float* x = inp + (long long)blockIdx.x * C;
@@ -403,14 +405,21 @@ int tf_concat_channels_f16(void* y, const void* a, const void* b, long long rows
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
-int tf_im2col_nhwc_f16(void* y, const void* x, int N, int H, int W, int C, int R, int S, int stride, int pad, int Kpad, tfStream_t s) {
-  TF_REQUIRE(y && x && Kpad >= R * S * C && stride >= 1, "tf_im2col_nhwc_f16: Kpad=%d < R*S*C=%d", Kpad, R * S * C);
+int tf_im2col_rows_nhwc_f16(void* y, const void* x, int N, int H, int W, int C, int R, int S, int stride, int pad, int Kpad, int ho_begin, int ho_end,
+                            tfStream_t s) {
+  TF_REQUIRE(y && x && Kpad >= R * S * C && stride >= 1, "tf_im2col_rows_nhwc_f16: Kpad=%d < R*S*C=%d", Kpad, R * S * C);
   int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
-  long long total = (long long)N * Ho * Wo * Kpad;
-  if (total == 0) return TF_OK;
-  hipLaunchKernelGGL(k_im2col, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)y, (const half_t*)x, N, H, W, C, R, S, stride, pad, Ho, Wo, Kpad);
+  TF_REQUIRE(ho_begin >= 0 && ho_begin <= ho_end && ho_end <= Ho, "tf_im2col_rows_nhwc_f16: rows [%d, %d) outside [0, %d)", ho_begin, ho_end, Ho);
+  long long total = (long long)N * (ho_end - ho_begin) * Wo * Kpad;
+  if (total <= 0) return TF_OK;
+  hipLaunchKernelGGL(k_im2col, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)y, (const half_t*)x, N, H, W, C, R, S, stride, pad, ho_begin,
+                     ho_end - ho_begin, Wo, Kpad);
   TF_LAUNCH_CHECK();
   return TF_OK;
+}
+int tf_im2col_nhwc_f16(void* y, const void* x, int N, int H, int W, int C, int R, int S, int stride, int pad, int Kpad, tfStream_t s) {
+  TF_REQUIRE(stride >= 1, "tf_im2col_nhwc_f16: stride=%d", stride);
+  return tf_im2col_rows_nhwc_f16(y, x, N, H, W, C, R, S, stride, pad, Kpad, 0, (H + 2 * pad - R) / stride + 1, s);
 }
 int tf_cast_f32_to_f16(void* dst, const void* src, long long n, tfStream_t s) {
   TF_REQUIRE(dst && src && n >= 0, "tf_cast_f32_to_f16: bad arguments");

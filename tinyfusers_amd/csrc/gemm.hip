@@ -1514,6 +1514,11 @@ int tf_gemm_tune_load(const char* path) {
     n += fscanf(f, "%d %d %d %d %d", &bm, &bn, &sk, &wide, &order);
     if (n != 15) break;
     bool ok = (bm == 64 || bm == 128) && (bn == 64 || bn == 128 || bn == 160) && sk >= 1 && sk <= 32;
+    // rows the tuner itself never emits: GEGLU (act = 1) pairs 16-row value|gate blocks inside a wave tile (bn % 64 == 0), and
+    // neither GEGLU nor the LayerNorm fold (flag bit 8) can be split along K
+    const int act = k[8], ln = k[9] & 8;
+    if (act == 1 && (bn % 64) != 0) ok = false;
+    if ((act == 1 || ln) && sk > 1) ok = false;
     if (ok) g_tuned[k] = {{bm, bn, sk}, wide < 0 || wide > 3 ? 0 : wide, order != 0 ? 1 : 0};
   }
   fclose(f);

@@ -229,6 +229,61 @@ __global__ void __launch_bounds__(256) k_layer_norm(half_t* __restrict__ y, cons
   }
 }
 
+// ---- LayerNorm for any row length (C not a multiple of 8, or beyond what k_layer_norm keeps in registers): the reference's own
+// tests normalise 10-element rows and (C, 10, 10) = 76 800 ... 160 000-element slabs (tests/layer_norm.py:22-71).  WAVE = true: one
+// wave per row (4 rows per block); false: one 256-thread block per row.  Two-pass variance; the second and third sweeps hit L2.
+template <bool WAVE>
+__global__ void __launch_bounds__(256) k_layer_norm_any(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ gamma,
+                                                        const half_t* __restrict__ beta, int rows, long long C, float eps) {
+  __shared__ float red[8];
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const long long row = WAVE ? (long long)blockIdx.x * 4 + w : blockIdx.x;
+  const int t = WAVE ? l : threadIdx.x, nt = WAVE ? 64 : 256;
+  const bool live = row < rows;
+  const half_t* xr = x + (live ? row : 0) * C;
+  const bool vec = (C & 7) == 0;
+  auto block_sum = [&](float v, int slot) {
+    v = wave_sum(v);
+    if (WAVE) return v;
+    if (l == 0) red[slot * 4 + w] = v;
+    __syncthreads();
+    return red[slot * 4] + red[slot * 4 + 1] + red[slot * 4 + 2] + red[slot * 4 + 3];
+  };
+  float s = 0.f;
+  if (vec) {
+    for (long long i = (long long)t * 8; i < C; i += nt * 8) { h8 v = *reinterpret_cast<const h8*>(xr + i); for (int j = 0; j < 8; ++j) s += (float)v[j]; }
+  } else {
+    for (long long i = t; i < C; i += nt) s += (float)xr[i];
+  }
+  const float mean = block_sum(s, 0) / (float)C;
+  float q = 0.f;
+  if (vec) {
+    for (long long i = (long long)t * 8; i < C; i += nt * 8) { h8 v = *reinterpret_cast<const h8*>(xr + i); for (int j = 0; j < 8; ++j) { float d = (float)v[j] - mean; q += d * d; } }
+  } else {
+    for (long long i = t; i < C; i += nt) { float d = (float)xr[i] - mean; q += d * d; }
+  }
+  const float rstd = rsqrtf(block_sum(q, 1) / (float)C + eps);
+  if (!live) return;
+  half_t* yr = y + row * C;
+  if (vec) {
+    for (long long i = (long long)t * 8; i < C; i += nt * 8) {
+      h8 v = *reinterpret_cast<const h8*>(xr + i), o;
+      if (gamma) {
+        h8 gm = *reinterpret_cast<const h8*>(gamma + i), bt = *reinterpret_cast<const h8*>(beta + i);
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)(((float)v[j] - mean) * rstd * (float)gm[j] + (float)bt[j]);
+      } else {
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)(((float)v[j] - mean) * rstd);
+      }
+      *reinterpret_cast<h8*>(yr + i) = o;
+    }
+  } else {
+    for (long long i = t; i < C; i += nt) {
+      float f = ((float)xr[i] - mean) * rstd;
+      yr[i] = (half_t)(gamma ? f * (float)gamma[i] + (float)beta[i] : f);
+    }
+  }
+}
+
 static void gn_geometry(int HW, int C, int N, int* CV, int* RPB, int* threads, int* chunks, int* ppc, int* ablocks, int* appb) {
   *CV = C / 8;
   *RPB = *CV >= 256 ? 1 : 256 / *CV;
@@ -327,8 +382,17 @@ int tf_group_norm_apply2_f16(void* y, const void* x, const void* x2, const void*
 int tf_layer_norm_f16(void* y, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s) {
   TF_REQUIRE(y && x && rows >= 0, "tf_layer_norm_f16: null tensor");
   TF_REQUIRE((gamma == nullptr) == (beta == nullptr), "tf_layer_norm_f16: gamma and beta must both be given or both NULL");
-  TF_REQUIRE(C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXV, "tf_layer_norm_f16: C=%d must be a multiple of 8 and <= %d", C, 64 * 8 * LN_MAXV);
+  TF_REQUIRE(C > 0, "tf_layer_norm_f16: C=%d", C);
   if (rows == 0) return TF_OK;
+  if (C % 8 != 0 || C > 64 * 8 * LN_MAXV) {
+    // any row length: a wave per row while the row is short, a block per row beyond
+    if (C <= 4096) hipLaunchKernelGGL(k_layer_norm_any<true>, dim3(ceil_div(rows, 4)), dim3(256), 0, tf_hs(s), (half_t*)y, (const half_t*)x,
+                                      (const half_t*)gamma, (const half_t*)beta, rows, (long long)C, eps);
+    else hipLaunchKernelGGL(k_layer_norm_any<false>, dim3(rows), dim3(256), 0, tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)gamma,
+                            (const half_t*)beta, rows, (long long)C, eps);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+  }
   int cv = C / 8;
 #define LN_LAUNCH(LPR_)                                                                                                            \
   hipLaunchKernelGGL(k_layer_norm<LPR_>, dim3(ceil_div(rows, 4 * (64 / LPR_))), dim3(256), 0, tf_hs(s), (half_t*)y, (const half_t*)x, \

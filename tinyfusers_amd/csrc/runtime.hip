@@ -148,6 +148,19 @@ int tf_graph_end_capture(tfStream_t s, tfGraph_t* out) {
   *out = g;
   return TF_OK;
 }
+int tf_graph_abort_capture(tfStream_t s) {
+  // leave capture mode after a failed capture: whatever was recorded is discarded; a stream that is not capturing is left alone
+  TF_REQUIRE(s, "tf_graph_abort_capture: needs the captured stream");
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s->s, &cs);
+  if (cs == hipStreamCaptureStatusNone) return TF_OK;
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(s->s, &g);      // an invalidated capture returns an error AND leaves capture mode
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+  (void)e;
+  return TF_OK;
+}
 int tf_graph_launch(tfGraph_t g, tfStream_t s) { TF_REQUIRE(g, "null graph"); TF_HIP(hipGraphLaunch(g->x, tf_hs(s))); return TF_OK; }
 int tf_graph_destroy(tfGraph_t g) {
   if (!g) return TF_OK;

@@ -30,13 +30,13 @@ class GEGLU:
         self._packed = None
 
     def _pack(self):
-        key = (self.proj.weight.ptr, self.proj.bias.ptr)
+        key = (self.proj.weight.wkey, self.proj.bias.wkey)
         if self._packed is None or self._packed[0] != key:
             self._packed = (key,) + pack_geglu(self.proj.weight, self.proj.bias)
         return self._packed[1], self._packed[2]
 
     def _pack_ln(self, ln):
-        key = (self.proj.weight.ptr, self.proj.bias.ptr, ln.weight.ptr, ln.bias.ptr)
+        key = (self.proj.weight.wkey, self.proj.bias.wkey, ln.weight.wkey, ln.bias.wkey)
         if getattr(self, "_packed_ln", None) is None or self._packed_ln[0] != key:
             wf, bf, cs = fold_layer_norm(self.proj.weight, self.proj.bias, ln)       # fold first ...
             wp, bp = pack_geglu(wf, bf)                                            # ... then interleave value | gate blocks
@@ -82,7 +82,7 @@ class CLIPMLP:
         self.fc2 = Linear(3072, 768, init=init)
 
     def _folded(self, ln):
-        key = (self.fc1.weight.ptr, self.fc1.bias.ptr, ln.weight.ptr, ln.bias.ptr)
+        key = (self.fc1.weight.wkey, self.fc1.bias.wkey, ln.weight.wkey, ln.bias.wkey)
         if getattr(self, "_ln_fold", None) is None or self._ln_fold[0] != key:
             self._ln_fold = (key, fold_layer_norm(self.fc1.weight, self.fc1.bias, ln))
         return self._ln_fold[1]

@@ -249,7 +249,8 @@ _NP = {"f16": np.float16, "f32": np.float32}
 
 class DeviceArray:
     """(ptr, logical shape, dtype, layout) handle.  layout: 'nhwc' (4-D, logical NCHW) or 'row'."""
-    __slots__ = ("ptr", "shape", "dtype", "layout", "_base", "_fin", "gn", "__weakref__")
+    __slots__ = ("ptr", "shape", "dtype", "layout", "_base", "_fin", "gn", "_uid", "_version", "__weakref__")
+    _next_uid = [0]
 
     def __init__(self, ptr, shape, dtype=np.float16, layout=None, base=None):
         self.ptr = int(ptr)
@@ -259,6 +260,14 @@ class DeviceArray:
         self._base = base
         self._fin = None
         self.gn = None       # (partials, chunks, groups): GroupNorm statistics emitted by the conv that produced this array
+        DeviceArray._next_uid[0] += 1
+        self._uid, self._version = DeviceArray._next_uid[0], 0
+
+    @property
+    def wkey(self):
+        """Identity of this array's CONTENTS for derived-weight caches (folded / packed / concatenated weights): unique per handle
+        (a recycled device pointer under a new handle is a different key) and bumped by every in-place upload."""
+        return (self._uid, self._version)
 
     # -- construction
     @staticmethod
@@ -285,7 +294,12 @@ class DeviceArray:
         if self.layout == "nhwc":
             host = host.transpose(0, 2, 3, 1)
         host = np.ascontiguousarray(host)
+        if _sh():
+            # the copy runs on the NULL stream and the library's streams are non-blocking: kernels already queued on the current
+            # stream may still be reading the block this array was just handed by the pool -- drain it first
+            hip.tf_stream_sync(_sh())
         hip.tf_memcpy(self.ptr, host.ctypes.data, host.nbytes, H2D)
+        self._version += 1
         return self
 
     @staticmethod

@@ -90,7 +90,19 @@ class _ZipData:
 def _make_unpickler(data: _ZipData):
     def rebuild_tensor_v2(storage, storage_offset, size, stride, requires_grad=False, backward_hooks=None, metadata=None):
         flat, is_bf16 = data.array(storage)
-        size, stride = tuple(size), tuple(stride)
+        size, stride = tuple(int(v) for v in size), tuple(int(v) for v in stride)
+        storage_offset = int(storage_offset)
+        # the view must stay inside the storage's bytes as they exist in the FILE: offset, sizes and strides come from the pickle
+        # (untrusted) and go to as_strided, which checks nothing.  The reference's np.reshape would have raised (storage/unpicker.py:38).
+        if flat.size < storage.numel:
+            raise pickle.UnpicklingError(f"storage {storage.key}: the zip entry holds {flat.size} elements, the pickle claims {storage.numel}")
+        if len(size) != len(stride) or storage_offset < 0 or any(v < 0 for v in size) or any(v < 0 for v in stride):
+            raise pickle.UnpicklingError(f"storage {storage.key}: bad tensor geometry offset={storage_offset} size={size} stride={stride}")
+        if all(v > 0 for v in size):
+            last = storage_offset + sum((n - 1) * st for n, st in zip(size, stride))
+            if last >= flat.size:
+                raise pickle.UnpicklingError(f"storage {storage.key}: tensor view (offset {storage_offset}, size {size}, stride {stride}) "
+                                             f"reaches element {last} of a {flat.size}-element storage")
         if len(size) == 0:
             t = flat[storage_offset: storage_offset + 1].reshape(())
         else:

@@ -5,7 +5,7 @@ returns x_{t-1}.  Differences, all MI355X-first:
   * no host round trip / device syncs per step (variants/sd.py:34-41); CFG duplicate, CFG combine and the DDIM
     update are two tiny kernels; the latent state stays fp32 NCHW on the device;
   * batch generalised from the reference's hard-coded 1 (D8) to [uncond x B ; cond x B];
-  * ``compile()`` captures the whole step (≈450 launches) into one HIP graph replayed per step.
+  * ``compile()`` captures the whole step (one launch per fused op) into one HIP graph replayed per step.
 Beyond the UNet denoising path the next rows are built too: first_stage_model (VAE decode side, 8(f1))
 and cond_stage_model.transformer.text_model (CLIP text encoder, 8(f2)), under the reference's attribute names so that
 update_state walks the same LDM checkpoint keys.
@@ -140,14 +140,21 @@ class StableDiffusion:
                 pool().disown(self._graph_blocks)
                 self._graph, self._graph_blocks = None, None
             pool().begin_capture()
+            g, ok = ctypes.c_void_p(), False
             try:
                 hip.tf_graph_begin_capture(self._stream.handle)
                 self._eager_step(sp)
-                g = ctypes.c_void_p()
                 hip.tf_graph_end_capture(self._stream.handle, ctypes.byref(g))
+                ok = True
             finally:
-                self._graph_blocks = pool().end_capture()    # every block the captured step touches now belongs to the graph
-            self._graph = g
+                blocks = pool().end_capture()    # every block the captured step touches now belongs to the graph
+                if not ok:
+                    # an op raised inside the capture (pool frozen, untuned shape, ...): leave capture mode so that the stream
+                    # stays usable, and give the blocks back -- there is no graph to own them
+                    hip.tf_graph_abort_capture(self._stream.handle)
+                    self._keep = None
+                    pool().disown(blocks)
+            self._graph, self._graph_blocks = g, blocks
         return self
 
     def _eager_step(self, sp):

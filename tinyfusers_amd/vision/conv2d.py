@@ -13,7 +13,7 @@ from ..storage.tensor import DeviceArray, _sh, asarray
 from ..ff.linear import workspace, linear_f16
 
 
-def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, upsample=False, gn=0, extra=None):
+def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, upsample=False, gn=0, extra=None, out=None):
     x2 = None
     if isinstance(x, (tuple, list)):
         x, x2 = x
@@ -35,7 +35,8 @@ def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, up
     up = 1 if upsample else 0
     ho = ((h << up) + 2 * padding[0] - r) // stride[0] + 1
     wo = ((wd << up) + 2 * padding[1] - s) // stride[1] + 1
-    y = DeviceArray.empty((n, k, ho, wo), np.float16, "nhwc")
+    y = out if out is not None else DeviceArray.empty((n, k, ho, wo), np.float16, "nhwc")
+    assert y.shape == (n, k, ho, wo) and y.layout == "nhwc"
     nb = hip.tf_conv2d_fused_workspace(n, h, wd, c1, c2, k, r, s, stride[0], padding[0], up, c3, c4)
     ws = workspace(nb)
     bnc_stride = 0
@@ -59,6 +60,9 @@ def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, up
     return y
 
 
+_BAND_BYTES = 1 << 30      # patch-matrix bytes per launch of the small-C path
+
+
 def _conv_small_c(x, w, bias, padding, stride, cache, gn=0):
     """Cin % 8 != 0 (the 4-channel conv_in): im2col to K padded to 64, then the same GEMM kernel -- as a 1x1 convolution over the
     (n, ho, wo, kpad) patch image, so that the GroupNorm statistics of the output can ride along (gn) like for any other conv."""
@@ -68,14 +72,30 @@ def _conv_small_c(x, w, bias, padding, stride, cache, gn=0):
     kpad = (kk + 63) // 64 * 64
     ho = (h + 2 * padding[0] - r) // stride[0] + 1
     wo = (wd + 2 * padding[1] - s) // stride[1] + 1
-    key = (w.ptr, kpad)
+    key = (w.wkey, kpad)
     if cache.get("key") != key:
         wp = DeviceArray.zeros((k, kpad), np.float16, "row")
         hip.tf_memcpy_2d_async(wp.ptr, kpad * 2, w.ptr, kk * 2, kk * 2, k, _sh())
         cache["key"], cache["w"] = key, wp
-    col = DeviceArray.empty((n * ho * wo, kpad), np.float16, "row")
-    hip.tf_im2col_nhwc_f16(col.ptr, x.ptr, n, h, wd, c, r, s, stride[0], padding[0], kpad, _sh())
-    return _conv(col.view((n, kpad, ho, wo), "nhwc"), cache["w"].view((k, kpad, 1, 1), "nhwc"), bias, [0, 0], [1, 1], [1, 1], gn=gn)
+    if n * ho * wo * kpad * 2 <= _BAND_BYTES:
+        col = DeviceArray.empty((n * ho * wo, kpad), np.float16, "row")
+        hip.tf_im2col_nhwc_f16(col.ptr, x.ptr, n, h, wd, c, r, s, stride[0], padding[0], kpad, _sh())
+        return _conv(col.view((n, kpad, ho, wo), "nhwc"), cache["w"].view((k, kpad, 1, 1), "nhwc"), bias, [0, 0], [1, 1], [1, 1], gn=gn)
+    # large images (the reference's own conv test is 10000 x 10000, tests/conv2d.py:13-33): bands of output rows, image by image,
+    # each band's patch matrix and GEMM operands far below the 2 GiB one buffer descriptor spans
+    assert gn == 0, "banded small-C conv: no GroupNorm statistics"
+    y = DeviceArray.empty((n, k, ho, wo), np.float16, "nhwc")
+    rows = max(1, _BAND_BYTES // (wo * kpad * 2))
+    wv = cache["w"].view((k, kpad, 1, 1), "nhwc")
+    for img in range(n):
+        xi = x.view((1, c, h, wd), "nhwc", img * h * wd * c)
+        for o0 in range(0, ho, rows):
+            o1 = min(ho, o0 + rows)
+            col = DeviceArray.empty(((o1 - o0) * wo, kpad), np.float16, "row")
+            hip.tf_im2col_rows_nhwc_f16(col.ptr, xi.ptr, 1, h, wd, c, r, s, stride[0], padding[0], kpad, o0, o1, _sh())
+            _conv(col.view((1, kpad, o1 - o0, wo), "nhwc"), wv, bias, [0, 0], [1, 1], [1, 1],
+                  out=y.view((1, k, o1 - o0, wo), "nhwc", (img * ho + o0) * wo * k))
+    return y
 
 
 def conv_2d(X_gpu, W_gpu, padding, stride, dilation):
@@ -103,7 +123,7 @@ class Conv2d:
     def fold_1x1(self, proj):
         """(w, bias) of this conv with the 1x1 conv ``proj`` folded in as extra K columns (see __call__'s ``extra``): packed
         once on the device, rebuilt when either module's weights are replaced."""
-        key = (self.weight.ptr, self.bias.ptr, proj.weight.ptr, proj.bias.ptr)
+        key = (self.weight.wkey, self.bias.wkey, proj.weight.wkey, proj.bias.wkey)
         if self._cache.get("fold_key") != key:
             k, c, r, s = self.weight.shape
             kc, ce = r * s * c, proj.weight.shape[1]

@@ -136,7 +136,8 @@ class UNetModel:
 
     def _prepare(self):
         res, sts = self._all(ResBlock), self._all(SpatialTransformer)
-        key = tuple(r.emb_layers[1].weight.ptr for r in res) + tuple(s.transformer_blocks[0].attn2.to_k.weight.ptr for s in sts)
+        key = tuple(r.emb_layers[1].weight.wkey for r in res) + tuple(r.emb_layers[1].bias.wkey for r in res) \
+            + tuple(w.wkey for s in sts for w in (s.transformer_blocks[0].attn2.to_k.weight, s.transformer_blocks[0].attn2.to_v.weight))
         if self._batched is not None and self._batched["key"] == key:
             return self._batched
         emb_w = _concat_rows([r.emb_layers[1].weight for r in res])

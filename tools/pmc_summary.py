@@ -3,7 +3,7 @@
 Units/corrections per MI355X_MICROARCH.md (HBM section): counters are in KiB-granular units of 1024 B ... the
 FETCH_SIZE of a wide coalesced stream reads exactly half of the real bytes on gfx950 -> doubled.
 usage: pmc_summary.py <fetch_dir> <write_dir> [out.json]"""
-import csv, glob, json, sys
+import csv, glob, hashlib, json, os, sys
 
 def load(d, counter):
     f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
@@ -23,6 +23,13 @@ for fam in sorted(ft):
     write_b = wt.get(fam, 0.0) * 1024
     out[fam] = {"launches": fn[fam], "fetch_bytes_per_launch": fetch_b / fn[fam], "write_bytes_per_launch": write_b / max(1, wn.get(fam, 1)),
                 "hbm_bytes_per_launch": fetch_b / fn[fam] + write_b / max(1, wn.get(fam, 1))}
+# stamp: hash of the kernel sources this profile was taken on (bench.py reports `traffic` only while it still matches)
+_d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tinyfusers_amd", "csrc")
+_h = hashlib.sha256()
+for _f in sorted(os.listdir(_d)):
+    if _f.endswith((".hip", ".h")):
+        _h.update(_f.encode()); _h.update(open(os.path.join(_d, _f), "rb").read())
+out["csrc_sha16"] = _h.hexdigest()[:16]
 print(json.dumps(out, indent=1))
 if len(sys.argv) > 3:
     json.dump(out, open(sys.argv[3], "w"), indent=1)
