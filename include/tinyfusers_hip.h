@@ -164,6 +164,30 @@ int tf_conv2d_fused_f16(void* y, const void* x, const void* x2, const void* w, c
                         int S, int stride, int pad, int upsample, void* workspace, size_t workspace_bytes, const void* x3,
                         const void* x4, int C3, int C4, void* gn_partial, size_t gn_partial_bytes, int gn_groups,
                         int* gn_chunks, tfStream_t s);
+/* tf_conv2d_fused_f16 that also APPLIES the GroupNorm (+ SiLU) reading its output (conv -> GroupNorm -> SiLU of vision/resnet.py:17-22,
+ * :13-15 of the next block, attention/attention.py:66): when the shape runs split-K, the reduce kernel owns whole (image, group) slabs
+ * (k_splitk_reduce_gn_apply), finishes the statistics and writes z = silu?(GroupNorm(y) * gamma + beta) next to y -- the
+ * tf_group_norm_apply_f16 launch disappears.  *z_written = 1 when z was produced; 0 (shape ran unsplit, or groups the reduce cannot
+ * hold): the caller runs tf_group_norm_apply_f16 with the statistics as before.  gn_groups must be the GroupNorm's group count. */
+int tf_conv2d_fused_norm_f16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
+                             const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
+                             void* workspace, size_t workspace_bytes, const void* x3, const void* x4, int C3, int C4, void* gn_partial,
+                             size_t gn_partial_bytes, int gn_groups, int* gn_chunks, void* z, const void* z_gamma, const void* z_beta, float z_eps,
+                             int z_silu, int* z_written, tfStream_t s);
+/* tf_conv2d_fused_f16 with the GroupNorm (+ SiLU) of its INPUT applied inside the launch: GroupNorm -> SiLU -> Conv2d of
+ * vision/resnet.py:13-17, :22-27 and GroupNorm -> 1x1 conv of attention/attention.py:66-68 as ONE kernel.  The statistics of x (and
+ * x2) arrive as the partials their producing convs emitted (gn_partial of tf_conv2d_fused_f16: in_partial / in_chunks / in_groups1
+ * for x, in_partial2 / in_chunks2 / in_groups2 for x2 or NULL; sub-group contract of tf_group_norm_apply_cat_f16); in_groups is the
+ * GroupNorm's group count over C1 + C2, in_gamma / in_beta its affine (or both NULL).  The extra 1x1 sources x3 / x4 stay raw.
+ * Ask tf_conv2d_gn_supported first (3x3 / stride 1 / pad 1 and 1x1 convolutions with every channel count a multiple of 64, image
+ * sizes the tile grid divides); TF_E_UNSUPPORTED otherwise, and the caller runs tf_group_norm_apply_f16 + the plain conv. */
+int tf_conv2d_gn_supported(int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample, int C3, int C4, int in_groups);
+int tf_conv2d_gn_f16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
+                     const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
+                     void* workspace, size_t workspace_bytes, const void* x3, const void* x4, int C3, int C4, void* gn_partial,
+                     size_t gn_partial_bytes, int gn_groups, int* gn_chunks, const void* in_gamma, const void* in_beta, const void* in_partial,
+                     int in_chunks, int in_groups1, const void* in_partial2, int in_chunks2, int in_groups2, int in_groups, float in_eps, int in_silu,
+                     tfStream_t s);
 size_t tf_conv2d_fused_workspace(int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
                                  int C3, int C4);
 size_t tf_conv2d_gn_partial_bytes(int N, int groups);
@@ -210,6 +234,12 @@ int tf_sdpa_f16(void* o, const void* q, const void* k, const void* v, int B, int
                 int causal, tfStream_t s);
 /* row softmax over (N, C) fp32 -- Device.softmax (storage/device.py:129-157; softmax_func.cu:22-113) */
 int tf_softmax_rows_f32(void* out, const void* inp, int N, int C, tfStream_t s);
+/* softmax step of the UNFUSED attention (attention/sdpa.py:63-75 as the reference runs it: scale * matmul, + mask (:67-68: bool ->
+ * -inf where false, anything else additive), softmax kernel, matmul).  Serves what tf_sdpa_f16 does not: arbitrary masks and head sizes
+ * beyond 160 (AttnBlock's single head of 512, attention/attention.py:10-24).  out[r, c] = softmax_c(scale * inp[r, c] + mask[r % mask_rows, c]);
+ * rows are ldc apart (ldc >= C; out's pad columns are zero-filled); mask_f32: (mask_rows, C) fp32 additive or NULL. */
+int tf_softmax_mask_rows_f16(void* out, const void* inp, const void* mask_f32, long long rows, int C, int ldc, float scale, long long mask_rows,
+                             tfStream_t s);
 
 /* ---- normalisation ---------------------------------------------------------------------------
  * group_norm + GroupNorm affine (+ the SiLU that always follows it in ResBlock / UNet.out)

@@ -51,19 +51,26 @@ def resnet_block(x, W, p):
     return x + h
 
 
-def attn_block(x, W, p):
+def attn_block(x, W, p, head_merge="reference_exact"):
     """attention/attention.py:19-24 -- AttnBlock.__call__.  q/k/v stay NCHW and go straight into
-    scaled_dot_product_attention, which therefore reads them as (B, NH, T, HS) = (b, c, h, w) (reference-exact)."""
+    scaled_dot_product_attention, which therefore reads them as (B, NH, T, HS) = (b, c, h, w) (reference-exact).
+    head_merge='intended' is the LDM form the comment at :18 refers to ("copied from AttnBlock in ldm repo"): ONE head of size c
+    attending over the h*w pixels (what real SD weights need)."""
     h_ = ops.group_norm_affine(x, 32, W[p + ".norm.weight"], W[p + ".norm.bias"])
     q, k, v = [ops.conv2d_bias(h_, W[f"{p}.{n}.weight"], W[f"{p}.{n}.bias"]) for n in ("q", "k", "v")]
-    h_tf = ops.scaled_dot_product_attention(q, k, v)
+    if head_merge == "intended":
+        b, c, h, w = q.shape
+        tok = lambda t: t.reshape(b, c, h * w).permute(0, 2, 1).reshape(b, 1, h * w, c)
+        h_tf = ops.scaled_dot_product_attention(tok(q), tok(k), tok(v)).reshape(b, h * w, c).permute(0, 2, 1).reshape(b, c, h, w)
+    else:
+        h_tf = ops.scaled_dot_product_attention(q, k, v)
     return x + ops.conv2d_bias(h_tf, W[p + ".proj_out.weight"], W[p + ".proj_out.bias"])
 
 
-def vae_decoder(x, W, d="first_stage_model.decoder"):
+def vae_decoder(x, W, d="first_stage_model.decoder", head_merge="reference_exact"):
     """vae/decoder.py:22-34 -- Decoder.__call__."""
     x = ops.conv2d_bias(x, W[d + ".conv_in.weight"], W[d + ".conv_in.bias"], (1, 1))
-    x = resnet_block(x, W, d + ".mid.block_1"); x = attn_block(x, W, d + ".mid.attn_1"); x = resnet_block(x, W, d + ".mid.block_2")
+    x = resnet_block(x, W, d + ".mid.block_1"); x = attn_block(x, W, d + ".mid.attn_1", head_merge); x = resnet_block(x, W, d + ".mid.block_2")
     for i in reversed(range(4)):
         for j in range(3):
             x = resnet_block(x, W, f"{d}.up.{i}.block.{j}")
@@ -73,11 +80,11 @@ def vae_decoder(x, W, d="first_stage_model.decoder"):
     return ops.conv2d_bias(x, W[d + ".conv_out.weight"], W[d + ".conv_out.bias"], (1, 1))
 
 
-def sd_decode(latent, W, prefix="first_stage_model."):
+def sd_decode(latent, W, prefix="first_stage_model.", head_merge="reference_exact"):
     """variants/sd.py:48-54 -- decode: returns (float image in [-..], uint8 HWC image)."""
     W = {k: ops.as_t(v) for k, v in W.items()}
     x = ops.conv2d_bias(1 / 0.18215 * ops.as_t(latent), W[prefix + "post_quant_conv.weight"], W[prefix + "post_quant_conv.bias"])
-    x = vae_decoder(x, W, prefix + "decoder")
+    x = vae_decoder(x, W, prefix + "decoder", head_merge)
     img = (x + 1.0) / 2.0
     h, w = img.shape[2], img.shape[3]
     u8 = (torch.clip(img.reshape(3, h, w).permute(1, 2, 0), 0, 1) * 255).numpy().astype(np.uint8)

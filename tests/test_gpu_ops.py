@@ -636,3 +636,171 @@ def test_layer_norm_last_dim_any_width(tf, shape):
     m.weight = dev(tf, rnd("lnt.s", (wd,)), "row"); m.bias = dev(tf, rnd("lnt.b", (wd,)), "row")
     got = m(dev(tf, x, "row")).numpy()
     close(got, O.layer_norm(x, m.weight.numpy(), m.bias.numpy(), 1e-3).numpy())
+
+
+# ---- the mask forms of attention/sdpa.py:67-68 (boolean: attend where True; anything else: additive) and head sizes beyond the
+# flash kernel's, through the unfused matmul / softmax / matmul path
+@pytest.mark.parametrize("b,nh,tq,tk,hs,kind", [(2, 3, 40, 77, 40, "bool"), (2, 3, 40, 77, 40, "additive"), (1, 2, 64, 64, 64, "bool_bh"),
+                                                (1, 12, 77, 77, 64, "padding"), (1, 1, 256, 256, 512, "none"), (2, 1, 100, 60, 200, "additive")])
+def test_sdpa_masks_and_large_heads(tf, b, nh, tq, tk, hs, kind):
+    from oracle import ops as O
+    from tinyfusers_amd.attention.sdpa import scaled_dot_product_attention
+    q, k, v = rnd("m.q", (b, nh, tq, hs)), rnd("m.k", (b, nh, tk, hs)), rnd("m.v", (b, nh, tk, hs))
+    rng = np.random.default_rng(5)
+    if kind == "bool":
+        mask = rng.random((tq, tk)) < 0.6; mask[:, 0] = True
+    elif kind == "bool_bh":
+        mask = rng.random((b, nh, tq, tk)) < 0.5; mask[..., 3] = True
+    elif kind == "padding":
+        mask = np.ones((1, 1, tq, tk), dtype=bool); mask[..., 50:] = False           # key-padding mask
+    elif kind == "additive":
+        mask = rng.standard_normal((tq, tk)).astype(np.float32) * 2.0
+    else:
+        mask = None
+    got = scaled_dot_product_attention(dev(tf, q, "row"), dev(tf, k, "row"), dev(tf, v, "row"), mask).numpy()
+    close(got, O.scaled_dot_product_attention(q, k, v, mask).numpy())
+
+
+@pytest.mark.parametrize("c,hw", [(64, 8), (512, 16), (512, 64)])
+def test_attn_block_intended_single_head(tf, c, hw):
+    """attention/attention.py:10-24 in the LDM form (one head of size c over the h*w pixels): what real SD weights need."""
+    import oracle
+    from oracle import vae as OV
+    from tinyfusers_amd import config
+    from tinyfusers_amd.attention.attention import AttnBlock
+    from tinyfusers_amd.storage.state import update_state
+    from tinyfusers_amd.storage.synth import synth_tensor
+    names = {f"{n}.{t}": ((c, c, 1, 1) if t == "weight" else (c,)) for n in ("q", "k", "v", "proj_out") for t in ("weight", "bias")}
+    names.update({"norm.weight": (c,), "norm.bias": (c,)})
+    W = {k_: synth_tensor(9, "vae.mid.attn_1." + k_, s_) for k_, s_ in names.items()}
+    m = AttnBlock(c, init=False)
+    update_state(m, W, "")
+    x = rnd("ab.x", (1, c, hw, hw))
+    old = config.head_merge
+    config.head_merge = "intended"
+    try:
+        got = m(dev(tf, x)).numpy()
+    finally:
+        config.head_merge = old
+    Wt = {"p." + k_: torch.from_numpy(v_.astype(np.float32)) for k_, v_ in W.items()}
+    want = OV.attn_block(torch.from_numpy(x), Wt, "p", head_merge="intended").numpy()
+    close(got, want, atol=2e-2)
+
+
+# ---- GroupNorm (+ SiLU) of the input applied INSIDE the conv launch (tf_conv2d_gn_f16): GroupNorm -> SiLU -> conv3x3 of
+# vision/resnet.py:13-17, :22-27 (patch kernel: the loader waves normalise each patch piece once, padding stays zero) and
+# GroupNorm -> 1x1 conv of attention/attention.py:66-68 (tap-by-tap kernel), statistics from the producing convs' partials.
+GI_CASES = [  # n, c1, c2 (concat partner or 0), hw, cout, k, c3 (extra 1x1 source: folded skip projection), silu, forced (bm, bn, splitk) or None
+    (2, 128, 0, 8, 128, 3, 0, True, None), (2, 128, 0, 16, 128, 3, 0, True, (64, 128, 1)), (2, 320, 0, 64, 320, 3, 0, True, (64, 160, 1)),
+    (2, 320, 0, 64, 320, 3, 0, True, (128, 160, 2)), (2, 640, 0, 32, 640, 3, 0, True, (128, 128, 2)), (2, 1280, 0, 16, 1280, 3, 0, True, (128, 160, 8)),
+    (2, 1280, 0, 8, 1280, 3, 0, True, (64, 160, 16)), (2, 1280, 1280, 8, 1280, 3, 0, True, (64, 160, 16)), (2, 1280, 640, 16, 1280, 3, 0, True, None),
+    (2, 640, 320, 32, 640, 3, 0, True, (128, 160, 4)), (2, 640, 0, 32, 640, 3, 320, True, (64, 160, 2)), (1, 128, 0, 16, 128, 3, 64, True, (64, 128, 1)),
+    (2, 320, 0, 64, 320, 1, 0, False, (64, 64, 1)), (2, 320, 0, 64, 320, 1, 0, False, (64, 160, 1)), (2, 640, 0, 32, 640, 1, 0, False, (64, 128, 1)),
+    (2, 1280, 0, 16, 1280, 1, 0, False, (128, 64, 1)), (2, 1280, 0, 8, 1280, 1, 0, False, None), (2, 128, 0, 16, 64, 1, 0, True, (128, 64, 1)),
+    (3, 128, 0, 8, 128, 3, 0, False, (64, 128, 1)),
+]
+
+
+@pytest.mark.parametrize("n,c1,c2,hw,cout,k,c3,silu,force", GI_CASES)
+def test_conv2d_with_input_group_norm_inside(tf, n, c1, c2, hw, cout, k, c3, silu, force):
+    from oracle import ops as O
+    from tinyfusers_amd import config
+    from tinyfusers_amd.native import lib
+    from tinyfusers_amd.ff.group_norm import GroupNorm
+    from tinyfusers_amd.vision.conv2d import Conv2d
+    # producers: two convs whose epilogues emit the statistics of x (and x2), as inside the UNet
+    srcs = []
+    sub = (c2 // 32) if c2 else 0
+    for tag, c in (("a", c1), ("b", c2)):
+        if not c:
+            continue
+        x0 = rnd("gi.x" + tag, (n, 64, hw, hw)); w0 = rnd("gi.w" + tag, (c, 64, 3, 3), (64 * 9) ** -0.5); b0 = rnd("gi.b" + tag, (c,), 0.5)
+        m0 = Conv2d(64, c, [3, 3], padding=[1, 1], init=False); m0.weight = dev(tf, w0); m0.bias = dev(tf, b0)
+        srcs.append(m0(dev(tf, x0), gn=(c // sub) if c2 else 32))
+        assert srcs[-1].gn is not None
+    C = c1 + c2
+    gam = 1.0 + rnd("gi.g", (C,), 0.2); bet = rnd("gi.bt", (C,), 0.2)
+    g = GroupNorm(32, C, init=False); g.weight = dev(tf, gam, "row"); g.bias = dev(tf, bet, "row")
+    wt = rnd("gi.w", (cout, C, k, k), (C * k * k) ** -0.5); b = rnd("gi.b", (cout,), 0.1)
+    m = Conv2d(C, cout, [k, k], padding=[k // 2, k // 2], init=False); m.weight = dev(tf, wt); m.bias = dev(tf, b)
+    e = rnd("gi.e", (n, cout), 0.5)
+    kw = dict(bias_nc=dev(tf, e), gn=32)
+    xe = None
+    if c3:
+        xe = rnd("gi.x3", (n, c3, hw, hw)); ws = rnd("gi.ws", (cout, c3, 1, 1), c3 ** -0.5); bs = rnd("gi.bs", (cout,), 0.1)
+        proj = Conv2d(c3, cout, [1, 1], init=False); proj.weight = dev(tf, ws); proj.bias = dev(tf, bs)
+        kw["extra"] = (proj, dev(tf, xe))
+    xin = (srcs[0], srcs[1]) if c2 else srcs[0]
+    assert lib.tf_conv2d_gn_supported(n, hw, hw, c1, c2, cout, k, k, 1, k // 2, 0, c3, 0, 32) == 1
+    if force:
+        lib.tf_gemm_force_config(*force)
+    config.fuse_group_norm_3x3 = True
+    try:
+        y = m(xin, gn_in=(g, silu), **kw)                  # ONE launch: normalise + conv (+ statistics of y)
+    finally:
+        lib.tf_gemm_force_config(0, 0, 0)
+        config.fuse_group_norm_3x3 = False
+    config.fuse_group_norm = False
+    try:
+        y_ref = m(xin, gn_in=(g, silu), **kw)              # GroupNorm launch + conv launch on the same inputs
+    finally:
+        config.fuse_group_norm = True
+    cat = torch.from_numpy(np.concatenate([s_.numpy() for s_ in srcs], 1))
+    hn = O.group_norm_affine(cat, 32, gam, bet, 1e-5)
+    hn = O.silu(hn) if silu else hn
+    hn = hn.to(torch.float16).to(torch.float32)            # what the conv reads is the fp16-rounded normalised tensor
+    want = O.conv2d_bias(hn, wt, b, (k // 2, k // 2)) + torch.from_numpy(e)[:, :, None, None]
+    if c3:
+        want = want + O.conv2d_bias(xe, ws, bs, (0, 0))
+    close(y.numpy(), want.numpy())
+    np.testing.assert_allclose(y.numpy(), y_ref.numpy(), atol=4e-3, rtol=4e-3)
+    assert y.gn is not None or force is None or hw * hw % force[0] != 0 or cout // 32 < 4
+    if y.gn is not None:                                   # the statistics emitted on the way still describe y
+        g2 = GroupNorm(32, cout, init=False); g2.weight = dev(tf, 1.0 + rnd("gi.g2", (cout,), 0.1), "row"); g2.bias = dev(tf, rnd("gi.b2", (cout,), 0.1), "row")
+        close(g2(y, silu=True).numpy(), O.silu(O.group_norm_affine(torch.from_numpy(y.numpy()), 32, g2.weight.numpy(), g2.bias.numpy(), 1e-5)).numpy())
+
+
+# ---- conv -> GroupNorm (-> SiLU) behind a split-K shape: the reduce kernel owns whole (image, group) slabs, finishes the statistics and
+# writes the normalised tensor next to y (tf_conv2d_fused_norm_f16 / k_splitk_reduce_gn_apply)
+RGA_CASES = [  # n, cin, hw, cout, k, forced (bm, bn, splitk), silu, expect z
+    (2, 1280, 8, 1280, 3, (64, 160, 16), True, True), (2, 1280, 16, 1280, 3, (128, 160, 8), True, True), (2, 640, 32, 640, 3, (128, 160, 4), True, True),
+    (2, 320, 32, 640, 3, (64, 128, 2), False, True), (2, 640, 32, 320, 3, (64, 160, 4), True, True), (1, 128, 16, 64, 3, (64, 64, 2), True, True),
+    (3, 640, 16, 1280, 1, (64, 160, 2), False, True),
+    (2, 640, 64, 320, 3, (128, 160, 2), True, False),      # 4096 rows of 20-channel slabs do not fit a block's registers: reduce + apply launches
+    (2, 320, 16, 320, 3, (64, 160, 1), True, False),       # unsplit: the statistics come from the GEMM epilogue, the apply stays a launch
+]
+
+
+@pytest.mark.parametrize("n,cin,hw,cout,k,force,silu,expect", RGA_CASES)
+def test_conv2d_split_k_reduce_applies_group_norm(tf, n, cin, hw, cout, k, force, silu, expect):
+    from oracle import ops as O
+    from tinyfusers_amd.native import lib
+    from tinyfusers_amd.ff.group_norm import GroupNorm
+    from tinyfusers_amd.vision.conv2d import Conv2d
+    x = rnd("rg.x", (n, cin, hw, hw)); wt = rnd("rg.w", (cout, cin, k, k), (cin * k * k) ** -0.5); b = rnd("rg.b", (cout,), 0.1)
+    e = rnd("rg.e", (n, cout), 0.5); r = rnd("rg.r", (n, cout, hw, hw))
+    gam = 1.0 + rnd("rg.g", (cout,), 0.1); bet = rnd("rg.bt", (cout,), 0.1)
+    m = Conv2d(cin, cout, [k, k], padding=[k // 2, k // 2], init=False); m.weight = dev(tf, wt); m.bias = dev(tf, b)
+    g = GroupNorm(32, cout, init=False); g.weight = dev(tf, gam, "row"); g.bias = dev(tf, bet, "row")
+    lib.tf_gemm_force_config(*force)
+    try:
+        y = m(dev(tf, x), bias_nc=dev(tf, e), residual=dev(tf, r), gn=32, out_norm=(g, silu))
+    finally:
+        lib.tf_gemm_force_config(0, 0, 0)
+    assert (y.normed is not None) == expect
+    want_y = O.conv2d_bias(x, wt, b, (k // 2, k // 2)) + torch.from_numpy(e)[:, :, None, None] + torch.from_numpy(r)
+    close(y.numpy(), want_y.numpy())
+    z = g(y, silu=silu)                                    # returns y.normed's tensor without a launch when the reduce wrote it
+    if expect:
+        assert z is y.normed[2] and y.gn is not None and y.gn[1] == 1
+    yq = torch.from_numpy(y.numpy())
+    want = O.group_norm_affine(yq, 32, gam, bet, 1e-5)
+    want = O.silu(want) if silu else want
+    close(z.numpy(), want.numpy())
+    # the one-chunk statistics left behind serve any other reader of y (e.g. a later concat), and agree with a stand-alone pass
+    y.normed = None
+    again = g(y, silu=silu).numpy()
+    np.testing.assert_allclose(again, z.numpy(), atol=2e-3, rtol=2e-3)
+    y.gn = None
+    plain = g(y, silu=silu).numpy()
+    np.testing.assert_allclose(plain, z.numpy(), atol=2e-3, rtol=2e-3)

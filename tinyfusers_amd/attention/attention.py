@@ -61,7 +61,11 @@ class AttnBlock:
             o = DeviceArray.empty((b, c, h, w), np.float16, "nhwc")
             hip.tf_nchw_to_nhwc_f16(o.ptr, on.ptr, b, c, h, w, _sh())
         else:
-            raise NotImplementedError("AttnBlock: the LDM single-head form (head size = channels) is not built yet")
+            # LDM form: ONE head of size c over the h*w tokens; NHWC q/k/v are already (b, hw, c) token matrices.  Head size 512 is
+            # beyond the flash kernel's registers: the unfused matmul / softmax / matmul path (once per image, not per step).
+            from .sdpa import sdpa_unfused
+            t = h * w
+            o = sdpa_unfused(q.view((b, 1, t, c), "row"), k.view((b, 1, t, c), "row"), v.view((b, 1, t, c), "row")).view((b, c, h, w), "nhwc")
         return self.proj_out(o, residual=x)
 
 
@@ -178,11 +182,10 @@ class SpatialTransformer:
             self._fold = (key, DeviceArray.from_numpy(wf.reshape(c, -1, 1, 1)), DeviceArray.from_numpy(bf, layout="row"))
         return self._fold[1], self._fold[2]
 
-    def __call__(self, x, context=None, kv=None, out_gn=0):
+    def __call__(self, x, context=None, kv=None, out_gn=0, out_norm=None):
         b, c, h, w = x.shape
         x_in = x
-        x = self.norm(x)
-        x = self.proj_in(x)
+        x = self.proj_in(x, gn_in=(self.norm, False))    # GroupNorm -> 1x1 conv (attention.py:66-68) as one launch where the statistics came with x
         x = x.tokens()                                   # (b, hw, c): free re-view of NHWC (attention.py:71)
         if config.fold_proj_out and c % 8 == 0 and self.proj_out.weight.shape[0] == c:
             for block in self.transformer_blocks[:-1]:
@@ -190,11 +193,11 @@ class SpatialTransformer:
             hid, x2 = self.transformer_blocks[-1](x, context=context, kv=kv, defer_ff2=True)
             wf, bf = self._ff2_proj_out()
             pair = (hid.image(b, hid.shape[-1], h, w), x2.image(b, c, h, w))
-            return _conv(pair, wf, bf, [0, 0], [1, 1], [1, 1], residual=x_in, gn=out_gn)
+            return _conv(pair, wf, bf, [0, 0], [1, 1], [1, 1], residual=x_in, gn=out_gn, out_norm=out_norm)
         for block in self.transformer_blocks:
             x = block(x, context=context, kv=kv)
         x = x.image(b, c, h, w)                          # attention.py:74
-        return self.proj_out(x, residual=x_in, gn=out_gn)   # + x_in fused (attention.py:75)
+        return self.proj_out(x, residual=x_in, gn=out_gn, out_norm=out_norm)   # + x_in fused (attention.py:75)
 
 
 class CLIPAttention:

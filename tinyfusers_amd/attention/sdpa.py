@@ -23,16 +23,82 @@ def _is_causal_mask(m, tq, tk):
     return bool(np.isneginf(m2[~tri]).all() and (m2[tri] == 0).all())
 
 
+def _additive_mask(attn_mask, B, NH, Tq, Tk):
+    """attention/sdpa.py:67-68: a boolean mask keeps where True (-inf elsewhere), any other dtype is added.  Returns the fp32
+    additive mask as a device array of shape (rows, Tk) with rows = Tq (broadcast over batch and heads) or B*NH*Tq."""
+    m = np.asarray(attn_mask.numpy() if isinstance(attn_mask, DeviceArray) else attn_mask)
+    if m.dtype == np.bool_:
+        m = np.where(m, np.float32(0.0), np.float32(-np.inf))
+    m = m.astype(np.float32)
+    if m.ndim < 2 or m.shape[-2:] != (Tq, Tk):
+        m = np.broadcast_to(m, (Tq, Tk)) if m.ndim <= 2 else np.broadcast_to(m, m.shape[:-2] + (Tq, Tk))
+    if m.ndim > 2 and int(np.prod(m.shape[:-2])) > 1:
+        m = np.broadcast_to(m, (B, NH, Tq, Tk)).reshape(B * NH * Tq, Tk)
+    else:
+        m = m.reshape(Tq, Tk)
+    return DeviceArray.from_numpy(np.ascontiguousarray(m), np.float32, "row")
+
+
+def sdpa_unfused(q, k, v, mask=None, scale=None):
+    """The reference's own op sequence (attention/sdpa.py:63-76): scale * (q k^T) [+ mask] -> row softmax -> . v, per (batch, head)
+    on the MFMA GEMM kernel, scores in HBM as fp16.  q (B,NH,Tq,HS), k / v (B,NH,Tk,HS) contiguous row-major; any HS % 8 == 0, any mask.
+    The fused flash kernel (tf_sdpa_f16) is the hot path; this one covers masks other than causal and head sizes beyond 160."""
+    from ..ff.linear import linear_f16
+    B, NH, Tq, HS = q.shape
+    Tk = k.shape[-2]
+    assert HS % 8 == 0, "sdpa_unfused: head size must be a multiple of 8"
+    scale = float(1.0 / np.sqrt(HS)) if scale is None else float(scale)
+    Tkp = (Tk + 7) // 8 * 8
+    o = DeviceArray.empty((B, NH, Tq, HS), np.float16, "row")
+    mrows = mask.shape[0] if mask is not None else 1
+    for bh in range(B * NH):
+        qi = q.view((Tq, HS), "row", bh * Tq * HS)
+        ki = k.view((Tk, HS), "row", bh * Tk * HS)
+        vi = v.view((Tk, HS), "row", bh * Tk * HS)
+        s = DeviceArray.zeros((Tq, Tkp), np.float16, "row") if Tkp != Tk else DeviceArray.empty((Tq, Tkp), np.float16, "row")
+        if Tkp == Tk:
+            hip.tf_linear_f16(s.ptr, qi.ptr, ki.ptr, None, None, Tq, Tk, HS, 0, None, 0, _sh())
+        else:
+            s = linear_f16(qi, _pad_rows(ki, Tkp))                 # zero key rows: their scores never reach the softmax (C = Tk)
+        mk = None
+        if mask is not None:
+            mk = mask.ptr + (bh * Tq * Tk * 4 if mrows != Tq else 0)
+        hip.tf_softmax_mask_rows_f16(s.ptr, s.ptr, mk, Tq, Tk, Tkp, scale, Tq, _sh())
+        vt = DeviceArray.zeros((HS, Tkp), np.float16, "row") if Tkp != Tk else DeviceArray.empty((HS, Tkp), np.float16, "row")
+        if Tkp == Tk:
+            hip.tf_nhwc_to_nchw_f16(vt.ptr, vi.ptr, 1, HS, 1, Tk, _sh())     # (Tk, HS) -> (HS, Tk)
+        else:
+            vp = _pad_rows(vi, Tkp)
+            hip.tf_nhwc_to_nchw_f16(vt.ptr, vp.ptr, 1, HS, 1, Tkp, _sh())
+        oi = o.view((Tq, HS), "row", bh * Tq * HS)
+        hip.tf_linear_f16(oi.ptr, s.ptr, vt.ptr, None, None, Tq, HS, Tkp, 0, None, 0, _sh())
+    return o
+
+
+def _pad_rows(a, rows):
+    r, c = a.shape
+    out = DeviceArray.zeros((rows, c), np.float16, "row")
+    hip.tf_memcpy_async(out.ptr, a.ptr, a.nbytes, 3, _sh())
+    return out
+
+
 def scaled_dot_product_attention(q_cp, k_cp, v_cp, attn_mask=None):
-    """q,k,v: (B, NH, T, HS) contiguous DeviceArrays -> (B, NH, Tq, HS).  attn_mask: None or a causal mask
-    (the only mask the reference ever passes, attention/attention.py:94)."""
+    """q,k,v: (B, NH, T, HS) contiguous DeviceArrays -> (B, NH, Tq, HS).  attn_mask as in attention/sdpa.py:67-68: None, a boolean
+    mask (attend where True) or an additive mask, broadcastable to (B, NH, Tq, Tk).  No mask and the causal mask (the only one the
+    reference ever passes, attention/attention.py:94) run on the fused flash kernel; any other mask, or a head size beyond 160, on the
+    unfused matmul / softmax / matmul path."""
     B, NH, Tq, HS = q_cp.shape
     Tk = k_cp.shape[-2]
     causal = False
     if attn_mask is not None:
-        if not _is_causal_mask(attn_mask, Tq, Tk):
-            raise NotImplementedError("tf_sdpa_f16 supports attn_mask=None or a causal mask")
+        if not _is_causal_mask(attn_mask.numpy() if isinstance(attn_mask, DeviceArray) else attn_mask, Tq, Tk):
+            return sdpa_unfused(q_cp, k_cp, v_cp, _additive_mask(attn_mask, B, NH, Tq, Tk))
         causal = True
+    if HS > 160 or HS % 8 != 0:
+        m = None
+        if causal:
+            m = _additive_mask(np.tril(np.ones((Tq, Tk), dtype=bool)), B, NH, Tq, Tk)
+        return sdpa_unfused(q_cp, k_cp, v_cp, m)
     o = DeviceArray.empty((B, NH, Tq, HS), np.float16, "row")
     st = lambda T: (NH * T * HS, T * HS, HS)
     return sdpa_strided(o, q_cp, k_cp, v_cp, B, NH, Tq, Tk, HS, st(Tq), st(Tk), st(Tk), st(Tq), causal)

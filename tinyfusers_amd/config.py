@@ -40,6 +40,19 @@ fold_proj_out = _flag("TF_FOLD_PROJ_OUT", True)
 # (pairs of groups merge) instead of a statistics pass over the concat.
 concat_stats = _flag("TF_CONCAT_STATS", True)
 
+# GroupNorm (+ SiLU) in front of a convolution applied inside the conv launch (tf_conv2d_gn_f16): the loader waves normalise the
+# activation pieces in LDS.  False = a GroupNorm-apply launch in front of every such conv (the unfused reference structure).
+fuse_group_norm = _flag("TF_FUSE_GROUP_NORM", True)
+# ... also for the 3x3 convolutions of the ResBlocks (patch kernel).  Correct and covered by the GPU tests, but MEASURED SLOWER on MI355X
+# (profiles/r02_gn_in_conv.txt): every block normalises its whole input patch for all its n-tiles (4-8x the elements k_gn_apply
+# touches) on loader waves whose LDS-DMA issue is the kernel's critical path: +12...20 us per conv against the 8.5 us launch saved.
+# On by default only for the 1x1 proj_in convolutions (+3 us against 8.5 us saved).
+fuse_group_norm_3x3 = _flag("TF_FUSE_GROUP_NORM_3X3", False)
+
+# conv -> GroupNorm (-> SiLU) behind a split-K shape: the reduce kernel that already owns the statistics also writes the normalised
+# tensor (k_splitk_reduce_gn_apply, tf_conv2d_fused_norm_f16).  False = reduce launch + GroupNorm-apply launch.
+fuse_reduce_norm = _flag("TF_FUSE_REDUCE_NORM", True)
+
 # Operand type of the conv / linear GEMMs: "fp16" (default; BASELINE configs 2-4) or "fp8" (config 5: OCP e4m3 weights with
 # per-output-channel scales packed once, e4m3 activations with a per-tensor scale quantised by the loader side, fp32 accumulate,
 # fp16 residual stream).  Set through set_dtype() before the first forward.

@@ -247,6 +247,34 @@ __global__ void __launch_bounds__(256) k_softmax_rows(float* __restrict__ out, c
   for (int i = t; i < C; i += 256) y[i] = __expf(x[i] - m) * inv;
 }
 
+// row softmax of fp16 scores for the UNFUSED attention path (attention/sdpa.py:53-77 as written: matmul, + mask, softmax kernel,
+// matmul) that serves what the flash kernels do not: arbitrary additive / boolean masks (:67-68) and head sizes beyond 160
+// (the single-head d = 512 attention of the VAE's AttnBlock).  y[r, c] = softmax_c(scale * x[r, c] + mask[r % mask_rows, c]);
+// columns [C, ldc) of y are zero-filled (the P.V GEMM runs over the padded width).  fp32 math, one block per row.
+__global__ void __launch_bounds__(256) k_softmax_mask_rows_f16(half_t* __restrict__ y, const half_t* __restrict__ x, const float* __restrict__ mask,
+                                                               int C, int ldc, float scale, long long mask_rows) {
+  __shared__ float red[8];
+  const long long r = blockIdx.x;
+  const half_t* xr = x + r * ldc;
+  half_t* yr = y + r * ldc;
+  const float* mr = mask ? mask + (r % mask_rows) * C : nullptr;
+  int t = threadIdx.x, w = t >> 6, l = t & 63;
+  float m = -INFINITY;
+  for (int i = t; i < C; i += 256) m = fmaxf(m, scale * (float)xr[i] + (mr ? mr[i] : 0.f));
+  m = wave_max(m);
+  if (l == 0) red[w] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+  for (int i = t; i < C; i += 256) s += __expf(scale * (float)xr[i] + (mr ? mr[i] : 0.f) - m);
+  s = wave_sum(s);
+  if (l == 0) red[4 + w] = s;
+  __syncthreads();
+  s = red[4] + red[5] + red[6] + red[7];
+  const float inv = 1.0f / s;
+  for (int i = t; i < ldc; i += 256) yr[i] = i < C ? (half_t)(__expf(scale * (float)xr[i] + (mr ? mr[i] : 0.f) - m) * inv) : (half_t)0.f;
+}
+
 // ---- sampler pieces ----------------------------------------------------------------------------
 __global__ void k_set_params(float* p, float t, float a_t, float a_prev, float g) {
   if (threadIdx.x == 0) { p[0] = t; p[1] = a_t; p[2] = a_prev; p[3] = g; }
@@ -527,6 +555,16 @@ int tf_softmax_rows_f32(void* out, const void* inp, int N, int C, tfStream_t s) 
   TF_REQUIRE(out && inp && N >= 0 && C >= 1, "tf_softmax_rows_f32: bad arguments");
   if (N == 0) return TF_OK;
   hipLaunchKernelGGL(k_softmax_rows, dim3(N), dim3(256), 0, tf_hs(s), (float*)out, (const float*)inp, C);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_softmax_mask_rows_f16(void* out, const void* inp, const void* mask_f32, long long rows, int C, int ldc, float scale, long long mask_rows,
+                             tfStream_t s) {
+  TF_REQUIRE(out && inp && rows >= 0 && C >= 1 && ldc >= C && rows < (1LL << 31), "tf_softmax_mask_rows_f16: bad arguments (rows=%lld C=%d ldc=%d)", rows, C, ldc);
+  TF_REQUIRE(!mask_f32 || mask_rows >= 1, "tf_softmax_mask_rows_f16: mask_rows=%lld", mask_rows);
+  if (rows == 0) return TF_OK;
+  hipLaunchKernelGGL(k_softmax_mask_rows_f16, dim3((unsigned)rows), dim3(256), 0, tf_hs(s), (half_t*)out, (const half_t*)inp, (const float*)mask_f32, C, ldc,
+                     scale, mask_rows > 0 ? mask_rows : 1);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }

@@ -47,6 +47,18 @@ struct GemmP {
   int gn_G, gn_cpg, gn_chunks;
   // k_igemm_patch geometry (patch_setup): pieces / pixels of one activation patch, bytes of a ring slot, ring depth, log2(W)
   int pt_ppc, pt_ppix, pt_stage, pt_ns, pt_log2w;
+  // GroupNorm (+ SiLU) of the INPUT applied inside this launch (tf_conv2d_gn_f16; vision/resnet.py:8-22 GN -> SiLU -> conv,
+  // attention/attention.py:66-68 GN -> 1x1 conv): the statistics arrive as the producers' partials (the layout k_gn_apply folds),
+  // the consumer waves fold them into a per-channel (a, b) table in LDS during the prologue, and the loader waves normalise the
+  // activation pieces they staged -- in LDS, once per piece -- before the consumers read them.  gi_part == NULL: off.
+  const float* gi_part; const float* gi_part2;
+  const half_t* gi_gamma; const half_t* gi_beta;
+  int gi_chunks, gi_chunks2, gi_G, gi_G1, gi_G2, gi_mr, gi_silu;
+  float gi_eps;
+  int gi_off;           // byte offset of the table in LDS: [G] (mean, rstd) then [C] (a, b), fp32 pairs
+  // GroupNorm (+ SiLU) of the OUTPUT applied by the split-K reduce (tf_conv2d_fused_norm_f16): when the shape runs split-K, the reduce
+  // kernel owns whole (image, group) slabs, so it can finish the statistics AND write the normalised tensor z next to y
+  half_t* on_z; const half_t* on_gamma; const half_t* on_beta; float on_eps; int on_silu; int* on_applied;
 };
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;   // 128-bit buffer resource
@@ -81,6 +93,104 @@ __device__ __forceinline__ void wait_stages(int k) {
     if (k >= MAXK) wait_vm<(MAXK * LPS > 63 ? 63 : MAXK * LPS)>();
     else wait_stages<LPS, MAXK - 1>(k);
   }
+}
+
+// ---- GroupNorm of the input inside the GEMM (GemmP::gi_*) ----------------------------------------------------------------
+// LDS accesses that touch (or sit next to) LDS-DMA landing zones go through inline asm: for an LDS access the compiler cannot
+// disambiguate from an outstanding LDS-DMA it inserts s_waitcnt vmcnt(0), which would drain the whole ring.
+__device__ __forceinline__ unsigned lds_off(const char* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+__device__ __forceinline__ h8 lds_read16(unsigned a) {
+  h8 v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_read16x2(unsigned a0, unsigned a1, h8& v0, h8& v1) {
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(a0), "v"(a1) : "memory");
+}
+__device__ __forceinline__ void lds_write16(unsigned a, h8 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+
+// Prologue, run by the four CONSUMER waves (t = 0..255) while the loaders' first LDS-DMA stages are in flight: fold the statistics
+// partials of image `img` into (mean, rstd) per group -- the very fold of k_gn_apply (8 lanes per group strided over the chunks,
+// fp64, fixed order: the same bits) -- then a[c] = rstd * gamma[c], b[c] = beta[c] - mean * a[c] for every input channel.
+// Contains two workgroup barriers (A: statistics in LDS, B: table in LDS); the loader waves execute the matching pair.
+__device__ __forceinline__ void gi_prologue(const GemmP& p, char* smem, int img, int t) {
+  f2* st = reinterpret_cast<f2*>(smem + p.gi_off);
+  f2* ab = st + p.gi_G;
+  const int G = p.gi_G, C = p.C, cpg = C / G, HW = p.H * p.W;
+  const int sub = t & 7;
+  for (int g0 = 0; g0 < G; g0 += 32) {
+    const int g = g0 + (t >> 3);
+    double S = 0.0, SS = 0.0;
+    if (g < G) {
+      const int nsub = p.gi_part2 ? p.gi_mr : 1;
+      for (int j = 0; j < nsub; ++j) {
+        const float* pp = p.gi_part + (long long)img * p.gi_chunks * G * 2 + g * 2;
+        int nch = p.gi_chunks, gstride = G * 2;
+        if (p.gi_part2) {
+          const int sg = p.gi_mr * g + j;
+          const bool first = sg < p.gi_G1;
+          nch = first ? p.gi_chunks : p.gi_chunks2;
+          gstride = (first ? p.gi_G1 : p.gi_G2) * 2;
+          pp = (first ? p.gi_part : p.gi_part2) + (long long)img * nch * gstride + (first ? sg : sg - p.gi_G1) * 2;
+        }
+        for (int k0 = sub; k0 < nch; k0 += 64) {
+          f2 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            int k = k0 + 8 * u;
+            v[u] = k < nch ? *reinterpret_cast<const f2*>(pp + (long long)k * gstride) : (f2){0.f, 0.f};
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { S += (double)v[u][0]; SS += (double)v[u][1]; }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { S += __shfl_xor(S, o, 64); SS += __shfl_xor(SS, o, 64); }
+    if (g < G && sub == 0) {
+      double cnt = (double)HW * cpg;
+      double mean = S / cnt;
+      double var = SS / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      st[g] = (f2){(float)mean, (float)(1.0 / sqrt(var + (double)p.gi_eps))};
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                           // barrier A: (mean, rstd) of every group
+  asm volatile("" ::: "memory");
+  for (int c = t; c < C; c += 256) {
+    f2 m = st[c / cpg];
+    float gm = p.gi_gamma ? (float)p.gi_gamma[c] : 1.0f, bt = p.gi_gamma ? (float)p.gi_beta[c] : 0.0f;
+    float a = m[1] * gm;
+    ab[c] = (f2){a, bt - m[0] * a};
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                           // barrier B: the (a, b) table
+  asm volatile("" ::: "memory");
+}
+// the (a, b) of the 8 consecutive channels c0 .. c0 + 7 from the LDS table (loader waves)
+__device__ __forceinline__ void gi_load_ab(const GemmP& p, char* smem, int c0, float (&a)[8], float (&b)[8]) {
+  const unsigned base = lds_off(smem + p.gi_off) + (unsigned)(p.gi_G + c0) * 8u;
+  h8 r0, r1, r2, r3;
+  lds_read16x2(base, base + 16, r0, r1);
+  lds_read16x2(base + 32, base + 48, r2, r3);
+  f4 q0 = __builtin_bit_cast(f4, r0), q1 = __builtin_bit_cast(f4, r1), q2 = __builtin_bit_cast(f4, r2), q3 = __builtin_bit_cast(f4, r3);
+  a[0] = q0[0]; b[0] = q0[1]; a[1] = q0[2]; b[1] = q0[3];
+  a[2] = q1[0]; b[2] = q1[1]; a[3] = q1[2]; b[3] = q1[3];
+  a[4] = q2[0]; b[4] = q2[1]; a[5] = q2[2]; b[5] = q2[3];
+  a[6] = q3[0]; b[6] = q3[1]; a[7] = q3[2]; b[7] = q3[3];
+}
+// normalise one 16-byte element vector: x * a + b, optional SiLU, rounded to fp16 exactly as k_gn_apply does; `keep` = false
+// leaves zeros (zero padding of the convolution is applied AFTER the normalisation: the padded pixels must stay zero)
+__device__ __forceinline__ h8 gi_apply(h8 x, const float (&a)[8], const float (&b)[8], int do_silu, bool keep) {
+  h8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float f = (float)x[j] * a[j] + b[j];
+    o[j] = (half_t)(do_silu ? silu_f(f) : f);
+  }
+  if (!keep) o = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+  return o;
 }
 
 // deep-variant ring depth: as many slots as 160 KiB of LDS hold (<= 8): LDS-DMA ingest is latency x bytes-in-flight bound
@@ -360,6 +470,25 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
         }
       }
     };
+    // GroupNorm of the input (1x1 convolutions: k = input channel): normalise this wave's activation pieces of K tile kt where
+    // they landed (LDS position lane -> source chunk cs), before the barrier that hands the tile to the consumers
+    constexpr bool GI_OK = !GENERIC && !(BM == 128 && BN == 160);   // (instances the host never launches with gi_part set)
+    const bool gi_on = GI_OK && p.gi_part != nullptr;
+    auto gi_tile = [&](int slot, int kt) {
+      if (!GI_OK || kt * 64 >= p.Kc) return;               // the extra 1x1 segment stays raw
+      float ga[8], gb[8];
+      gi_load_ab(p, smem, kt * 64 + cs * 8, ga, gb);
+      const unsigned base = lds_off(smem + slot * STAGE) + lane * 16;
+#pragma unroll
+      for (int i = 0; i < LPS; ++i) {
+        const int g = w4 + 4 * i;
+        if (g * 8 < BM) {
+          h8 x = lds_read16(base + g * 1024);
+          lds_write16(base + g * 1024, gi_apply(x, ga, gb, p.gi_silu, true));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
     int st_r, st_s, st_c;                                  // wave-uniform (tap, channel) of the next tile to stage
     {
       int kg0 = kt_begin * 64;
@@ -448,8 +577,10 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
       // 2-slot ring: barrier(it) hands tile it to the consumers and slot (it-1) % 2 back; tile it+1 is in flight
       // while tile it is multiplied.
       if (nt > 0) stage(0, kt_begin);
+      if (gi_on) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }   // barriers A, B of gi_prologue (consumer waves)
       for (int it = 0; it < nt; ++it) {
         wait_vm<0>();
+        if (gi_on) gi_tile(it & 1, kt_begin + it);
         __builtin_amdgcn_s_barrier();                     // barrier(it)
         asm volatile("" ::: "memory");
         if (it + 1 < nt) stage((it + 1) & 1, kt_begin + it + 1);
@@ -462,12 +593,15 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
 #pragma unroll
       for (int s_ = 0; s_ < NS; ++s_)
         if (s_ < nt) stage(s_, kt_begin + s_);
+      if (gi_on) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }   // barriers A, B of gi_prologue (consumer waves)
       wait_stages<LPS, NS - 1>(nt - 1);                    // tile 0 landed; up to NS-1 newer stages in flight
+      if (gi_on && nt > 0) gi_tile(0, kt_begin);
       __builtin_amdgcn_s_barrier();                       // barrier P
       if (ln_on && nt > 0) ln_tile(0);                    // slot 0 is refilled only after barrier(0)
       asm volatile("" ::: "memory");
       for (int it = 0; it < nt; ++it) {
         if (it + 1 < nt) wait_stages<LPS, NS - 2>(nt - 2 - it);   // tile it+1 landed (ring holds up to tile it+NS-1 here)
+        if (gi_on && it + 1 < nt) gi_tile((it + 1) % NS, kt_begin + it + 1);
         __builtin_amdgcn_s_barrier();                     // barrier(it)
         asm volatile("" ::: "memory");
         if (it + NS < nt) stage(it % NS, kt_begin + it + NS);
@@ -511,6 +645,9 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   }
 
   // ================================= CONSUMER WAVES ===============================================
+  if constexpr (!GENERIC && !(BM == 128 && BN == 160)) {
+    if (p.gi_part) gi_prologue(p, smem, m0 / p.HoWo, w4 * 64 + lane);   // first: its global loads must not wait behind this wave's own DMA (ALL8)
+  }
   const int wave_m = w4 & 1, wave_n = w4 >> 1;
   const int lr = lane & 15, lg = lane >> 4;
   f4 acc[NI][MJ];
@@ -866,6 +1003,23 @@ __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
         default: one(pp[8], 8); break;
       }
     };
+    // GroupNorm (+ SiLU) of the input: every loader wave normalises the patch pieces IT staged (its own vmcnt covers their
+    // landing), in LDS, once per piece instead of once per tap; padding pixels (pp < 0) stay zero
+    const bool gi_on = p.gi_part != nullptr;
+    float na[8], nb[8];
+    int ab_group = -1;
+    auto gi_piece = [&](int G, int v, int i) {            // piece w4 + 4 i of patch(G); v = pp[i]
+      if (w4 + 4 * i >= PPC) return;
+      const unsigned a = lds_off(smem + (G & 1) * PB) + (unsigned)(w4 + 4 * i) * 1024u + lane * 16;
+      lds_write16(a, gi_apply(lds_read16(a), na, nb, p.gi_silu, v >= 0));
+    };
+    auto gi_range = [&](int G, int lo, int hi) {          // pieces lo <= i < hi of patch(G) (static register indices)
+      if (ab_group != G) { gi_load_ab(p, smem, (G << 6) + cs * 8, na, nb); ab_group = G; }
+#pragma unroll
+      for (int i = 0; i < TF_PATCH_PPW; ++i)
+        if (i >= lo && i < hi) gi_piece(G, pp[i], i);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
     // does the stage of conv tile (g, tap) carry pieces of patch(g + 1)?  and how many loads does stage (g, tap) issue
     auto carries = [&](int g, int tap) { return tap >= TAP0 && g + 1 < G1 && 9 * (g + 1) < kt_end; };
     auto count = [&](int g, int tap) {                    // g >= G1: a K tile of the extra 1x1 segment
@@ -898,10 +1052,13 @@ __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
       }
       return n;
     };
+    int pro_g = -1, pro_next = 0;                          // prologue patches to normalise: patch(pro_g) whole, pieces [0, pro_next) of patch(pro_g + 1)
     if (kt_begin < T1) {
       sg = kt_begin / 9; stap = kt_begin - 9 * sg;
       patch_pieces(sg, 0, TF_PATCH_PPW);                   // the first patch of this split, whole
+      pro_g = sg;
       if (stap > TAP0 && carries(sg, stap - 1)) patch_pieces(sg + 1, 0, (stap - TAP0) * PQ);   // what the skipped stages carry
+      if (stap >= TAP0 && carries(sg, stap)) pro_next = (stap - TAP0 + 1) * PQ;   // ... plus what tile 0's own stage carries: all landed with tile 0
     } else {
       sg = G1 + (kt_begin - T1);
     }
@@ -912,16 +1069,25 @@ __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
     {
       int s_ = 0;
       for (; s_ < NS && s_ < nt; ++s_) { int n = stage(s_); if (s_ > 0) W += n; }
+      if (gi_on) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }   // barriers A, B of gi_prologue (consumer waves)
       wait_vm_dyn(W);                                      // tile 0 (and everything issued before it) landed
+      if (gi_on && pro_g >= 0) {
+        gi_range(pro_g, 0, TF_PATCH_PPW);
+        if (pro_next > 0) gi_range(pro_g + 1, 0, pro_next);
+      }
     }
     __builtin_amdgcn_s_barrier();                         // barrier P
     asm volatile("" ::: "memory");
     int slot = 0;
     for (int it = 0; it < nt; ++it) {
       if (it + 1 < nt) {
+        const int lg_ = ng, lt_ = ntap;                    // tile it+1 = (group, tap)
         W -= count(ng, ntap);                              // tile it+1 must have landed: only newer stages may be in flight
         advance();
         wait_vm_dyn(W);
+        // the pieces of patch(group + 1) that rode on tile it+1's stage have landed with it: normalise them now (the consumers
+        // read that patch from tile 9 (group + 1) on, behind barrier(9 group + 8) at the earliest)
+        if (gi_on && lg_ < G1 && carries(lg_, lt_)) gi_range(lg_ + 1, (lt_ - TAP0) * PQ, (lt_ - TAP0 + 1) * PQ);
       }
       __builtin_amdgcn_s_barrier();                       // barrier(it)
       asm volatile("" ::: "memory");
@@ -938,6 +1104,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
   }
 
   // ================================= CONSUMER WAVES ===============================================
+  if (p.gi_part) gi_prologue(p, smem, m0 / p.HoWo, w4 * 64 + lane);
   const int wave_m = w4 & 1, wave_n = w4 >> 1;
   const int lr = lane & 15, lg = lane >> 4;
   f4 acc[NI][MJ];
@@ -1130,6 +1297,139 @@ __global__ void __launch_bounds__(1024) k_splitk_reduce_gn(half_t* __restrict__ 
   }
 }
 
+// split-K reduce + epilogue + GroupNorm of the output, statistics AND apply, in one launch (conv -> GroupNorm -> SiLU of
+// vision/resnet.py:17-22 behind a split-K conv): a block owns ALL rows of one image for `gpb` whole groups (CW = gpb * cpg channels),
+// so the statistics are complete inside the block and no second launch has to wait for them.  Thread t holds the column quad
+// t % CV of rows t / CV + k * RPS (k < RGA_MAXR) in registers: partials summed in split order (8 loads in flight), + bias + bias_nc +
+// residual, rounded to fp16 (y, optional), per-channel sums in registers -> LDS -> fixed-order fold -> (mean, rstd) -> z = silu?(y a + b).
+// Also leaves the (sum, sum of squares) of every group as a one-chunk partial table, so y.gn stays available to later consumers.
+#define RGA_MAXR 8
+__global__ void __launch_bounds__(1024) k_splitk_reduce_gn_apply(half_t* __restrict__ y, half_t* __restrict__ z, const float* __restrict__ partial,
+                                                                 const half_t* __restrict__ bias, const half_t* __restrict__ bias_nc,
+                                                                 const half_t* __restrict__ residual, int M, int N, int HoWo, int splitk, long long bnc_stride,
+                                                                 float* __restrict__ gn_part, int G, int cpg, int gpb, const half_t* __restrict__ gamma,
+                                                                 const half_t* __restrict__ beta, float eps, int do_silu, int RPS, int CV) {
+  extern __shared__ float sm[];                          // [RPS][CW][2], then [parts][CW][2] behind it, then [gpb][2]
+  const int nb = G / gpb;
+  const int img = blockIdx.x / nb, gs = blockIdx.x - img * nb;
+  const int CW = gpb * cpg, c0 = gs * CW;
+  const int t = threadIdx.x;
+  const int rl = t / CV, v = t - rl * CV;
+  const bool act = rl < RPS;
+  const int n = c0 + v * 4;
+  const long long total = (long long)M * N;
+  f4 bv = {0.f, 0.f, 0.f, 0.f};
+  h4 bnc = {0, 0, 0, 0};
+  if (act) {
+    if (bias) { h4 b = *reinterpret_cast<const h4*>(bias + n); for (int e = 0; e < 4; ++e) bv[e] = (float)b[e]; }
+    if (bias_nc) bnc = *reinterpret_cast<const h4*>(bias_nc + (long long)img * bnc_stride + n);
+  }
+  h4 out[RGA_MAXR];
+  f4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < RGA_MAXR; ++k) {
+    const int r = rl + k * RPS;
+    out[k] = (h4){0, 0, 0, 0};
+    if (act && r < HoWo) {
+      const long long e0 = ((long long)img * HoWo + r) * N + n;
+      h4 res = {0, 0, 0, 0};
+      if (residual) res = *reinterpret_cast<const h4*>(residual + e0);
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int z0 = 0; z0 < splitk; z0 += 8) {
+        f4 u[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = z0 + i < splitk ? *reinterpret_cast<const f4*>(partial + (long long)(z0 + i) * total + e0) : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += u[i];
+      }
+      acc += bv;
+      for (int e = 0; e < 4; ++e) acc[e] += (float)bnc[e];
+      for (int e = 0; e < 4; ++e) acc[e] += (float)res[e];
+      h4 o;
+      for (int e = 0; e < 4; ++e) { o[e] = (half_t)acc[e]; float f = (float)o[e]; cs[e] += f; cq[e] += f * f; }
+      out[k] = o;
+      if (y) *reinterpret_cast<h4*>(y + e0) = o;
+    }
+  }
+  f2* col = reinterpret_cast<f2*>(sm);                   // [RPS][CW]
+  if (act) for (int e = 0; e < 4; ++e) col[rl * CW + v * 4 + e] = (f2){cs[e], cq[e]};
+  __syncthreads();
+  // fold 1: thread (part, c) sums the row lanes part, part + parts, ... of channel c, in order
+  const int parts = 1024 / CW;
+  f2* p1 = col + RPS * CW;                               // [parts][CW]
+  {
+    const int part = t / CW, c = t - part * CW;
+    if (part < parts) {
+      float S = 0.f, Q = 0.f;
+      for (int l = part; l < RPS; l += parts) { f2 q = col[l * CW + c]; S += q[0]; Q += q[1]; }
+      p1[part * CW + c] = (f2){S, Q};
+    }
+  }
+  __syncthreads();
+  // fold 2: one wave per group: lanes stride over the (part, channel of the group) pairs in a fixed order, fp64, shuffle tree
+  float* st = reinterpret_cast<float*>(p1 + parts * CW);  // [gpb][2]: mean, rstd
+  {
+    const int wv = t >> 6, lane = t & 63;
+    if (wv < gpb) {
+      double S = 0.0, Q = 0.0;
+      const int npairs = parts * cpg;
+      for (int q = lane; q < npairs; q += 64) {
+        int part = q / cpg, c = wv * cpg + (q - part * cpg);
+        f2 u = p1[part * CW + c];
+        S += (double)u[0]; Q += (double)u[1];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { S += __shfl_xor(S, o, 64); Q += __shfl_xor(Q, o, 64); }
+      if (lane == 0) {
+        const double cnt = (double)HoWo * cpg;
+        double mean = S / cnt, var = Q / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        st[2 * wv] = (float)mean; st[2 * wv + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        if (gn_part) { float* d = gn_part + ((long long)img * G + gs * gpb + wv) * 2; d[0] = (float)S; d[1] = (float)Q; }
+      }
+    }
+  }
+  __syncthreads();
+  if (!act) return;
+  float a[4], b[4];
+  {
+    h4 gm = {1, 1, 1, 1}, bt = {0, 0, 0, 0};
+    if (gamma) { gm = *reinterpret_cast<const h4*>(gamma + n); bt = *reinterpret_cast<const h4*>(beta + n); }
+    for (int e = 0; e < 4; ++e) {
+      const int g = (v * 4 + e) / cpg;
+      a[e] = st[2 * g + 1] * (float)gm[e];
+      b[e] = (float)bt[e] - st[2 * g] * a[e];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < RGA_MAXR; ++k) {
+    const int r = rl + k * RPS;
+    if (r < HoWo) {
+      h4 o;
+      for (int e = 0; e < 4; ++e) { float f = (float)out[k][e] * a[e] + b[e]; o[e] = (half_t)(do_silu ? silu_f(f) : f); }
+      *reinterpret_cast<h4*>(z + ((long long)img * HoWo + r) * N + n) = o;
+    }
+  }
+}
+// geometry of that launch for (HoWo, N, G): groups per block, quads per row, rows per sweep, LDS bytes; false = not eligible
+static bool rga_geometry(int HoWo, int N, int G, int* gpb, int* CV, int* RPS, size_t* lds) {
+  if (G < 1 || N % G || N % 4) return false;
+  const int cpg = N / G;
+  int g = 1;
+  while (g <= G && ((g * cpg) % 4 != 0 || G % g != 0)) ++g;
+  if (g > G || g > 16) return false;                     // one wave per group in fold 2
+  const int CW = g * cpg;
+  if (CW > 256) return false;
+  int cv = CW / 4, rps = 1024 / cv;
+  if (rps > HoWo) rps = HoWo;
+  if ((long long)rps * RGA_MAXR < HoWo) return false;
+  const int parts = 1024 / CW;
+  size_t bytes = ((size_t)rps * CW + (size_t)parts * CW) * 8 + (size_t)g * 8;
+  if (bytes > 160 * 1024) return false;
+  *gpb = g; *CV = cv; *RPS = rps; *lds = bytes;
+  return true;
+}
+
 // ---- weight-streaming GEMV for M <= 8 (time-embedding MLP, ResBlock emb_layers): one wave per output row
 __global__ void __launch_bounds__(256) k_gemv(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ w,
                                               const half_t* __restrict__ bias, int M, int N, int K, int silu_in) {
@@ -1238,6 +1538,14 @@ static int gn_chunks_for(const GemmP& p, TileCfg c, int splitk) {
 }
 static bool gn_tile_ok(const GemmP& p, int bm, int bn) { return p.HoWo % bm == 0 && gn_pieces(p, bn) * (p.HoWo / bm) <= TF_GN_MAX_CHUNKS; }
 
+static int gi_table_bytes(const GemmP& p) { return p.gi_part ? (p.gi_G + p.C) * 8 : 0; }
+// LDS of a k_igemm<bm, bn> launch without the gi table (ring or epilogue scratch, whichever is larger)
+static int igemm_lds_bytes(int bm, int bn, bool wide) {
+  const int ring = (wide ? 2 : ring_slots(bm, bn)) * (bm + bn) * 128;
+  const int scratch = 4 * (bm / 2) * (bn / 2 + 4) * 4, tail = bm * 8 + 4 * bn * 8;
+  return ring > scratch + tail ? ring : scratch + tail;
+}
+
 template <int BM, int BN, bool GENERIC, bool WIDE, bool ALL8 = false>
 static int launch_cfg3(const GemmP& p, hipStream_t st) {
   constexpr int TM = BM / 2, TN = BN / 2;
@@ -1247,8 +1555,17 @@ static int launch_cfg3(const GemmP& p, hipStream_t st) {
   constexpr int smem = ring > scratch + tail ? ring : scratch + tail;
   static bool attr_set = false;
   if (!attr_set) {
-    TF_HIP(hipFuncSetAttribute((const void*)k_igemm<BM, BN, GENERIC, WIDE, ALL8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    TF_HIP(hipFuncSetAttribute((const void*)k_igemm<BM, BN, GENERIC, WIDE, ALL8>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     attr_set = true;
+  }
+  if (p.gi_part) {                                       // the (mean, rstd) + (a, b) table of the input's GroupNorm sits behind everything else
+    GemmP q = p;
+    q.gi_off = (smem + 15) & ~15;
+    const int total = q.gi_off + gi_table_bytes(p);
+    if (GENERIC || (BM == 128 && BN == 160) || total > 163840) { tf_set_error("k_igemm<%d,%d>: no room for the GroupNorm table (%d B)", BM, BN, total); return TF_E_UNSUPPORTED; }
+    hipLaunchKernelGGL((k_igemm<BM, BN, GENERIC, WIDE, ALL8>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), total, st, q);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
   }
   hipLaunchKernelGGL((k_igemm<BM, BN, GENERIC, WIDE, ALL8>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
   TF_LAUNCH_CHECK();
@@ -1266,17 +1583,18 @@ static bool patch_setup(GemmP& p, int bm, int bn) {
   const int ppix = (bm / p.W + 2) * (p.W + 2), ppc = (ppix + 7) / 8;
   if ((ppc + 3) / 4 > TF_PATCH_PPW) return false;
   const int stage = bn * 128 + ((p.C3 + p.C4) ? bm * 128 : 0);
-  int ns = (163840 - 2 * ppc * 1024) / stage;
+  int ns = (163840 - 2 * ppc * 1024 - gi_table_bytes(p)) / stage;
   if (ns > 5) ns = 5;                                    // patch pieces ride from tap 4 on: needs ns - 1 <= 4 (k_igemm_patch TAP0)
   if (ns < 3) return false;
   p.pt_ppc = ppc; p.pt_ppix = ppix; p.pt_stage = stage; p.pt_ns = ns; p.pt_log2w = l2;
+  p.gi_off = 2 * ppc * 1024 + ns * stage;
   return true;
 }
 template <int BM, int BN>
 static int launch_patch(const GemmP& p, hipStream_t st) {
   constexpr int TM = BM / 2, TN = BN / 2;
   constexpr int scratch = 4 * TM * (TN + 4) * 4, tail = BM * 8 + 4 * BN * 8;
-  const int ring = 2 * p.pt_ppc * 1024 + p.pt_ns * p.pt_stage;
+  const int ring = 2 * p.pt_ppc * 1024 + p.pt_ns * p.pt_stage + gi_table_bytes(p);
   const int smem = ring > scratch + tail ? ring : scratch + tail;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1297,12 +1615,35 @@ static int launch_cfg(const GemmP& p, hipStream_t st, bool wide, bool all8 = fal
   return generic ? launch_cfg3<BM, BN, true, false>(p, st) : launch_cfg3<BM, BN, false, false>(p, st);
 }
 
+// GroupNorm of the input inside the launch (gi): which (tile, variant) can carry it.  3x3 / stride 1 / pad 1: the PATCH kernel only
+// (a piece is normalised once for its nine taps); 1x1: the tap-by-tap kernel (k = channel), any ring variant; every channel count on
+// the 64 grid, m-tiles inside one image (one statistics table per block), and room in LDS for the table.
+static bool gi_tile_ok(const GemmP& p, int bm, int bn, int variant) {
+  if (!p.gi_part) return true;
+  if (gemm_generic(p) || p.act || p.ln_colsum || p.HoWo % bm) return false;
+  if (p.S == 3) { GemmP probe = p; return variant == 2 && patch_setup(probe, bm, bn); }
+  if (p.S != 1 || p.Kc != p.C || p.stride != 1 || p.pad != 0 || p.ups) return false;
+  if (variant == 2 || (bm == 128 && bn == 160)) return false;
+  return ((igemm_lds_bytes(bm, bn, variant == 1) + 15) & ~15) + gi_table_bytes(p) <= 163840;
+}
+static bool gi_any_ok(const GemmP& p) {
+  static const int cand[][2] = {{128, 160}, {64, 160}, {128, 128}, {64, 128}, {128, 64}, {64, 64}};
+  for (int ci = 0; ci < 6; ++ci)
+    for (int v = 0; v < 4; ++v)
+      if (gi_tile_ok(p, cand[ci][0], cand[ci][1], v)) return true;
+  return false;
+}
+
 // one fully specified launch (tile, split-K, ring variant) of the kernel family (+ the split-K reduce)
 // variant: 0 deep ring, 1 WIDE (two blocks per CU), 2 PATCH (k_igemm_patch; falls back to 0 when the shape is not eligible),
 // 3 ALL8 (deep ring, the consumer waves issue part of the weight pieces; falls back to 0 for channel counts off the 64 grid)
 static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspace, hipStream_t st) {
   int rc = 0;
   const bool wide = variant == 1, all8 = variant == 3;
+  if (p.gi_part && !gi_tile_ok(p, c.bm, c.bn, variant)) {
+    tf_set_error("run_gemm: tile %dx%d variant %d cannot carry the input GroupNorm", c.bm, c.bn, variant);
+    return TF_E_UNSUPPORTED;
+  }
   p.order = order;
   p.ktiles_per_split = (p.ktiles + c.splitk - 1) / c.splitk;
   p.splitk = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
@@ -1330,7 +1671,19 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
   else { tf_set_error("run_gemm: no kernel for tile %dx%d", c.bm, c.bn); return TF_E_UNSUPPORTED; }
   if (rc) return rc;
   p.gn_part = gn_part;
-  if (p.splitk > 1 && p.gn_part) {
+  if (p.on_applied) *p.on_applied = 0;
+  int rg_gpb = 0, rg_cv = 0, rg_rps = 0;
+  size_t rg_lds = 0;
+  if (p.splitk > 1 && p.on_z && p.gn_part && rga_geometry(p.HoWo, p.N, p.gn_G, &rg_gpb, &rg_cv, &rg_rps, &rg_lds)) {
+    static bool attr_set = false;
+    if (!attr_set) { TF_HIP(hipFuncSetAttribute((const void*)k_splitk_reduce_gn_apply, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+    const int nimg = p.M / p.HoWo;
+    hipLaunchKernelGGL(k_splitk_reduce_gn_apply, dim3(nimg * (p.gn_G / rg_gpb)), dim3(1024), rg_lds, st, p.y, p.on_z, (const float*)p.partial, p.bias, p.bias_nc,
+                       p.residual, p.M, p.N, p.HoWo, p.splitk, p.bias_nc_stride, p.gn_part, p.gn_G, p.gn_cpg, rg_gpb, p.on_gamma, p.on_beta, p.on_eps, p.on_silu,
+                       rg_rps, rg_cv);
+    TF_LAUNCH_CHECK();
+    if (p.on_applied) *p.on_applied = 1;
+  } else if (p.splitk > 1 && p.gn_part) {
     const int R = p.HoWo / p.gn_chunks, nq = p.N >> 2;
     int RL = 1024 / nq;
     if (RL > R) RL = R;
@@ -1358,6 +1711,21 @@ static bool g_autotune = true;
 struct TunedCfg { TileCfg c; int variant; int order; };   // variant: see launch_one
 static std::map<std::array<int, 10>, TunedCfg> g_tuned;
 
+// untuned default for a launch that carries the input GroupNorm: the first admissible (tile, variant), split-K of the cost model
+static TunedCfg gi_default(const GemmP& p) {
+  static const int cand[][2] = {{64, 160}, {128, 160}, {64, 128}, {128, 128}, {64, 64}, {128, 64}};
+  TileCfg m = choose_tiles(p.M, p.N, p.K, p.act, true);
+  for (int ci = 0; ci < 6; ++ci)
+    for (int v = (p.S == 3 ? 2 : 0); v < 4; ++v)
+      if (gi_tile_ok(p, cand[ci][0], cand[ci][1], v)) {
+        int sk = m.splitk;
+        long long blocks = (long long)((p.M + cand[ci][0] - 1) / cand[ci][0]) * ((p.N + cand[ci][1] - 1) / cand[ci][1]);
+        while (sk > 1 && (blocks * sk > 1024 || p.ktiles / sk < 4)) sk >>= 1;
+        return {{cand[ci][0], cand[ci][1], sk}, v, 0};
+      }
+  return {m, 0, 0};
+}
+
 #define TF_FLUSH_BYTES ((size_t)384 << 20)
 static void* g_flush = nullptr;
 static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hipStream_t st, TunedCfg* out) {
@@ -1367,6 +1735,7 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
   TF_HIP(hipEventCreate(&a)); TF_HIP(hipEventCreate(&b));
   float best = 1e30f;
   TunedCfg bc = {choose_tiles(p.M, p.N, p.K, p.act, true), 0, 0};
+  if (p.gi_part) bc = gi_default(p);
   for (int ci = 0; ci < 6; ++ci) {
     int bm = cand[ci][0], bn = cand[ci][1];
     if (p.act == 1 && (bn % 64) != 0) continue;
@@ -1381,6 +1750,7 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
         if (wide == 1 && (bm == 128 && bn == 160)) continue;
         if (wide == 1 && blocks <= 256) continue;          // two blocks per CU need more blocks than CUs
         if (wide == 2) { GemmP probe = p; if (!patch_setup(probe, bm, bn)) continue; }
+        if (!gi_tile_ok(p, bm, bn, wide)) continue;
         TileCfg c = {bm, bn, sk};
         for (int order = 0; order < 2; ++order) {
           if (order == 1 && (p.M + bm - 1) / bm == 1) continue;   // a single m tile: both orders coincide
@@ -1402,6 +1772,9 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
           }
           for (int i = 0; i < 5; ++i) for (int j = i + 1; j < 5; ++j) if (tv[j] < tv[i]) { float t = tv[i]; tv[i] = tv[j]; tv[j] = t; }
           float ms = tv[2];
+          // the output's GroupNorm is applied by the split-K reduce when there is one; a shape that runs unsplit needs the
+          // k_gn_apply launch behind it instead (8.5 us in the step, profiles/r01_kernel_stats_per_step.txt)
+          if (p.on_z && q.gn_part && sk == 1) ms += 0.0085f;
           if (ms < best) { best = ms; bc = {c, wide, order}; }
         }
       }
@@ -1419,11 +1792,14 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
   fast_div_magic((unsigned)p.Wo, &p.dv_wo_mul, &p.dv_wo_shr);
   TunedCfg t = {choose_tiles(p.M, p.N, p.K, p.act, true), 0, 0};
   bool tuned = false;
+  if (p.gi_part) { t = gi_default(p); tuned = true; }    // (tuned: keep gi_default's variant unless the tuner knows better)
   if (force_bm) {
     t.c = {force_bm, force_bn, force_split > 0 ? force_split : 1};
     t.order = g_force_order > 0 ? 1 : 0;
+    if (p.gi_part) t.variant = p.S == 3 ? 2 : 0;
   } else if (g_autotune && !g_dbg) {
-    std::array<int, 10> key = {p.M, p.N, p.K, p.C1, p.C2, p.S, p.stride, p.ups, p.act, (p.bias ? 1 : 0) | (p.residual ? 2 : 0) | (p.bias_nc ? 4 : 0) | (p.ln_colsum ? 8 : 0)};
+    std::array<int, 10> key = {p.M, p.N, p.K, p.C1, p.C2, p.S, p.stride, p.ups, p.act,
+                               (p.bias ? 1 : 0) | (p.residual ? 2 : 0) | (p.bias_nc ? 4 : 0) | (p.ln_colsum ? 8 : 0) | (p.gi_part ? 16 : 0) | (p.on_z ? 32 : 0)};
     auto it = g_tuned.find(key);
     if (it != g_tuned.end()) { t = it->second; tuned = true; }
     else {
@@ -1448,7 +1824,7 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     long long blocks = (long long)((p.M + t.c.bm - 1) / t.c.bm) * ((p.N + t.c.bn - 1) / t.c.bn) * t.c.splitk;
     wide = (blocks > 256 && p.ktiles / t.c.splitk <= 24) ? 1 : 0;
   }
-  if (g_force_wide >= 0) wide = g_force_wide;
+  if (g_force_wide >= 0 && !(p.gi_part && p.S == 3)) wide = g_force_wide;
   ProfRec rec;
   if (g_prof) {
     TF_HIP(hipEventCreate(&rec.a)); TF_HIP(hipEventCreate(&rec.b));
@@ -1463,6 +1839,8 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     int kps = (p.ktiles + t.c.splitk - 1) / t.c.splitk, eff = (p.ktiles + kps - 1) / kps;
     if (eff == 1 && !gn_tile_ok(p, t.c.bm, t.c.bn)) p.gn_part = nullptr;
     if (gn_chunks) *gn_chunks = p.gn_part ? gn_chunks_for(p, t.c, eff) : 0;
+    int a_, b_, c_; size_t d_;
+    if (gn_chunks && p.gn_part && eff > 1 && p.on_z && rga_geometry(p.HoWo, p.N, p.gn_G, &a_, &b_, &c_, &d_)) *gn_chunks = 1;   // the fused reduce leaves whole-image sums
   }
   int rc = launch_one(p, t.c, wide, t.order, workspace, st);
   if (rc) return rc;
@@ -1599,7 +1977,7 @@ size_t tf_conv2d_workspace(int N, int H, int W, int C1, int C2, int Cout, int R,
 static int conv2d_impl(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
                        const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
                        void* workspace, size_t workspace_bytes, float* gn_partial, size_t gn_partial_bytes, int gn_groups, int* gn_chunks,
-                       const void* x3, const void* x4, int C3, int C4, tfStream_t s) {
+                       const void* x3, const void* x4, int C3, int C4, tfStream_t s, const GemmP* gi = nullptr) {
   if (gn_chunks) *gn_chunks = 0;
   TF_REQUIRE(C3 >= 0 && C4 >= 0 && (C3 == 0 || x3) && (C4 == 0 || (x4 && C3 > 0)) && C3 % 8 == 0 && C4 % 8 == 0,
              "tf_conv2d_fused_f16: extra sources C3=%d C4=%d must be multiples of 8 with their tensors given (x4 needs x3)", C3, C4);
@@ -1639,7 +2017,69 @@ static int conv2d_impl(void* y, const void* x, const void* x2, const void* w, co
       p.gn_part = gn_partial; p.gn_G = gn_groups; p.gn_cpg = cpg;
     }
   }
+  if (gi && gi->on_z && p.gn_part) {                       // (groups the epilogue cannot fold: no statistics, no apply -- *z_written stays 0)
+    p.on_z = gi->on_z; p.on_gamma = gi->on_gamma; p.on_beta = gi->on_beta; p.on_eps = gi->on_eps; p.on_silu = gi->on_silu; p.on_applied = gi->on_applied;
+  }
+  if (gi && gi->gi_part) {
+    p.gi_part = gi->gi_part; p.gi_part2 = gi->gi_part2; p.gi_gamma = gi->gi_gamma; p.gi_beta = gi->gi_beta;
+    p.gi_chunks = gi->gi_chunks; p.gi_chunks2 = gi->gi_chunks2; p.gi_G = gi->gi_G; p.gi_G1 = gi->gi_G1; p.gi_G2 = gi->gi_G2; p.gi_mr = gi->gi_mr;
+    p.gi_silu = gi->gi_silu; p.gi_eps = gi->gi_eps;
+    p.ktiles = (p.K + 63) / 64;
+    if (!gi_any_ok(p)) { tf_set_error("tf_conv2d_gn_f16: this geometry cannot carry the input GroupNorm (ask tf_conv2d_gn_supported first)"); return TF_E_UNSUPPORTED; }
+  }
   return run_gemm(p, workspace, workspace_bytes, g_force_bm, g_force_bn, g_force_split, tf_hs(s), gn_chunks);
+}
+
+int tf_conv2d_fused_norm_f16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
+                             const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
+                             void* workspace, size_t workspace_bytes, const void* x3, const void* x4, int C3, int C4, void* gn_partial,
+                             size_t gn_partial_bytes, int gn_groups, int* gn_chunks, void* z, const void* z_gamma, const void* z_beta, float z_eps,
+                             int z_silu, int* z_written, tfStream_t s) {
+  TF_REQUIRE(gn_partial && gn_chunks && z && z_written, "tf_conv2d_fused_norm_f16: gn_partial, gn_chunks, z and z_written must be given");
+  TF_REQUIRE((z_gamma == nullptr) == (z_beta == nullptr), "tf_conv2d_fused_norm_f16: gamma and beta must both be given or both NULL");
+  *z_written = 0;
+  GemmP ex = {};
+  ex.on_z = (half_t*)z; ex.on_gamma = (const half_t*)z_gamma; ex.on_beta = (const half_t*)z_beta; ex.on_eps = z_eps; ex.on_silu = z_silu ? 1 : 0;
+  ex.on_applied = z_written;
+  return conv2d_impl(y, x, x2, w, bias, bias_nc, bias_nc_stride, residual, N, H, W, C1, C2, Cout, R, S, stride, pad, upsample, workspace,
+                     workspace_bytes, (float*)gn_partial, gn_partial_bytes, gn_groups, gn_chunks, x3, x4, C3, C4, s, &ex);
+}
+
+int tf_conv2d_gn_supported(int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample, int C3, int C4, int in_groups) {
+  int Ho, Wo;
+  if (N < 1 || C1 < 1 || C2 < 0 || Cout < 1 || R != S || stride < 1 || in_groups < 1 || (C1 + C2) % in_groups) return 0;
+  if (conv_geometry(H, W, R, S, stride, pad, upsample ? 1 : 0, &Ho, &Wo)) return 0;
+  static float dummy;
+  GemmP p = {};
+  p.M = N * Ho * Wo; p.N = Cout; p.C1 = C1; p.C2 = C2; p.C = C1 + C2; p.Kc = R * S * p.C; p.K = p.Kc + C3 + C4; p.C3 = C3; p.C4 = C4;
+  p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.HoWo = Ho * Wo; p.S = S; p.stride = stride; p.pad = pad; p.ups = upsample ? 1 : 0;
+  p.gi_part = &dummy; p.gi_G = in_groups;
+  return gi_any_ok(p) ? 1 : 0;
+}
+
+int tf_conv2d_gn_f16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
+                     const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
+                     void* workspace, size_t workspace_bytes, const void* x3, const void* x4, int C3, int C4, void* gn_partial,
+                     size_t gn_partial_bytes, int gn_groups, int* gn_chunks, const void* in_gamma, const void* in_beta, const void* in_partial,
+                     int in_chunks, int in_groups1, const void* in_partial2, int in_chunks2, int in_groups2, int in_groups, float in_eps, int in_silu,
+                     tfStream_t s) {
+  TF_REQUIRE(!gn_partial || gn_chunks, "tf_conv2d_gn_f16: gn_chunks must be given with gn_partial");
+  TF_REQUIRE(in_partial && in_chunks >= 1 && in_chunks <= 4096 && in_groups >= 1 && (C1 + C2) % in_groups == 0, "tf_conv2d_gn_f16: input statistics missing (chunks=%d groups=%d)", in_chunks, in_groups);
+  TF_REQUIRE((in_gamma == nullptr) == (in_beta == nullptr), "tf_conv2d_gn_f16: gamma and beta must both be given or both NULL");
+  GemmP gi = {};
+  gi.gi_part = (const float*)in_partial; gi.gi_gamma = (const half_t*)in_gamma; gi.gi_beta = (const half_t*)in_beta;
+  gi.gi_chunks = in_chunks; gi.gi_G = in_groups; gi.gi_G1 = in_groups; gi.gi_mr = 1; gi.gi_eps = in_eps; gi.gi_silu = in_silu ? 1 : 0;
+  if (in_partial2) {
+    // concat (x, x2) whose statistics came with its two sources: partials of G1 sub-groups of x and G2 of x2, all of one width,
+    // mr adjacent sub-groups of the list [x's | x2's] form a group of the concat (tf_group_norm_apply_cat_f16's contract)
+    TF_REQUIRE(C2 > 0 && in_groups1 >= 1 && in_groups2 >= 1 && C1 % in_groups1 == 0 && C2 % in_groups2 == 0 && in_chunks2 >= 1 && in_chunks2 <= 4096,
+               "tf_conv2d_gn_f16: C1=%d C2=%d groups1=%d groups2=%d chunks2=%d", C1, C2, in_groups1, in_groups2, in_chunks2);
+    const int sub = C1 / in_groups1, cpg = (C1 + C2) / in_groups;
+    TF_REQUIRE(C2 / in_groups2 == sub && cpg % sub == 0 && cpg / sub <= 8, "tf_conv2d_gn_f16: the partials' sub-groups (%d and %d channels) do not tile the %d-channel groups", sub, C2 / in_groups2, cpg);
+    gi.gi_part2 = (const float*)in_partial2; gi.gi_chunks2 = in_chunks2; gi.gi_G1 = in_groups1; gi.gi_G2 = in_groups2; gi.gi_mr = cpg / sub;
+  }
+  return conv2d_impl(y, x, x2, w, bias, bias_nc, bias_nc_stride, residual, N, H, W, C1, C2, Cout, R, S, stride, pad, upsample, workspace,
+                     workspace_bytes, (float*)gn_partial, gn_partial_bytes, gn_groups, gn_chunks, x3, x4, C3, C4, s, &gi);
 }
 
 int tf_conv2d_f16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,

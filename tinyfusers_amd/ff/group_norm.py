@@ -51,4 +51,7 @@ class GroupNorm:
         self.bias = (asarray(np.zeros(num_channels, dtype=np.float16)) if init else None) if affine else None
 
     def __call__(self, x, silu=False):
+        nd = getattr(x, "normed", None)
+        if nd is not None and nd[0] is self and nd[1] == bool(silu):
+            return nd[2]                                 # the conv that produced x already applied this very norm (split-K reduce)
         return _gn(x, self.num_groups, self.eps, self.weight, self.bias, silu)

@@ -249,7 +249,7 @@ _NP = {"f16": np.float16, "f32": np.float32}
 
 class DeviceArray:
     """(ptr, logical shape, dtype, layout) handle.  layout: 'nhwc' (4-D, logical NCHW) or 'row'."""
-    __slots__ = ("ptr", "shape", "dtype", "layout", "_base", "_fin", "gn", "_uid", "_version", "__weakref__")
+    __slots__ = ("ptr", "shape", "dtype", "layout", "_base", "_fin", "gn", "normed", "_uid", "_version", "__weakref__")
     _next_uid = [0]
 
     def __init__(self, ptr, shape, dtype=np.float16, layout=None, base=None):
@@ -260,6 +260,7 @@ class DeviceArray:
         self._base = base
         self._fin = None
         self.gn = None       # (partials, chunks, groups): GroupNorm statistics emitted by the conv that produced this array
+        self.normed = None   # (GroupNorm module, silu, z): z = that module applied to this array, written by the producing conv's split-K reduce
         DeviceArray._next_uid[0] += 1
         self._uid, self._version = DeviceArray._next_uid[0], 0
 

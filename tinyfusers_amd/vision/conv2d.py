@@ -8,12 +8,67 @@ import operator
 
 import numpy as np
 
-from ..native import hip
+from .. import config
+from ..native import hip, lib
 from ..storage.tensor import DeviceArray, _sh, asarray
 from ..ff.linear import workspace, linear_f16
 
 
-def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, upsample=False, gn=0, extra=None, out=None):
+_gi_support = {}
+
+
+def _gn_in_args(x, x2, norm, k, r, s, stride, pad, up, c3, c4):
+    """Arguments of tf_conv2d_gn_f16 for applying GroupNorm ``norm`` to the conv's input inside the launch, or None when the
+    statistics did not come with the input(s) or the geometry cannot carry it (the caller then runs the norm on its own)."""
+    if not config.fuse_group_norm or x.gn is None or (x2 is not None and x2.gn is None) or k < 64:
+        return None
+    if r != 1 and not config.fuse_group_norm_3x3:
+        return None
+    n, c1, h, wd = x.shape
+    c2 = x2.shape[1] if x2 is not None else 0
+    G = norm.num_groups
+    if x2 is None:
+        if x.gn[2] != G:
+            return None
+        stats = (x.gn[0].ptr, x.gn[1], G, None, 0, 0)
+    else:
+        g1, g2 = x.gn[2], x2.gn[2]
+        cpg = (c1 + c2) // G
+        if not (config.concat_stats and c1 % g1 == 0 and c2 % g2 == 0 and c1 // g1 == c2 // g2 and cpg % (c1 // g1) == 0 and cpg // (c1 // g1) <= 8):
+            return None
+        stats = (x.gn[0].ptr, x.gn[1], g1, x2.gn[0].ptr, x2.gn[1], g2)
+    key = (n, h, wd, c1, c2, k, r, s, stride, pad, up, c3, c4, G)
+    ok = _gi_support.get(key)
+    if ok is None:
+        ok = _gi_support[key] = bool(lib.tf_conv2d_gn_supported(*key))
+    if not ok:
+        return None
+    return (norm.weight.ptr if norm.weight is not None else None, norm.bias.ptr if norm.bias is not None else None, *stats, G, float(norm.eps))
+
+
+def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, upsample=False, gn=0, extra=None, out=None, gn_in=None, out_norm=None):
+    """gn_in = (GroupNorm module, silu): the conv reads GroupNorm(x) [-> SiLU]; applied inside the conv launch when the statistics came
+    with x (x.gn) and the geometry allows (tf_conv2d_gn_f16), as a GroupNorm launch in front otherwise.
+    out_norm = (GroupNorm module, silu): the module that reads y next; when the shape runs split-K its reduce kernel also writes the
+    normalised tensor (y.normed), and that module's call returns it without a launch (tf_conv2d_fused_norm_f16)."""
+    if gn_in is not None:
+        norm, silu = gn_in
+        xa, xb = x if isinstance(x, (tuple, list)) else (x, None)
+        nd = xa.normed if xb is None else None
+        if nd is not None and nd[0] is norm and nd[1] == bool(silu):
+            return _conv(nd[2], w, bias, padding, stride, dilation, bias_nc, residual, upsample, gn, extra, out, None, out_norm)
+        if extra is not None:
+            kk, rr, ss = extra["cout"], extra["r"], extra["s"]
+            e3, e4 = extra["x"] if isinstance(extra["x"], (tuple, list)) else (extra["x"], None)
+            cc3, cc4 = e3.shape[1], (e4.shape[1] if e4 is not None else 0)
+        else:
+            kk, _, rr, ss = w.shape
+            cc3 = cc4 = 0
+        gi = _gn_in_args(xa, xb, norm, kk, rr, ss, stride[0], padding[0], 1 if upsample else 0, cc3, cc4) if not upsample else None
+        if gi is None:
+            return _conv(norm(x, silu=silu), w, bias, padding, stride, dilation, bias_nc, residual, upsample, gn, extra, out, None, out_norm)
+    else:
+        gi = None
     x2 = None
     if isinstance(x, (tuple, list)):
         x, x2 = x
@@ -46,7 +101,28 @@ def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, up
             bias_nc.ptr if bias_nc is not None else None, bnc_stride, residual.ptr if residual is not None else None,
             n, h, wd, c1, c2, k, r, s, stride[0], padding[0], up, ws.ptr if ws else None, nb)
     ex = (x3.ptr if x3 is not None else None, x4.ptr if x4 is not None else None, c3, c4)
-    if gn:
+    if gi is not None:
+        pb, part, chunks = 0, None, ctypes.c_int(0)
+        if gn:
+            pb = hip.tf_conv2d_gn_partial_bytes(n, gn)
+            part = workspace(pb)
+        hip.tf_conv2d_gn_f16(*args, *ex, part.ptr if part is not None else None, pb, gn, ctypes.byref(chunks), *gi, 1 if gn_in[1] else 0, _sh())
+        if chunks.value > 0:
+            y.gn = (part, chunks.value, gn)
+        y._base = (y._base, x.gn[0], x2.gn[0] if x2 is not None else None)   # the statistics stay referenced while the launch is queued
+    elif gn and out_norm is not None and config.fuse_reduce_norm and out_norm[0].num_groups == gn and out is None:
+        # ... and, behind a split-K shape, is applied by the reduce kernel as well: z rides along with y
+        pb = hip.tf_conv2d_gn_partial_bytes(n, gn)
+        part, chunks, zw = workspace(pb), ctypes.c_int(0), ctypes.c_int(0)
+        z = DeviceArray.empty((n, k, ho, wo), np.float16, "nhwc")
+        nm = out_norm[0]
+        hip.tf_conv2d_fused_norm_f16(*args, *ex, part.ptr, pb, gn, ctypes.byref(chunks), z.ptr, nm.weight.ptr if nm.weight is not None else None,
+                                     nm.bias.ptr if nm.bias is not None else None, float(nm.eps), 1 if out_norm[1] else 0, ctypes.byref(zw), _sh())
+        if chunks.value > 0:
+            y.gn = (part, chunks.value, gn)
+        if zw.value:
+            y.normed = (nm, bool(out_norm[1]), z)
+    elif gn:
         # the GroupNorm(gn) that consumes y next gets its statistics from this conv's epilogue (when the shape allows)
         pb = hip.tf_conv2d_gn_partial_bytes(n, gn)
         part, chunks = workspace(pb), ctypes.c_int(0)
@@ -136,18 +212,21 @@ class Conv2d:
             self._cache["fold_key"], self._cache["fold"] = key, (wp, bp)
         return self._cache["fold"]
 
-    def __call__(self, x, bias_nc=None, residual=None, upsample=False, gn=0, extra=None):
+    def __call__(self, x, bias_nc=None, residual=None, upsample=False, gn=0, extra=None, gn_in=None, out_norm=None):
         """gn = G: also emit the statistics of the output for the GroupNorm(G) that reads it next (y.gn).
-        extra = (proj, x3): add ``proj(x3)`` (a Conv2d 1x1; x3 a tensor or a concat pair) inside this conv's GEMM."""
+        extra = (proj, x3): add ``proj(x3)`` (a Conv2d 1x1; x3 a tensor or a concat pair) inside this conv's GEMM.
+        gn_in = (GroupNorm, silu): this conv reads GroupNorm(x) [-> SiLU] (x is the RAW tensor): one launch where possible."""
         if extra is not None:
             proj, x3 = extra
             wp, bp = self.fold_1x1(proj)
             k, _, r, s = self.weight.shape
             assert not isinstance(x, (tuple, list)) and x.shape[1] % 8 == 0
             return _conv(x, wp, bp, self.padding, self.stride, self.dilation, bias_nc, residual, upsample, gn,
-                         {"x": x3, "cout": k, "r": r, "s": s})
+                         {"x": x3, "cout": k, "r": r, "s": s}, gn_in=gn_in, out_norm=out_norm)
         cin = (x[0].shape[1] + x[1].shape[1]) if isinstance(x, (tuple, list)) else x.shape[1]
         if cin % 8 != 0:
             assert bias_nc is None and residual is None and not upsample
+            if gn_in is not None:
+                x = gn_in[0](x, silu=gn_in[1])
             return _conv_small_c(x, self.weight, self.bias, self.padding, self.stride, self._cache, gn)
-        return _conv(x, self.weight, self.bias, self.padding, self.stride, self.dilation, bias_nc, residual, upsample, gn)
+        return _conv(x, self.weight, self.bias, self.padding, self.stride, self.dilation, bias_nc, residual, upsample, gn, gn_in=gn_in, out_norm=out_norm)

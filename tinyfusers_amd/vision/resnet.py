@@ -27,29 +27,31 @@ class ResBlock:
         ]
         self.skip_connection = Conv2d(channels, out_channels, kernel_size=[1, 1], init=init) if channels != out_channels else lambda x: x
 
-    def __call__(self, x, emb, emb_out=None, out_gn=0):
-        """out_gn = G: the block's output is read next by a GroupNorm(G); its statistics ride on the last conv."""
+    def __call__(self, x, emb, emb_out=None, out_gn=0, out_norm=None):
+        """out_gn = G: the block's output is read next by a GroupNorm(G); its statistics ride on the last conv.
+        out_norm = (that GroupNorm, silu): where the last conv runs split-K, its reduce applies the norm as well."""
         br = None
         if config.parallel_branches and isinstance(self.skip_connection, Conv2d):
             br = Branch()                                              # the 1x1 skip projection only needs x: parallel branch
             with br:
                 skip = self.skip_connection(x)
-        h = self.in_layers[0](x, silu=True)
         if emb_out is None:
             emb_out = self.emb_layers[1](emb, silu_input=True)         # Linear(SiLU(emb)): (rows, Cout)
         g2 = self.out_layers[0].num_groups
-        h = self.in_layers[2](h, bias_nc=emb_out, gn=g2)               # conv + bias + emb[:, :, None, None] (+ stats for norm2)
-        h = self.out_layers[0](h, silu=True)
+        # GroupNorm -> SiLU -> conv as one launch (gn_in: the conv normalises its input patches in LDS) + bias + emb[:, :, None, None]
+        # (+ the statistics for norm2)
+        h = self.in_layers[2](x, bias_nc=emb_out, gn=g2, gn_in=(self.in_layers[0], True), out_norm=(self.out_layers[0], True))
+        n2 = (self.out_layers[0], True)
         if br is not None:
             br.join()
         elif config.fold_skip_projection and isinstance(self.skip_connection, Conv2d) and self.out_layers[3].weight.shape[0] % 8 == 0 \
                 and self.skip_connection.weight.shape[1] % 8 == 0:
             # skip_connection(x) + h in ONE GEMM: the 1x1 projection rides as extra K columns of the last conv
-            return self.out_layers[3](h, gn=out_gn, extra=(self.skip_connection, x))
+            return self.out_layers[3](h, gn=out_gn, extra=(self.skip_connection, x), gn_in=n2, out_norm=out_norm)
         else:
             skip = self.skip_connection(x)
         assert not isinstance(skip, (tuple, list)), "identity skip needs a single tensor (cin == cout)"
-        return self.out_layers[3](h, residual=skip, gn=out_gn)
+        return self.out_layers[3](h, residual=skip, gn=out_gn, gn_in=n2, out_norm=out_norm)
 
 
 class ResnetBlock:
@@ -62,6 +64,6 @@ class ResnetBlock:
         self.conv2 = Conv2d(out_channels, out_channels, kernel_size=[3, 3], padding=[1, 1], init=init)
         self.nin_shortcut = Conv2d(in_channels, out_channels, kernel_size=[1, 1], init=init) if in_channels != out_channels else lambda x: x
 
-    def __call__(self, x, out_gn=0):
-        h = self.conv1(self.norm1(x, silu=True), gn=self.norm2.num_groups)
-        return self.conv2(self.norm2(h, silu=True), residual=self.nin_shortcut(x), gn=out_gn)
+    def __call__(self, x, out_gn=0, out_norm=None):
+        h = self.conv1(x, gn=self.norm2.num_groups, gn_in=(self.norm1, True), out_norm=(self.norm2, True))
+        return self.conv2(h, residual=self.nin_shortcut(x), gn=out_gn, gn_in=(self.norm2, True), out_norm=out_norm)

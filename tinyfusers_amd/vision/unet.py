@@ -47,16 +47,16 @@ class Upsample:
     def __init__(self, channels, init=True):
         self.conv = Conv2d(channels, channels, kernel_size=[3, 3], padding=[1, 1], init=init)
 
-    def __call__(self, x, out_gn=0):
-        return self.conv(x, upsample=True, gn=out_gn)       # nearest-2x (unet.py:81-83) folded into the conv gather
+    def __call__(self, x, out_gn=0, out_norm=None):
+        return self.conv(x, upsample=True, gn=out_gn, out_norm=out_norm)       # nearest-2x (unet.py:81-83) folded into the conv gather
 
 
 class Downsample:
     def __init__(self, channels, init=True):
         self.op = Conv2d(channels, channels, stride=[2, 2], kernel_size=[3, 3], padding=[1, 1], init=init)
 
-    def __call__(self, x, out_gn=0):
-        return self.op(x, gn=out_gn)
+    def __call__(self, x, out_gn=0, out_norm=None):
+        return self.op(x, gn=out_gn, out_norm=out_norm)
 
 
 class StepParams:
@@ -175,16 +175,19 @@ class UNetModel:
             # with a GroupNorm, the statistics are produced by this module's last conv.  force_gn: the output (also) enters
             # an equal-split concat whose GroupNorm merges the two producers' partials (tf_group_norm_apply2_f16)
             gn = nxt.num_groups if isinstance(nxt, GroupNorm) else 32 if isinstance(nxt, (ResBlock, SpatialTransformer)) else force_gn
+            # ... and where that conv runs split-K its reduce applies the norm too: (the GroupNorm module that opens nxt, silu)
+            on = (nxt, True) if isinstance(nxt, GroupNorm) else (nxt.in_layers[0], True) if isinstance(nxt, ResBlock) \
+                else (nxt.norm, False) if isinstance(nxt, SpatialTransformer) else None
             if isinstance(bb, ResBlock):
                 off, n = bt["emb_off"][id(bb)]
-                return bb(x, emb, emb_out=emb_all.view((emb_all.shape[0], n), "row", off), out_gn=gn)
+                return bb(x, emb, emb_out=emb_all.view((emb_all.shape[0], n), "row", off), out_gn=gn, out_norm=on)
             if isinstance(bb, SpatialTransformer):
                 c = bb.proj_in.weight.shape[0]
-                return bb(x, context, kv=KVSlice(kv_all, bt["kv_off"][id(bb)], c, bt["kv_n"]), out_gn=gn)
+                return bb(x, context, kv=KVSlice(kv_all, bt["kv_off"][id(bb)], c, bt["kv_n"]), out_gn=gn, out_norm=on)
             if isinstance(bb, (Downsample, Upsample)):
-                return bb(x, out_gn=gn)
+                return bb(x, out_gn=gn, out_norm=on)
             if isinstance(bb, Conv2d):
-                return bb(x, gn=gn)                            # conv_in: its output feeds the first ResBlock's GroupNorm and the last skip concat
+                return bb(x, gn=gn, out_norm=on)               # conv_in: its output feeds the first ResBlock's GroupNorm and the last skip concat
             return bb(x)
 
         saved_inputs = []
