@@ -87,6 +87,27 @@ int tf_graph_abort_capture(tfStream_t s);
 int tf_graph_launch(tfGraph_t g, tfStream_t s);
 int tf_graph_destroy(tfGraph_t g);
 
+/* ---- fp8 (OCP e4m3) conv / linear path, BASELINE config 5 (SD1.5 768x768 batch 32 on 8 GPUs, "fp8 MFMA conv/linear path"); the ops
+ * extended are vision/conv2d.py:9-28 and ff/linear.py:112-121.  Weights: e4m3 with ONE fp32 scale per output channel, computed at pack
+ * time (tf_pack_weight_fp8: scale[n] = max|w[n,:]| / 448); activations: e4m3 with scale 1, written directly by the kernels that
+ * produce normalised tensors (tf_group_norm_apply_fp8, tf_layer_norm_fp8, the GEGLU epilogue of tf_linear_fp8) or by tf_quantize_fp8_f16;
+ * fp32 accumulate on v_mfma_f32_16x16x32_fp8_fp8, fp16 residual stream (bias / time embedding / residual adds and the output stay
+ * fp16).  Every channel count (conv) / K (linear) a multiple of 64.  x8 / x28 / w8 hold one byte per element in the layouts of the
+ * fp16 entries (NHWC, KRSC, row-major). */
+int tf_quantize_fp8_f16(void* y8, const void* x, long long n, float scale, tfStream_t s);
+int tf_pack_weight_fp8(void* w8, void* scale_f32, const void* w, int N, int K, tfStream_t s);
+size_t tf_conv2d_fp8_workspace(int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample);
+int tf_conv2d_fp8(void* y, const void* x8, const void* x28, const void* w8, const void* wscale, const void* bias, const void* bias_nc,
+                  long long bias_nc_stride, const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad,
+                  int upsample, void* workspace, size_t workspace_bytes, void* gn_partial, size_t gn_partial_bytes, int gn_groups, int* gn_chunks,
+                  tfStream_t s);
+int tf_linear_fp8(void* y, const void* x8, const void* w8, const void* wscale, const void* bias, const void* residual, int M, int N, int K, int act,
+                  int out_fp8, void* workspace, size_t workspace_bytes, tfStream_t s);
+int tf_group_norm_apply_fp8(void* y8, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial, int chunks,
+                            int groups1, const void* partial2, int chunks2, int groups2, int N, int HW, int C1, int C2, int G, float eps, int silu,
+                            tfStream_t s);
+int tf_layer_norm_fp8(void* y8, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s);
+
 /* ---- multi-GPU: one process per GPU, the path shards by image, and the only exchange is the one-off broadcast of
  * the packed weight arena.  The reference has no communication (device_id = 0, storage/device.py:23).  RCCL over xGMI, opened on
  * first use.  tf_comm_unique_id: rank 0 fills 128 bytes and hands them to the other ranks over any host channel; every rank then

@@ -1,0 +1,58 @@
+"""CPU emulation of the fp8 (OCP e4m3) conv / linear path of BASELINE config 5 -- TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+The reference has no fp8 path (it runs fp32 throughout, example/sd1.py:33); config 5 asks for one, gated at UNet rel-L2 <= 0.1 against
+the fp32 oracle.  This module restates the quantisation the HIP path applies so that (a) single ops can be
+checked tightly -- same e4m3 operands on both sides, fp32 accumulate -- and (b) the layer policy can be evaluated on the CPU:
+e4m3 weights with one scale per output channel (max|w| / 448), e4m3 activations with scale 1 (saturating), for the 3x3 convolutions
+with Cin, Cout >= 64 and the FeedForward linears; everything else as in oracle.unet."""
+import numpy as np
+import torch
+
+from . import ops
+
+F8 = torch.float8_e4m3fn
+
+
+def quant_act(t):
+    """activation operand as the HIP kernels store it: e4m3, scale 1, saturating at +-448, round to nearest even."""
+    return ops.as_t(t).clamp(-448.0, 448.0).to(F8).to(torch.float32)
+
+
+def quant_weight(w):
+    """(dequantised weight, scale per output channel): scale = max|w[n]| / 448, w8 = e4m3(w / scale)."""
+    w = ops.as_t(w)
+    s = w.reshape(w.shape[0], -1).abs().amax(1)
+    s = torch.where(s > 0, s / 448.0, torch.ones_like(s))
+    sh = (-1,) + (1,) * (w.dim() - 1)
+    return (w / s.reshape(sh)).to(F8).to(torch.float32) * s.reshape(sh), s
+
+
+def decode_e4m3(raw_u8):
+    """uint8 array of e4m3 bytes (as downloaded from the device) -> float32 array."""
+    return torch.from_numpy(np.ascontiguousarray(raw_u8, dtype=np.uint8)).view(F8).to(torch.float32).numpy()
+
+
+class policy:
+    """``with oracle.fp8.policy():`` makes oracle.unet_forward evaluate the fp8 layer policy (3x3 convs with Cin, Cout >= 64 and the
+    FeedForward linears on e4m3 operands).  Restores the fp32 functions on exit."""
+
+    def __enter__(self):
+        from . import unet as U
+        self._conv, self._ff = ops.conv2d_bias, U.feed_forward
+        conv0, lin0, geglu0 = ops.conv2d_bias, ops.linear, ops.geglu
+
+        def conv(x, w, b, padding=(0, 0), stride=(1, 1), dilation=(1, 1)):
+            w_ = ops.as_t(w)
+            if w_.shape[-1] == 3 and w_.shape[0] >= 64 and w_.shape[1] >= 64 and w_.shape[1] % 64 == 0:
+                return conv0(quant_act(x), quant_weight(w_)[0], b, padding, stride, dilation)
+            return conv0(x, w, b, padding, stride, dilation)
+
+        def ff(x, W, p):
+            h = geglu0(quant_act(x), quant_weight(W[p + ".net.0.proj.weight"])[0], W[p + ".net.0.proj.bias"])
+            return lin0(quant_act(h), quant_weight(W[p + ".net.2.weight"])[0], W[p + ".net.2.bias"])
+        ops.conv2d_bias, U.feed_forward = conv, ff
+        return self
+
+    def __exit__(self, *a):
+        from . import unet as U
+        ops.conv2d_bias, U.feed_forward = self._conv, self._ff

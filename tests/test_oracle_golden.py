@@ -175,3 +175,23 @@ def test_clip_text_transformer_vs_huggingface():
         want = model(input_ids=torch.from_numpy(ids)).last_hidden_state.numpy()
     got = oracle.clip_text_transformer(ids, W).numpy()
     close(got, want, rtol=2e-4, atol=5e-4)
+
+
+@pytest.mark.slow
+def test_fp8_layer_policy_meets_the_config5_gate_on_the_oracle():
+    """BASELINE config 5's precision gate (UNet rel-L2 <= 0.1 vs fp32) for the layer policy the HIP path implements: e4m3 operands for
+    the 3x3 convolutions (Cin, Cout >= 64) and the FeedForward linears, per-output-channel weight scales, activation scale 1 --
+    evaluated on the CPU oracle with e4m3 emulation (oracle/fp8.py)."""
+    import oracle
+    from oracle import fp8 as O8
+    from tinyfusers_amd.storage.synth import synth_normal, synth_state_dict
+    W = {k: torch.from_numpy(v.astype(np.float32)) for k, v in synth_state_dict(oracle.unet_param_shapes(oracle.SD15), 0).items()}
+    x = torch.from_numpy(synth_normal(1234, "sd.latent", (1, 4, 64, 64))).repeat(2, 1, 1, 1)
+    ctx = torch.from_numpy(np.concatenate([synth_normal(1234, "sd.uncond", (1, 77, 768)), synth_normal(1234, "sd.context", (1, 77, 768))]))
+    ref = oracle.unet_forward(x, np.array([981.0], np.float32), ctx, W)
+    with O8.policy():
+        got = oracle.unet_forward(x, np.array([981.0], np.float32), ctx, W)
+    again = oracle.unet_forward(x, np.array([981.0], np.float32), ctx, W)
+    assert torch.equal(again, ref)                         # the policy context restored the fp32 functions
+    rl2 = float((got - ref).norm() / ref.norm())
+    assert 0.01 < rl2 <= 0.1, rl2

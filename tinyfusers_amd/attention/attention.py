@@ -187,7 +187,7 @@ class SpatialTransformer:
         x_in = x
         x = self.proj_in(x, gn_in=(self.norm, False))    # GroupNorm -> 1x1 conv (attention.py:66-68) as one launch where the statistics came with x
         x = x.tokens()                                   # (b, hw, c): free re-view of NHWC (attention.py:71)
-        if config.fold_proj_out and c % 8 == 0 and self.proj_out.weight.shape[0] == c:
+        if config.fold_proj_out and config.dtype != "fp8" and c % 8 == 0 and self.proj_out.weight.shape[0] == c:   # (fp8: the FeedForward runs in e4m3, proj_out stays fp16)
             for block in self.transformer_blocks[:-1]:
                 x = block(x, context=context, kv=kv)
             hid, x2 = self.transformer_blocks[-1](x, context=context, kv=kv, defer_ff2=True)

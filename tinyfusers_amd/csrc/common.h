@@ -61,5 +61,16 @@ __device__ __forceinline__ float gelu_f(float x) {
   // 0.5 (1 + tanh(u)) = sigmoid(2u)
   return x * sigmoid_f(2.0f * u);
 }
+// 8 floats -> 8 OCP e4m3 bytes (saturating at +-448: v_cvt_pk_fp8_f32 itself does not clamp)
+__device__ __forceinline__ uint2 pack8_fp8(f4 v0, f4 v1) {
+  auto cl = [](float f) { return fminf(fmaxf(f, -448.0f), 448.0f); };
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(cl(v0[0]), cl(v0[1]), lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(cl(v0[2]), cl(v0[3]), lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(cl(v1[0]), cl(v1[1]), hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(cl(v1[2]), cl(v1[3]), hi, true);
+  return make_uint2((unsigned)lo, (unsigned)hi);
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }

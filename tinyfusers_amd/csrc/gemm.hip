@@ -59,6 +59,10 @@ struct GemmP {
   // GroupNorm (+ SiLU) of the OUTPUT applied by the split-K reduce (tf_conv2d_fused_norm_f16): when the shape runs split-K, the reduce
   // kernel owns whole (image, group) slabs, so it can finish the statistics AND write the normalised tensor z next to y
   half_t* on_z; const half_t* on_gamma; const half_t* on_beta; float on_eps; int on_silu; int* on_applied;
+  // fp8 (OCP e4m3) operands (k_igemm8, BASELINE config 5): x / x2 / w hold ONE byte per element, wscale[n] is the per-output-channel
+  // weight scale applied to the fp32 accumulators in the epilogue (activations use scale 1: normalised tensors); out8: y is stored as
+  // e4m3 as well (the GEGLU output that feeds the next fp8 GEMM)
+  const float* wscale; int out8, fp8;
 };
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;   // 128-bit buffer resource
@@ -261,7 +265,13 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rv[e]);
       }
-      *reinterpret_cast<h8*>(p.y + (long long)m * No + no) = o;
+      if (p.out8) {
+        f4 q0, q1;
+        for (int e = 0; e < 4; ++e) { q0[e] = (float)o[e]; q1[e] = (float)o[4 + e]; }
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.y) + (long long)m * No + no) = pack8_fp8(q0, q1);
+      } else {
+        *reinterpret_cast<h8*>(p.y + (long long)m * No + no) = o;
+      }
     }
     return;
   }
@@ -287,7 +297,8 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
       if (p.residual) { h8 b = *reinterpret_cast<const h8*>(p.residual + o); for (int e = 0; e < 4; ++e) { v0[e] += (float)b[e]; v1[e] += (float)b[4 + e]; } }
       h8 out;
       for (int e = 0; e < 4; ++e) { out[e] = (half_t)v0[e]; out[4 + e] = (half_t)v1[e]; }
-      *reinterpret_cast<h8*>(p.y + o) = out;
+      if (p.out8) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.y) + o) = pack8_fp8(v0, v1);
+      else *reinterpret_cast<h8*>(p.y + o) = out;
       if (p.gn_part) {   // the statistics pass below sums what the consumer will read: the fp16-rounded outputs
         float* rw = sc + row * RS + c8 * 8;
         for (int e = 0; e < 4; ++e) { v0[e] = (float)out[e]; v1[e] = (float)out[4 + e]; }
@@ -1198,6 +1209,220 @@ __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
   if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 0, lane);
 }
 
+// =====================================================================================================================
+// fp8 (OCP e4m3) variant, BASELINE config 5: same 4 loader + 4 consumer waves, LDS-DMA ring, raw barriers and epilogue as the deep
+// k_igemm, with one byte per operand element:
+//   * a K tile is still 64 elements = 64-BYTE rows, so a 1-KiB LDS-DMA piece covers 16 rows (lane -> row pair lane >> 3, half
+//     (lane >> 2) & 1, 16-byte chunk lane & 3) and a stage is (BM + BN) * 64 bytes: half the ingest per FLOP of the fp16 kernel, which
+//     is what bounds that one -- and room for a 256-row tile at 8 waves x 256 VGPRs;
+//   * swizzle for the 64-byte pitch: chunk ^ (-(row >> 2) & 3), conflict-free for the four 16-lane groups of a ds_read_b128
+//     (MI355X_MICROARCH.md, LDS table) -- applied on the source chunk by the loaders and again on the read;
+//   * ONE ds_read_b128 per 16-row fragment and K tile: lane group lg takes the 16 elements k = 16 lg .. 16 lg + 15, their low 8 bytes feed
+//     the first v_mfma_f32_16x16x32_fp8_fp8, the high 8 the second.  Both operands are cut the same way, so every k meets its partner
+//     (the MFMA sums over k in whatever order the lanes hold it);
+//   * the per-output-channel weight scale multiplies the fp32 accumulators before the shared epilogue (bias, time embedding, residual,
+//     GEGLU, GroupNorm statistics, split-K partials, optional e4m3 output).
+// Channel counts are multiples of 64 (taps and concat sources advance as wave-uniform scalars); no extra 1x1 segment, no LayerNorm fold.
+constexpr int ring_slots8(int bm, int bn) { int s = 163840 / ((bm + bn) * 64); return s > 8 ? 8 : s; }
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(512, 2) k_igemm8(const GemmP p) {
+  constexpr int TM = BM / 2, TN = BN / 2, MJ = TM / 16, NI = TN / 16;
+  constexpr int NG = (BM + BN) / 16;                      // 16-row staging pieces: activation rows first, then weight rows
+  constexpr int LPS = NG / 4;
+  constexpr int STAGE = (BM + BN) * 64;
+  constexpr int NS = ring_slots8(BM, BN);
+  static_assert(NG % 4 == 0 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
+  static_assert((NS - 2) * LPS <= 63, "vmcnt immediate is 6 bits");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned char* X = reinterpret_cast<const unsigned char*>(p.x);
+  const unsigned char* X2 = reinterpret_cast<const unsigned char*>(p.x2);
+  const unsigned char* Wt = reinterpret_cast<const unsigned char*>(p.w);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wid >= 4;
+  const int w4 = wid & 3;
+  const int ntiles = p.ntm * p.ntn;
+  const int nblk = ntiles * p.splitk;
+  int bid = blockIdx.x;
+  {
+    int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;      // XCD-aware order, as in k_igemm
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int split = bid / ntiles;
+  const int tid_ = bid - split * ntiles;
+  int tile_m, tile_n;
+  if (p.order == 0) { tile_m = tid_ / p.ntn; tile_n = tid_ - tile_m * p.ntn; }
+  else { tile_n = tid_ / p.ntm; tile_m = tid_ - tile_n * p.ntm; }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kt_begin = split * p.ktiles_per_split;
+  const int kt_end = min(p.ktiles, kt_begin + p.ktiles_per_split);
+  const int nt = kt_end - kt_begin;
+
+  if (loader) {
+    const rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, p.w_bytes, 0x00020000);
+    // lane -> row 2 (lane >> 3) + ((lane >> 2) & 1) of its 16-row piece, LDS chunk lane & 3; source chunk = LDS chunk ^ swizzle(row),
+    // swizzle(row) = -(row >> 2) & 3 = -(lane >> 4) & 3 for every piece (pieces start at multiples of 16 rows)
+    const int rin = 2 * (lane >> 3) + ((lane >> 2) & 1);
+    const int kc = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
+    int g_a[LPS], g_b[LPS], g_c[LPS];
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) {
+      const int row = 16 * (w4 + 4 * i) + rin;
+      g_a[i] = -(1 << 28); g_b[i] = 0; g_c[i] = (int)TF_OOB;
+      if (row < BM) {
+        int m = m0 + row;
+        if (m < p.M) {
+          int img = fast_div(m, p.dv_howo_mul, p.dv_howo_shr), rem = m - img * p.HoWo;
+          int ho = fast_div(rem, p.dv_wo_mul, p.dv_wo_shr), wo = rem - ho * p.Wo;
+          g_a[i] = ho * p.stride - p.pad;
+          g_b[i] = wo * p.stride - p.pad;
+          g_c[i] = img * p.H * p.W;
+        }
+      } else {
+        int n = n0 + row - BM;
+        if (n < p.N) g_c[i] = (int)((unsigned)n * (unsigned)p.K + (unsigned)kc * 16u);
+      }
+    }
+    const int Hl = p.H << p.ups, Wl = p.W << p.ups;
+    int st_r, st_s, st_c;
+    {
+      int kg0 = kt_begin * 64, tap = kg0 / p.C;
+      st_c = kg0 - tap * p.C;
+      st_r = tap / p.S;
+      st_s = tap - st_r * p.S;
+    }
+    auto stage = [&](int buf, int kt) {
+      char* base = smem + buf * STAGE;
+      const int r = st_r, s_ = st_s;
+      const bool second = st_c >= p.C1;
+      const int ld = second ? p.C2 : p.C1;
+      const int cc = (second ? st_c - p.C1 : st_c) + kc * 16;
+      st_c += 64;
+      if (st_c >= p.C) { st_c = 0; if (++st_s == p.S) { st_s = 0; ++st_r; } }
+      const rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? X2 : X), 0, second ? p.x2_bytes : p.x_bytes, 0x00020000);
+      const unsigned kb = (unsigned)kt * 64u;
+#pragma unroll
+      for (int i = 0; i < LPS; ++i) {
+        const int g = w4 + 4 * i;
+        char* dst = base + g * 1024;
+        if (g * 16 < BM) {
+          int hi = g_a[i] + r, wi = g_b[i] + s_;
+          bool ok = (unsigned)hi < (unsigned)Hl && (unsigned)wi < (unsigned)Wl;
+          int pix = g_c[i] + (hi >> p.ups) * p.W + (wi >> p.ups);
+          bload_lds16(rs_a, ok ? (unsigned)(pix * ld + cc) : TF_OOB, dst);
+        } else {
+          unsigned wo = (unsigned)g_c[i];
+          bload_lds16(rs_w, wo != TF_OOB ? wo + kb : TF_OOB, dst);
+        }
+      }
+    };
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_)
+      if (s_ < nt) stage(s_, kt_begin + s_);
+    wait_stages<LPS, NS - 1>(nt - 1);
+    __builtin_amdgcn_s_barrier();                         // barrier P
+    asm volatile("" ::: "memory");
+    for (int it = 0; it < nt; ++it) {
+      if (it + 1 < nt) wait_stages<LPS, NS - 2>(nt - 2 - it);
+      __builtin_amdgcn_s_barrier();                       // barrier(it)
+      asm volatile("" ::: "memory");
+      if (it + NS < nt) stage(it % NS, kt_begin + it + NS);
+    }
+    __builtin_amdgcn_s_barrier();                         // barrier X
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // barrier Y
+    asm volatile("" ::: "memory");
+    igemm_epilogue<BM, BN>(p, smem, m0, n0, split, w4, 1, lane);
+    if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 1, lane);
+    return;
+  }
+
+  // ================================= CONSUMER WAVES ===============================================
+  const int wave_m = w4 & 1, wave_n = w4 >> 1;
+  const int lr = lane & 15, lg = lane >> 4;
+  f4 acc[NI][MJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+  f4 wsc[NI];                                             // per-output-channel weight scales of this lane's 4 consecutive channels
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    int n = n0 + wave_n * TN + i * 16 + lg * 4;
+    wsc[i] = (f4){1.f, 1.f, 1.f, 1.f};
+    if (p.wscale) for (int e = 0; e < 4; ++e) if (n + e < p.N) wsc[i][e] = p.wscale[n + e];
+  }
+  int wa[NI], xa[MJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    int row = wave_n * TN + i * 16 + lr;
+    wa[i] = BM * 64 + row * 64 + ((lg ^ ((0 - (row >> 2)) & 3)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+    int row = wave_m * TM + j * 16 + lr;
+    xa[j] = row * 64 + ((lg ^ ((0 - (row >> 2)) & 3)) << 4);
+  }
+  typedef long l2v __attribute__((ext_vector_type(2)));
+  l2v wfA[NI], xfA[MJ], wfB[NI], xfB[MJ];
+  auto read_frags = [&](int slot, l2v (&wf)[NI], l2v (&xf)[MJ]) {
+    const char* sb = smem + slot * STAGE;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const l2v*>(sb + wa[i]);
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) xf[j] = *reinterpret_cast<const l2v*>(sb + xa[j]);
+  };
+  auto mma = [&](l2v (&wf)[NI], l2v (&xf)[MJ]) {
+    // both halves of a fragment pair back to back on the same accumulator (a 16x16x32 chain issues at the full rate on one
+    // accumulator): with the k halves as the outer loop the compiler ping-pongs the whole accumulator set between two register banks
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wf[i][0], xf[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wf[i][1], xf[j][1], acc[i][j], 0, 0, 0);
+      }
+  };
+  __builtin_amdgcn_s_barrier();                           // barrier P: tile 0 landed
+  asm volatile("" ::: "memory");
+  if (nt > 0) read_frags(0, wfA, xfA);
+  for (int it = 0; it < nt; it += 2) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // barrier(it): tile it+1 landed
+    asm volatile("" ::: "memory");
+    if (it + 1 < nt) read_frags((it + 1) % NS, wfB, xfB);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(wfA, xfA);
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + 1 >= nt) break;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // barrier(it+1)
+    asm volatile("" ::: "memory");
+    if (it + 2 < nt) read_frags((it + 2) % NS, wfA, xfA);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(wfB, xfB);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_s_barrier();                           // barrier X: every consumer is done with the ring
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) acc[i][j] *= wsc[i];
+  f4 csum[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) csum[i] = (f4){0.f, 0.f, 0.f, 0.f};
+  igemm_scratch_write<BM, BN>(p, acc, csum, smem, w4, lane);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                           // barrier Y
+  asm volatile("" ::: "memory");
+  igemm_epilogue<BM, BN>(p, smem, m0, n0, split, w4, 0, lane);
+  if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 0, lane);
+}
+
 // split-K reduce + epilogue: y[m,n] = sum_z partial[z,m,n] + bias + bias_nc + residual   (N % 4 == 0 fast path)
 __global__ void __launch_bounds__(256) k_splitk_reduce(half_t* __restrict__ y, const float* __restrict__ partial, const half_t* __restrict__ bias,
                                                        const half_t* __restrict__ bias_nc, const half_t* __restrict__ residual, int M, int N,
@@ -1430,6 +1655,37 @@ static bool rga_geometry(int HoWo, int N, int G, int* gpb, int* CV, int* RPS, si
   return true;
 }
 
+// ---- fp8 (OCP e4m3) packing for the config-5 path ---------------------------------------------------------------------------
+// activations: y8 = e4m3(x * scale), saturating (8 elements per thread, 16-byte loads / 8-byte stores)
+__global__ void __launch_bounds__(256) k_quantize_fp8(unsigned char* __restrict__ y, const half_t* __restrict__ x, float scale, long long n8) {
+  long long gs = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += gs) {
+    h8 v = *reinterpret_cast<const h8*>(x + i * 8);
+    f4 a, b;
+    for (int e = 0; e < 4; ++e) { a[e] = (float)v[e] * scale; b[e] = (float)v[4 + e] * scale; }
+    *reinterpret_cast<uint2*>(y + i * 8) = pack8_fp8(a, b);
+  }
+}
+// weights: one wave per output row n: scale[n] = max|w[n, :]| / 448 (1 for an all-zero row), w8[n, k] = e4m3(w[n, k] / scale[n])
+__global__ void __launch_bounds__(256) k_pack_weight_fp8(unsigned char* __restrict__ w8, float* __restrict__ scale, const half_t* __restrict__ w, int N, int K) {
+  int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+  int n = blockIdx.x * 4 + wv;
+  if (n >= N) return;
+  const half_t* wr = w + (long long)n * K;
+  float m = 0.f;
+  for (int k = l * 8; k < K; k += 512) { h8 v = *reinterpret_cast<const h8*>(wr + k); for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf((float)v[j])); }
+  m = wave_max(m);
+  const float sc = m > 0.f ? __fdiv_rn(m, 448.0f) : 1.0f;
+  if (l == 0) scale[n] = sc;
+  for (int k = l * 8; k < K; k += 512) {
+    h8 v = *reinterpret_cast<const h8*>(wr + k);
+    f4 a, b;
+    // a correctly rounded quotient (not w * (1 / scale)): a value on an e4m3 code boundary must round the way the definition says
+    for (int e = 0; e < 4; ++e) { a[e] = __fdiv_rn((float)v[e], sc); b[e] = __fdiv_rn((float)v[4 + e], sc); }
+    *reinterpret_cast<uint2*>(w8 + (long long)n * K + k) = pack8_fp8(a, b);
+  }
+}
+
 // ---- weight-streaming GEMV for M <= 8 (time-embedding MLP, ResBlock emb_layers): one wave per output row
 __global__ void __launch_bounds__(256) k_gemv(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ w,
                                               const half_t* __restrict__ bias, int M, int N, int K, int silu_in) {
@@ -1606,6 +1862,26 @@ static int launch_patch(const GemmP& p, hipStream_t st) {
   return TF_OK;
 }
 
+template <int BM, int BN>
+static int launch8(const GemmP& p, hipStream_t st) {
+  constexpr int TM = BM / 2, TN = BN / 2;
+  constexpr int ring = ring_slots8(BM, BN) * (BM + BN) * 64;
+  constexpr int scratch = 4 * TM * (TN + 4) * 4, tail = BM * 8 + 4 * BN * 8;
+  constexpr int smem = ring > scratch + tail ? ring : scratch + tail;
+  static_assert(smem <= 163840, "LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    TF_HIP(hipFuncSetAttribute((const void*)k_igemm8<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_igemm8<BM, BN>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+// (a 256x128 tile spills: the compiler keeps two copies of the accumulator set to issue the two k halves independently)
+static const int kTiles8[][2] = {{128, 128}, {64, 128}, {128, 64}, {256, 64}, {64, 64}};
+static const int kNumTiles8 = 5;
+
 static bool gemm_generic(const GemmP& p) { return (p.C1 % 64) != 0 || (p.C2 % 64) != 0 || (p.C3 % 64) != 0 || (p.C4 % 64) != 0; }
 template <int BM, int BN, bool WIDE_OK>
 static int launch_cfg(const GemmP& p, hipStream_t st, bool wide, bool all8 = false) {
@@ -1656,7 +1932,15 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
     if (p.splitk > 1) { p.gn_chunks = gn_reduce_chunks(p.HoWo); p.gn_part = nullptr; }
     else p.gn_chunks = gn_pieces(p, c.bn) * (p.HoWo / c.bm);
   }
-  if (variant == 2 && patch_setup(p, c.bm, c.bn)) {
+  if (p.fp8) {
+    if (c.bm == 128 && c.bn == 128) rc = launch8<128, 128>(p, st);
+    else if (c.bm == 64 && c.bn == 128) rc = launch8<64, 128>(p, st);
+    else if (c.bm == 128 && c.bn == 64) rc = launch8<128, 64>(p, st);
+    else if (c.bm == 256 && c.bn == 64) rc = launch8<256, 64>(p, st);
+    else if (c.bm == 64 && c.bn == 64) rc = launch8<64, 64>(p, st);
+    else { tf_set_error("run_gemm: no fp8 kernel for tile %dx%d", c.bm, c.bn); return TF_E_UNSUPPORTED; }
+  }
+  else if (variant == 2 && patch_setup(p, c.bm, c.bn)) {
     if (c.bm == 128 && c.bn == 160) rc = launch_patch<128, 160>(p, st);
     else if (c.bm == 64 && c.bn == 160) rc = launch_patch<64, 160>(p, st);
     else if (c.bm == 128 && c.bn == 128) rc = launch_patch<128, 128>(p, st);
@@ -1736,16 +2020,18 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
   float best = 1e30f;
   TunedCfg bc = {choose_tiles(p.M, p.N, p.K, p.act, true), 0, 0};
   if (p.gi_part) bc = gi_default(p);
-  for (int ci = 0; ci < 6; ++ci) {
-    int bm = cand[ci][0], bn = cand[ci][1];
+  for (int ci = 0; ci < (p.fp8 ? kNumTiles8 : 6); ++ci) {
+    int bm = p.fp8 ? kTiles8[ci][0] : cand[ci][0], bn = p.fp8 ? kTiles8[ci][1] : cand[ci][1];
     if (p.act == 1 && (bn % 64) != 0) continue;
-    if (bm == 128 && p.M <= 64) continue;
-    if (bn >= 128 && p.N <= 64 && ci != 5) continue;
+    if (bm >= 128 && p.M <= 64) continue;
+    if (bm == 256 && p.M <= 128) continue;
+    if (bn >= 128 && p.N <= 64) continue;
     for (int sk = 1; sk <= 32; sk *= 2) {
       if (sk > 1 && (p.act == 1 || p.ln_colsum || p.ktiles / sk < 4 || !workspace || (size_t)sk * p.M * p.N * 4 > workspace_bytes)) break;
       long long blocks = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * sk;
       if (sk > 1 && blocks > 1024) break;
       for (int wide = 0; wide < 4; ++wide) {                // the launch_one variants
+        if (p.fp8 && wide != 0) continue;                  // k_igemm8 has the deep ring only
         if (wide == 3 && gemm_generic(p)) continue;
         if (wide == 1 && (bm == 128 && bn == 160)) continue;
         if (wide == 1 && blocks <= 256) continue;          // two blocks per CU need more blocks than CUs
@@ -1793,13 +2079,18 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
   TunedCfg t = {choose_tiles(p.M, p.N, p.K, p.act, true), 0, 0};
   bool tuned = false;
   if (p.gi_part) { t = gi_default(p); tuned = true; }    // (tuned: keep gi_default's variant unless the tuner knows better)
+  if (p.fp8) {                                            // untuned fp8 default: the widest tile that still gives every CU a block
+    long long b128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    t.c = {p.M >= 128 ? 128 : 64, p.act == 1 || p.N >= 128 ? 128 : 64, b128 >= 128 ? 1 : t.c.splitk};
+    t.variant = 0; tuned = true;
+  }
   if (force_bm) {
     t.c = {force_bm, force_bn, force_split > 0 ? force_split : 1};
     t.order = g_force_order > 0 ? 1 : 0;
     if (p.gi_part) t.variant = p.S == 3 ? 2 : 0;
   } else if (g_autotune && !g_dbg) {
     std::array<int, 10> key = {p.M, p.N, p.K, p.C1, p.C2, p.S, p.stride, p.ups, p.act,
-                               (p.bias ? 1 : 0) | (p.residual ? 2 : 0) | (p.bias_nc ? 4 : 0) | (p.ln_colsum ? 8 : 0) | (p.gi_part ? 16 : 0) | (p.on_z ? 32 : 0)};
+                               (p.bias ? 1 : 0) | (p.residual ? 2 : 0) | (p.bias_nc ? 4 : 0) | (p.ln_colsum ? 8 : 0) | (p.gi_part ? 16 : 0) | (p.on_z ? 32 : 0) | (p.fp8 ? 64 : 0) | (p.out8 ? 128 : 0)};
     auto it = g_tuned.find(key);
     if (it != g_tuned.end()) { t = it->second; tuned = true; }
     else {
@@ -1891,7 +2182,9 @@ int tf_gemm_tune_load(const char* path) {
     for (int i = 0; i < 10; ++i) n += fscanf(f, "%d", &k[i]);
     n += fscanf(f, "%d %d %d %d %d", &bm, &bn, &sk, &wide, &order);
     if (n != 15) break;
-    bool ok = (bm == 64 || bm == 128) && (bn == 64 || bn == 128 || bn == 160) && sk >= 1 && sk <= 32;
+    const bool f8 = (k[9] & 64) != 0;
+    bool ok = (bm == 64 || bm == 128 || (f8 && bm == 256 && bn == 64)) && (bn == 64 || bn == 128 || (!f8 && bn == 160)) && sk >= 1 && sk <= 32;
+    if (f8 && wide != 0) ok = false;
     // rows the tuner itself never emits: GEGLU (act = 1) pairs 16-row value|gate blocks inside a wave tile (bn % 64 == 0), and
     // neither GEGLU nor the LayerNorm fold (flag bit 8) can be split along K
     const int act = k[8], ln = k[9] & 8;
@@ -2122,6 +2415,81 @@ int tf_linear_f16(void* y, const void* x, const void* w, const void* bias, const
     TF_REQUIRE(xb < (1LL << 31) && wb < (1LL << 31), "tf_linear_f16: tensors must be < 2 GiB each");
     p.x_bytes = (unsigned)xb; p.x2_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
   }
+  return run_gemm(p, workspace, workspace_bytes, g_force_bm, g_force_bn, g_force_split, tf_hs(s));
+}
+
+// ---- fp8 entries (config 5) ---------------------------------------------------------------------------------------------------
+int tf_quantize_fp8_f16(void* y8, const void* x, long long n, float scale, tfStream_t s) {
+  TF_REQUIRE(y8 && x && n >= 0 && n % 8 == 0, "tf_quantize_fp8_f16: n=%lld must be a multiple of 8", n);
+  if (n == 0) return TF_OK;
+  long long n8 = n / 8, grid = (n8 + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_quantize_fp8, dim3((unsigned)grid), dim3(256), 0, tf_hs(s), (unsigned char*)y8, (const half_t*)x, scale, n8);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_pack_weight_fp8(void* w8, void* scale_f32, const void* w, int N, int K, tfStream_t s) {
+  TF_REQUIRE(w8 && scale_f32 && w && N >= 1 && K >= 8 && K % 8 == 0, "tf_pack_weight_fp8: N=%d K=%d (K must be a multiple of 8)", N, K);
+  hipLaunchKernelGGL(k_pack_weight_fp8, dim3(ceil_div(N, 4)), dim3(256), 0, tf_hs(s), (unsigned char*)w8, (float*)scale_f32, (const half_t*)w, N, K);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+size_t tf_conv2d_fp8_workspace(int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample) {
+  return tf_conv2d_workspace(N, H, W, C1, C2, Cout, R, S, stride, pad, upsample);
+}
+int tf_conv2d_fp8(void* y, const void* x8, const void* x28, const void* w8, const void* wscale, const void* bias, const void* bias_nc,
+                  long long bias_nc_stride, const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad,
+                  int upsample, void* workspace, size_t workspace_bytes, void* gn_partial, size_t gn_partial_bytes, int gn_groups, int* gn_chunks,
+                  tfStream_t s) {
+  if (gn_chunks) *gn_chunks = 0;
+  TF_REQUIRE(y && x8 && w8 && wscale, "tf_conv2d_fp8: null tensor");
+  TF_REQUIRE(C1 > 0 && C2 >= 0 && (C2 == 0 || x28) && C1 % 64 == 0 && C2 % 64 == 0, "tf_conv2d_fp8: channel counts must be multiples of 64 (C1=%d C2=%d)", C1, C2);
+  TF_REQUIRE(R >= 1 && R == S && stride >= 1 && pad >= 0 && Cout >= 1 && N >= 0, "tf_conv2d_fp8: bad geometry R=%d S=%d stride=%d pad=%d", R, S, stride, pad);
+  TF_REQUIRE(!gn_partial || gn_chunks, "tf_conv2d_fp8: gn_chunks must be given with gn_partial");
+  int ups = upsample ? 1 : 0, Ho, Wo;
+  TF_REQUIRE(!conv_geometry(H, W, R, S, stride, pad, ups, &Ho, &Wo), "tf_conv2d_fp8: empty output for H=%d W=%d", H, W);
+  if (N == 0) return TF_OK;
+  TF_REQUIRE((long long)N * Ho * Wo < (1LL << 31), "tf_conv2d_fp8: problem too large for 32-bit indexing");
+  GemmP p = {};
+  p.fp8 = 1; p.wscale = (const float*)wscale;
+  p.x = (const half_t*)x8; p.x2 = (const half_t*)x28; p.w = (const half_t*)w8; p.y = (half_t*)y;
+  p.bias = (const half_t*)bias; p.bias_nc = (const half_t*)bias_nc; p.residual = (const half_t*)residual; p.bias_nc_stride = bias_nc_stride;
+  TF_REQUIRE(bias_nc_stride % 4 == 0 || Cout % 4 != 0, "tf_conv2d_fp8: bias_nc_stride must be a multiple of 4");
+  p.M = N * Ho * Wo; p.N = Cout; p.C1 = C1; p.C2 = C2; p.C = C1 + C2; p.Kc = R * S * p.C; p.K = p.Kc;
+  p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.HoWo = Ho * Wo; p.S = S; p.stride = stride; p.pad = pad; p.ups = ups;
+  {
+    long long xb = (long long)N * H * W * C1, x2b = (long long)N * H * W * C2, wb = (long long)Cout * p.K;
+    TF_REQUIRE(xb < (1LL << 31) && x2b < (1LL << 31) && wb < (1LL << 31), "tf_conv2d_fp8: tensors must be < 2 GiB each");
+    p.x_bytes = (unsigned)xb; p.x2_bytes = C2 ? (unsigned)x2b : (unsigned)xb; p.w_bytes = (unsigned)wb;
+    p.x3_bytes = p.x4_bytes = (unsigned)xb;
+  }
+  if (gn_partial) {
+    TF_REQUIRE(gn_groups >= 1 && Cout % gn_groups == 0, "tf_conv2d_fp8: Cout=%d not divisible by groups=%d", Cout, gn_groups);
+    TF_REQUIRE(gn_partial_bytes >= tf_conv2d_gn_partial_bytes(N, gn_groups), "tf_conv2d_fp8: statistics buffer too small (%zu bytes)", gn_partial_bytes);
+    int cpg = Cout / gn_groups;
+    if (cpg >= 4 && cpg <= 64 && Cout % 8 == 0 && Cout <= 4096 && gn_groups <= 256) { p.gn_part = (float*)gn_partial; p.gn_G = gn_groups; p.gn_cpg = cpg; }
+  }
+  return run_gemm(p, workspace, workspace_bytes, g_force_bm, g_force_bn, g_force_split, tf_hs(s), gn_chunks);
+}
+int tf_linear_fp8(void* y, const void* x8, const void* w8, const void* wscale, const void* bias, const void* residual, int M, int N, int K, int act,
+                  int out_fp8, void* workspace, size_t workspace_bytes, tfStream_t s) {
+  TF_REQUIRE(y && x8 && w8 && wscale, "tf_linear_fp8: null tensor");
+  TF_REQUIRE(M >= 0 && N >= 1 && K >= 64 && K % 64 == 0, "tf_linear_fp8: K=%d must be a positive multiple of 64", K);
+  TF_REQUIRE(act == 0 || act == 1, "tf_linear_fp8: act=%d", act);
+  TF_REQUIRE(act == 0 || (bias && N % 16 == 0), "tf_linear_fp8: GEGLU needs a bias and N %% 16 == 0 (N=%d)", N);
+  TF_REQUIRE(!out_fp8 || N % 8 == 0, "tf_linear_fp8: an e4m3 output needs N %% 8 == 0 (N=%d)", N);
+  if (M == 0) return TF_OK;
+  GemmP p = {};
+  p.fp8 = 1; p.wscale = (const float*)wscale; p.out8 = out_fp8 ? 1 : 0;
+  p.x = (const half_t*)x8; p.w = (const half_t*)w8; p.y = (half_t*)y; p.bias = (const half_t*)bias; p.residual = (const half_t*)residual;
+  p.M = M; p.N = act == 1 ? 2 * N : N; p.K = K; p.Kc = K; p.C1 = K; p.C2 = 0; p.C = K;
+  p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.HoWo = M; p.S = 1; p.stride = 1; p.pad = 0; p.ups = 0; p.act = act;
+  {
+    long long xb = (long long)M * K, wb = (long long)p.N * K;
+    TF_REQUIRE(xb < (1LL << 31) && wb < (1LL << 31), "tf_linear_fp8: tensors must be < 2 GiB each");
+    p.x_bytes = (unsigned)xb; p.x2_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb; p.x3_bytes = p.x4_bytes = (unsigned)xb;
+  }
+  if (p.out8) workspace = nullptr, workspace_bytes = 0;   // the split-K reduce writes fp16: an e4m3 output runs unsplit
   return run_gemm(p, workspace, workspace_bytes, g_force_bm, g_force_bn, g_force_split, tf_hs(s));
 }
 

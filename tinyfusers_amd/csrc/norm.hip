@@ -71,7 +71,7 @@ __global__ void k_gn_stats(float* __restrict__ partial, const half_t* __restrict
 __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ x2, const half_t* __restrict__ gamma,
                            const half_t* __restrict__ beta, const float* __restrict__ partial, int HW, int C1, int C2, int G, float eps,
                            int do_silu, int chunks, int pix_per_block, int CV, int RPB, const float* __restrict__ partial2, int chunks2,
-                           int G1, int G2, int mr) {
+                           int G1, int G2, int mr, int out8) {
   extern __shared__ float st[];  // [G][2] : mean, rstd
   int n = blockIdx.y;
   int C = C1 + C2, cpg = C / G;
@@ -163,9 +163,16 @@ __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x,
     int p = p0 + rr + i * RPB;
     if (p < p1) {
       h8 o;
+      f4 q0, q1;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { float f = (float)v[i][j] * a[j] + b[j]; o[j] = (half_t)(do_silu ? silu_f(f) : f); }
-      *reinterpret_cast<h8*>(yo + (long long)p * C) = o;
+      for (int j = 0; j < 8; ++j) {
+        float f = (float)v[i][j] * a[j] + b[j];
+        f = do_silu ? silu_f(f) : f;
+        o[j] = (half_t)f;
+        if (j < 4) q0[j] = f; else q1[j - 4] = f;
+      }
+      if (out8) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(y) + (long long)n * HW * C + c + (long long)p * C) = pack8_fp8(q0, q1);   // e4m3 operand of an fp8 conv
+      else *reinterpret_cast<h8*>(yo + (long long)p * C) = o;
     }
   }
 }
@@ -175,7 +182,7 @@ __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x,
 #define LN_MAXV 5
 template <int LPR>
 __global__ void __launch_bounds__(256) k_layer_norm(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ gamma,
-                                                    const half_t* __restrict__ beta, int rows, int C, float eps) {
+                                                    const half_t* __restrict__ beta, int rows, int C, float eps, int out8) {
   constexpr int RPW = 64 / LPR;                          // rows per wave
   int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   int row = (blockIdx.x * 4 + w) * RPW + l / LPR;
@@ -216,15 +223,17 @@ __global__ void __launch_bounds__(256) k_layer_norm(half_t* __restrict__ y, cons
     int cv = li + LPR * i;
     if (cv < CV) {
       h8 o;
+      f4 q0, q1;
       if (gamma) {
         h8 gm = *reinterpret_cast<const h8*>(gamma + cv * 8), bt = *reinterpret_cast<const h8*>(beta + cv * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)(((float)v[i][j] - mean) * rstd * (float)gm[j] + (float)bt[j]);
+        for (int j = 0; j < 8; ++j) { float f = ((float)v[i][j] - mean) * rstd * (float)gm[j] + (float)bt[j]; o[j] = (half_t)f; if (j < 4) q0[j] = f; else q1[j - 4] = f; }
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)(((float)v[i][j] - mean) * rstd);
+        for (int j = 0; j < 8; ++j) { float f = ((float)v[i][j] - mean) * rstd; o[j] = (half_t)f; if (j < 4) q0[j] = f; else q1[j - 4] = f; }
       }
-      *reinterpret_cast<h8*>(yr + cv * 8) = o;
+      if (out8) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(y) + (long long)row * C + cv * 8) = pack8_fp8(q0, q1);
+      else *reinterpret_cast<h8*>(yr + cv * 8) = o;
     }
   }
 }
@@ -327,7 +336,7 @@ int tf_group_norm_f16(void* y, const void* x, const void* x2, const void* gamma,
                      (const half_t*)x2, HW, C1, C2, G, chunks, ppc, CV, RPB);
   TF_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
-                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
+                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1, 0);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
@@ -344,14 +353,42 @@ int tf_group_norm_apply_f16(void* y, const void* x, const void* gamma, const voi
   gn_geometry(HW, C, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
   int tl = (threads + 7) & ~7;
   hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)nullptr,
-                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
+                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1, 0);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
 
+static int gn_apply_cat(void* y, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial, int chunks,
+                        int groups1, const void* partial2, int chunks2, int groups2, int N, int HW, int C1, int C2, int G, float eps, int silu,
+                        int out8, tfStream_t s);
 int tf_group_norm_apply_cat_f16(void* y, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial, int chunks,
                                 int groups1, const void* partial2, int chunks2, int groups2, int N, int HW, int C1, int C2, int G, float eps, int silu,
                                 tfStream_t s) {
+  return gn_apply_cat(y, x, x2, gamma, beta, partial, chunks, groups1, partial2, chunks2, groups2, N, HW, C1, C2, G, eps, silu, 0, s);
+}
+/* the same with an e4m3 (fp8) output -- the operand of an fp8 conv (config 5); x2 / partial2 may be NULL (single source: groups1 = G) */
+int tf_group_norm_apply_fp8(void* y8, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial, int chunks,
+                            int groups1, const void* partial2, int chunks2, int groups2, int N, int HW, int C1, int C2, int G, float eps, int silu,
+                            tfStream_t s) {
+  if (!x2) {
+    TF_REQUIRE(y8 && x && partial && C2 == 0 && groups1 == G, "tf_group_norm_apply_fp8: single source needs C2 = 0 and groups1 = G");
+    TF_REQUIRE((gamma == nullptr) == (beta == nullptr), "tf_group_norm_apply_fp8: gamma and beta must both be given or both NULL");
+    TF_REQUIRE(N >= 0 && HW >= 0 && G >= 1 && C1 > 0 && C1 % G == 0 && C1 % 8 == 0 && C1 / 8 <= 1024 && G <= 1024 && N <= 65535 && chunks >= 1 && chunks <= 4096,
+               "tf_group_norm_apply_fp8: C=%d G=%d N=%d chunks=%d", C1, G, N, chunks);
+    if (N == 0 || HW == 0) return TF_OK;
+    int CV, RPB, threads, sc, ppc, ablocks, appb;
+    gn_geometry(HW, C1, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
+    int tl = (threads + 7) & ~7;
+    hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y8, (const half_t*)x, (const half_t*)nullptr,
+                       (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1, 1);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+  }
+  return gn_apply_cat(y8, x, x2, gamma, beta, partial, chunks, groups1, partial2, chunks2, groups2, N, HW, C1, C2, G, eps, silu, 1, s);
+}
+static int gn_apply_cat(void* y, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial, int chunks,
+                        int groups1, const void* partial2, int chunks2, int groups2, int N, int HW, int C1, int C2, int G, float eps, int silu,
+                        int out8, tfStream_t s) {
   TF_REQUIRE(y && x && x2 && partial && partial2, "tf_group_norm_apply_cat_f16: null tensor");
   TF_REQUIRE((gamma == nullptr) == (beta == nullptr), "tf_group_norm_apply_cat_f16: gamma and beta must both be given or both NULL");
   const int C = C1 + C2;
@@ -368,7 +405,7 @@ int tf_group_norm_apply_cat_f16(void* y, const void* x, const void* x2, const vo
   int tl = (threads + 7) & ~7;
   hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
                      (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB,
-                     (const float*)partial2, chunks2, groups1, groups2, cpg / sub);
+                     (const float*)partial2, chunks2, groups1, groups2, cpg / sub, out8);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
@@ -379,7 +416,16 @@ int tf_group_norm_apply2_f16(void* y, const void* x, const void* x2, const void*
   return tf_group_norm_apply_cat_f16(y, x, x2, gamma, beta, partial, chunks, G, partial2, chunks2, G, N, HW, C1, C1, G, eps, silu, s);
 }
 
+static int layer_norm_impl(void* y, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, int out8, tfStream_t s);
 int tf_layer_norm_f16(void* y, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s) {
+  return layer_norm_impl(y, x, gamma, beta, rows, C, eps, 0, s);
+}
+/* LayerNorm with an e4m3 (fp8) output: the operand of an fp8 Linear (config 5's FeedForward); C a multiple of 8, <= 2560 */
+int tf_layer_norm_fp8(void* y8, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s) {
+  TF_REQUIRE(C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXV, "tf_layer_norm_fp8: C=%d must be a multiple of 8 and <= %d", C, 64 * 8 * LN_MAXV);
+  return layer_norm_impl(y8, x, gamma, beta, rows, C, eps, 1, s);
+}
+static int layer_norm_impl(void* y, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, int out8, tfStream_t s) {
   TF_REQUIRE(y && x && rows >= 0, "tf_layer_norm_f16: null tensor");
   TF_REQUIRE((gamma == nullptr) == (beta == nullptr), "tf_layer_norm_f16: gamma and beta must both be given or both NULL");
   TF_REQUIRE(C > 0, "tf_layer_norm_f16: C=%d", C);
@@ -396,7 +442,7 @@ int tf_layer_norm_f16(void* y, const void* x, const void* gamma, const void* bet
   int cv = C / 8;
 #define LN_LAUNCH(LPR_)                                                                                                            \
   hipLaunchKernelGGL(k_layer_norm<LPR_>, dim3(ceil_div(rows, 4 * (64 / LPR_))), dim3(256), 0, tf_hs(s), (half_t*)y, (const half_t*)x, \
-                     (const half_t*)gamma, (const half_t*)beta, rows, C, eps)
+                     (const half_t*)gamma, (const half_t*)beta, rows, C, eps, out8)
   // few rows: one wave per row (most waves in flight); many rows: several rows per wave (more loads per lane)
   if (rows < 8192 || cv > 32 * LN_MAXV) LN_LAUNCH(64);
   else if (cv <= 8 * LN_MAXV) LN_LAUNCH(8);

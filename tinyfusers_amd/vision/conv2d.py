@@ -224,6 +224,16 @@ class Conv2d:
             return _conv(x, wp, bp, self.padding, self.stride, self.dilation, bias_nc, residual, upsample, gn,
                          {"x": x3, "cout": k, "r": r, "s": s}, gn_in=gn_in, out_norm=out_norm)
         cin = (x[0].shape[1] + x[1].shape[1]) if isinstance(x, (tuple, list)) else x.shape[1]
+        from ..ff import fp8
+        if fp8.conv_eligible(self.weight.shape, [t.shape[1] for t in x] if isinstance(x, (tuple, list)) else [cin], extra):
+            # config 5: e4m3 operands.  The activation operand comes straight out of the GroupNorm apply (gn_in), or from one quantise
+            # pass over a raw tensor (up / down-sampling convs); bias / time embedding / residual / statistics as in the fp16 conv
+            w8, wsc = fp8.pack_weight(self.weight, self._cache)
+            if gn_in is not None:
+                x8 = fp8.group_norm_fp8(x, gn_in[0], gn_in[1])
+            else:
+                x8 = tuple(fp8.quantize(t) for t in x) if isinstance(x, (tuple, list)) else fp8.quantize(x)
+            return fp8.conv2d_fp8(x8, w8, wsc, self.bias, self.weight.shape, self.padding, self.stride, bias_nc, residual, upsample, gn)
         if cin % 8 != 0:
             assert bias_nc is None and residual is None and not upsample
             if gn_in is not None:
