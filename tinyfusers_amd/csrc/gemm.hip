@@ -1886,9 +1886,17 @@ static bool gemm_generic(const GemmP& p) { return (p.C1 % 64) != 0 || (p.C2 % 64
 template <int BM, int BN, bool WIDE_OK>
 static int launch_cfg(const GemmP& p, hipStream_t st, bool wide, bool all8 = false) {
   bool generic = gemm_generic(p);
-  if (all8 && !generic) return launch_cfg3<BM, BN, false, false, true>(p, st);
-  if (WIDE_OK && wide) return generic ? launch_cfg3<BM, BN, true, WIDE_OK>(p, st) : launch_cfg3<BM, BN, false, WIDE_OK>(p, st);
-  return generic ? launch_cfg3<BM, BN, true, false>(p, st) : launch_cfg3<BM, BN, false, false>(p, st);
+  // 128x160 sits at the 256-VGPR limit: its ALL8 and GENERIC forms spilled (5 / 3 VGPRs to scratch) and are not built -- ALL8 falls
+  // back to the plain deep ring there, channel counts off the 64 grid run the 128x128 tile (launch_one)
+  constexpr bool TIGHT = BM == 128 && BN == 160;
+  if constexpr (!TIGHT) {
+    if (all8 && !generic) return launch_cfg3<BM, BN, false, false, true>(p, st);
+    if (WIDE_OK && wide) return generic ? launch_cfg3<BM, BN, true, WIDE_OK>(p, st) : launch_cfg3<BM, BN, false, WIDE_OK>(p, st);
+    return generic ? launch_cfg3<BM, BN, true, false>(p, st) : launch_cfg3<BM, BN, false, false>(p, st);
+  } else {
+    if (generic) { tf_set_error("run_gemm: no 128x160 kernel for channel counts off the 64 grid"); return TF_E_UNSUPPORTED; }
+    return launch_cfg3<BM, BN, false, false>(p, st);
+  }
 }
 
 // GroupNorm of the input inside the launch (gi): which (tile, variant) can carry it.  3x3 / stride 1 / pad 1: the PATCH kernel only
@@ -1916,6 +1924,7 @@ static bool gi_any_ok(const GemmP& p) {
 static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspace, hipStream_t st) {
   int rc = 0;
   const bool wide = variant == 1, all8 = variant == 3;
+  if (c.bm == 128 && c.bn == 160 && gemm_generic(p)) c.bn = 128;      // (see launch_cfg: the GENERIC 128x160 instance is not built)
   if (p.gi_part && !gi_tile_ok(p, c.bm, c.bn, variant)) {
     tf_set_error("run_gemm: tile %dx%d variant %d cannot carry the input GroupNorm", c.bm, c.bn, variant);
     return TF_E_UNSUPPORTED;

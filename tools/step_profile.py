@@ -10,13 +10,20 @@ from tinyfusers_amd.storage.synth import synth_normal
 from tinyfusers_amd.variants.sd import StableDiffusion
 from bench import build_weight_arena
 
+# usage: step_profile.py [out.csv [images [latent [fp16|fp8 [tune-cache]]]]]
 out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/gemm_shapes.csv"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+from tinyfusers_amd import config
+config.set_dtype(sys.argv[4] if len(sys.argv) > 4 else "fp16")
+if len(sys.argv) > 5:
+    hip.tf_gemm_tune_load(sys.argv[5].encode())
 T.ensure_init(0)
 sd = StableDiffusion()
 arena = build_weight_arena(sd.model.diffusion_model, 0, 1, 0)
-lat = sd.latent_from_numpy(synth_normal(1234, "sd.latent", (1, 4, 64, 64)))
-ctx = T.DeviceArray.from_numpy(synth_normal(1234, "sd.context", (1, 77, 768)))
-unc = T.DeviceArray.from_numpy(synth_normal(1234, "sd.uncond", (1, 77, 768)))
+lat = sd.latent_from_numpy(synth_normal(1234, "sd.latent", (B, 4, S, S)))
+ctx = T.DeviceArray.from_numpy(synth_normal(1234, "sd.context", (B, 77, 768)))
+unc = T.DeviceArray.from_numpy(synth_normal(1234, "sd.uncond", (B, 77, 768)))
 sd.compile(unc, ctx, lat)
 lib.tf_prof_enable(1)
 for i in range(5):
