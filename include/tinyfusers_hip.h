@@ -329,6 +329,9 @@ int tf_cfg_duplicate_f16(void* x2b_nhwc, const void* latent_nchw_f32, int B, int
 /* e = e_u + g (e_c - e_u); DDIM sigma=0 update, latent updated in place (variants/sd.py:44-45, :14-25) */
 int tf_cfg_ddim_step_f32(void* latent_nchw_f32, const void* unet_out_2b_nhwc_f16, const void* step_params, int B, int C,
                          int H, int W, tfStream_t s);
+/* the same with the two UNet outputs in separate tensors (B,4,H,W each): the unconditional and the conditional half of the CFG pair
+ * (variants/sd.py:31-45) run as two independent UNet chains on two streams / graph branches (config.cfg_parallel) */
+int tf_cfg_ddim_step2_f32(void* latent, const void* eps_uncond, const void* eps_cond, const void* step_params, int B, int C, int H, int W, tfStream_t s);
 
 #ifdef __cplusplus
 }

@@ -303,16 +303,18 @@ __global__ void __launch_bounds__(EW_BLOCK) k_cfg_duplicate(half_t* __restrict__
   }
 }
 // e = e_u + g (e_c - e_u); pred_x0 = (x - sqrt(1-a_t) e)/sqrt(a_t); x' = sqrt(a_prev) pred_x0 + sqrt(1-a_prev) e
-__global__ void __launch_bounds__(EW_BLOCK) k_cfg_ddim(float* __restrict__ lat, const half_t* __restrict__ eps2, const float* __restrict__ params, int B, int C, int HW) {
+__global__ void __launch_bounds__(EW_BLOCK) k_cfg_ddim(float* __restrict__ lat, const half_t* __restrict__ eps2, const half_t* __restrict__ eps_c,
+                                                       const float* __restrict__ params, int B, int C, int HW) {
   float a_t = params[1], a_prev = params[2], g = params[3];
   float s1 = sqrtf(1.0f - a_t), r = sqrtf(a_t), sp = sqrtf(a_prev), dp = sqrtf(1.0f - a_prev);
   long long n = (long long)B * C * HW, gs = (long long)gridDim.x * EW_BLOCK;
+  if (!eps_c) eps_c = eps2 + n;                          // one (2B, ...) tensor [uncond x B ; cond x B], or the two halves apart
   for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += gs) {
     int hw = (int)(i % HW);
     long long q = i / HW;
     int c = (int)(q % C), b = (int)(q / C);
     long long j = ((long long)b * HW + hw) * C + c;
-    float eu = (float)eps2[j], ec = (float)eps2[n + j];
+    float eu = (float)eps2[j], ec = (float)eps_c[j];
     float e = eu + g * (ec - eu);
     float x = lat[i];
     float px0 = (x - s1 * e) / r;
@@ -590,7 +592,14 @@ int tf_cfg_duplicate_f16(void* x2b, const void* latent, int B, int C, int H, int
 int tf_cfg_ddim_step_f32(void* latent, const void* eps2, const void* params, int B, int C, int H, int W, tfStream_t s) {
   TF_REQUIRE(latent && eps2 && params && B > 0 && C > 0, "tf_cfg_ddim_step_f32: bad arguments");
   long long n = (long long)B * C * H * W;
-  hipLaunchKernelGGL(k_cfg_ddim, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (float*)latent, (const half_t*)eps2, (const float*)params, B, C, H * W);
+  hipLaunchKernelGGL(k_cfg_ddim, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (float*)latent, (const half_t*)eps2, (const half_t*)nullptr, (const float*)params, B, C, H * W);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_cfg_ddim_step2_f32(void* latent, const void* eps_uncond, const void* eps_cond, const void* params, int B, int C, int H, int W, tfStream_t s) {
+  TF_REQUIRE(latent && eps_uncond && eps_cond && params && B > 0 && C > 0, "tf_cfg_ddim_step2_f32: bad arguments");
+  long long n = (long long)B * C * H * W;
+  hipLaunchKernelGGL(k_cfg_ddim, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (float*)latent, (const half_t*)eps_uncond, (const half_t*)eps_cond, (const float*)params, B, C, H * W);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }

@@ -231,7 +231,7 @@ __device__ __forceinline__ void igemm_scratch_write(const GemmP& p, f4 (&acc)[BN
 }
 
 // all 8 waves: wave (w4, half) stores rows [half*TM/2, (half+1)*TM/2) of consumer w4's tile
-template <int BM, int BN>
+template <int BM, int BN, bool OUT8 = false>     // OUT8: the output is stored as e4m3 (k_igemm8 only; a template parameter keeps it out of the fp16 kernels)
 __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m0, int n0, int split, int w4, int half, int lane) {
   constexpr int TM = BM / 2, TN = BN / 2;
   const int wave_m = w4 & 1, wave_n = w4 >> 1;
@@ -265,7 +265,7 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rv[e]);
       }
-      if (p.out8) {
+      if constexpr (OUT8) {
         f4 q0, q1;
         for (int e = 0; e < 4; ++e) { q0[e] = (float)o[e]; q1[e] = (float)o[4 + e]; }
         *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.y) + (long long)m * No + no) = pack8_fp8(q0, q1);
@@ -297,7 +297,7 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
       if (p.residual) { h8 b = *reinterpret_cast<const h8*>(p.residual + o); for (int e = 0; e < 4; ++e) { v0[e] += (float)b[e]; v1[e] += (float)b[4 + e]; } }
       h8 out;
       for (int e = 0; e < 4; ++e) { out[e] = (half_t)v0[e]; out[4 + e] = (half_t)v1[e]; }
-      if (p.out8) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.y) + o) = pack8_fp8(v0, v1);
+      if constexpr (OUT8) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.y) + o) = pack8_fp8(v0, v1);
       else *reinterpret_cast<h8*>(p.y + o) = out;
       if (p.gn_part) {   // the statistics pass below sums what the consumer will read: the fp16-rounded outputs
         float* rw = sc + row * RS + c8 * 8;
@@ -385,7 +385,9 @@ __device__ __forceinline__ void igemm_gn_stats(const GemmP& p, char* smem, int m
 // that have loads outstanding, not by the pieces each keeps in flight (tools/ingest_waves.hip: 28 GB/s per CU with 4
 // issuing waves, 44-52 GB/s with 8), so the weight-bound shapes gain from eight issuing waves what the L2-resident ones
 // lose in MFMA issue slots; one of the autotuned variants.
-template <int BM, int BN, bool GENERIC, bool WIDE, bool ALL8 = false>
+// GI = true: the instance that can normalise its input (GemmP::gi_*); a template parameter so that the launches without it run the very
+// code they ran before the feature existed (its branches and SGPRs cost 3 % of the step when they sat in every instance)
+template <int BM, int BN, bool GENERIC, bool WIDE, bool ALL8 = false, bool GI = false>
 __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   constexpr int TM = BM / 2, TN = BN / 2, MJ = TM / 16, NI = TN / 16;
   constexpr int NG = (BM + BN) / 8;                       // 8-row staging groups: activation rows first, then weight rows
@@ -483,10 +485,9 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
     };
     // GroupNorm of the input (1x1 convolutions: k = input channel): normalise this wave's activation pieces of K tile kt where
     // they landed (LDS position lane -> source chunk cs), before the barrier that hands the tile to the consumers
-    constexpr bool GI_OK = !GENERIC && !(BM == 128 && BN == 160);   // (instances the host never launches with gi_part set)
-    const bool gi_on = GI_OK && p.gi_part != nullptr;
+    constexpr bool gi_on = GI;
     auto gi_tile = [&](int slot, int kt) {
-      if (!GI_OK || kt * 64 >= p.Kc) return;               // the extra 1x1 segment stays raw
+      if (!GI || kt * 64 >= p.Kc) return;                  // the extra 1x1 segment stays raw
       float ga[8], gb[8];
       gi_load_ab(p, smem, kt * 64 + cs * 8, ga, gb);
       const unsigned base = lds_off(smem + slot * STAGE) + lane * 16;
@@ -656,9 +657,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   }
 
   // ================================= CONSUMER WAVES ===============================================
-  if constexpr (!GENERIC && !(BM == 128 && BN == 160)) {
-    if (p.gi_part) gi_prologue(p, smem, m0 / p.HoWo, w4 * 64 + lane);   // first: its global loads must not wait behind this wave's own DMA (ALL8)
-  }
+  if constexpr (GI) gi_prologue(p, smem, m0 / p.HoWo, w4 * 64 + lane);   // first: its global loads must not wait behind this wave's own DMA (ALL8)
   const int wave_m = w4 & 1, wave_n = w4 >> 1;
   const int lr = lane & 15, lg = lane >> 4;
   f4 acc[NI][MJ];
@@ -666,13 +665,19 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < MJ; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
-  // LayerNorm fold: this lane's colsum values, fetched now so their latency hides under the K loop
+  // LayerNorm fold: this lane's colsum values, fetched now so their latency hides under the K loop -- except on the 128x160 tile,
+  // which sits at the 256-VGPR limit (20 registers held for the whole K loop made its ALL8 and GENERIC forms spill): there they are
+  // fetched in the epilogue (no LayerNorm-folded shape of the step runs that tile)
+  constexpr bool CSUM_LATE = BM == 128 && BN == 160;
   f4 csum[NI];
+  auto load_csum = [&]() {
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    int n = n0 + wave_n * TN + i * 16 + lg * 4;
-    csum[i] = (p.ln_colsum && n + 3 < p.N) ? *reinterpret_cast<const f4*>(p.ln_colsum + n) : (f4){0.f, 0.f, 0.f, 0.f};
-  }
+    for (int i = 0; i < NI; ++i) {
+      int n = n0 + wave_n * TN + i * 16 + lg * 4;
+      csum[i] = (p.ln_colsum && n + 3 < p.N) ? *reinterpret_cast<const f4*>(p.ln_colsum + n) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  if constexpr (!CSUM_LATE) load_csum();
   // fragment addresses inside a stage (swizzled chunk for k-step 0; k-step 1 is chunk ^ 4)
   int wa[NI], xa[MJ];
 #pragma unroll
@@ -806,6 +811,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
       for (int j = 0; j < MJ; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
+  if constexpr (CSUM_LATE) load_csum();
   if (p.ln_colsum) {
     __builtin_amdgcn_s_barrier();                         // barrier Z: the loaders' (mean, rstd) table is in LDS
     asm volatile("" ::: "memory");
@@ -915,7 +921,7 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {
 
 #define TF_PATCH_PPW 9     // patch pieces per loader wave at most (33 pieces: BM = 128, W = 64)
 
-template <int BM, int BN>
+template <int BM, int BN, bool GI = false>
 __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
   constexpr int TM = BM / 2, TN = BN / 2, MJ = TM / 16, NI = TN / 16;
   constexpr int BNP = BN / 32;                            // weight pieces per loader wave per K tile
@@ -1016,7 +1022,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
     };
     // GroupNorm (+ SiLU) of the input: every loader wave normalises the patch pieces IT staged (its own vmcnt covers their
     // landing), in LDS, once per piece instead of once per tap; padding pixels (pp < 0) stay zero
-    const bool gi_on = p.gi_part != nullptr;
+    constexpr bool gi_on = GI;
     float na[8], nb[8];
     int ab_group = -1;
     auto gi_piece = [&](int G, int v, int i) {            // piece w4 + 4 i of patch(G); v = pp[i]
@@ -1115,7 +1121,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
   }
 
   // ================================= CONSUMER WAVES ===============================================
-  if (p.gi_part) gi_prologue(p, smem, m0 / p.HoWo, w4 * 64 + lane);
+  if constexpr (GI) gi_prologue(p, smem, m0 / p.HoWo, w4 * 64 + lane);
   const int wave_m = w4 & 1, wave_n = w4 >> 1;
   const int lr = lane & 15, lg = lane >> 4;
   f4 acc[NI][MJ];
@@ -1335,7 +1341,8 @@ __global__ void __launch_bounds__(512, 2) k_igemm8(const GemmP p) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();                         // barrier Y
     asm volatile("" ::: "memory");
-    igemm_epilogue<BM, BN>(p, smem, m0, n0, split, w4, 1, lane);
+    if (p.out8) igemm_epilogue<BM, BN, true>(p, smem, m0, n0, split, w4, 1, lane);
+    else igemm_epilogue<BM, BN, false>(p, smem, m0, n0, split, w4, 1, lane);
     if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 1, lane);
     return;
   }
@@ -1419,7 +1426,8 @@ __global__ void __launch_bounds__(512, 2) k_igemm8(const GemmP p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                           // barrier Y
   asm volatile("" ::: "memory");
-  igemm_epilogue<BM, BN>(p, smem, m0, n0, split, w4, 0, lane);
+  if (p.out8) igemm_epilogue<BM, BN, true>(p, smem, m0, n0, split, w4, 0, lane);
+  else igemm_epilogue<BM, BN, false>(p, smem, m0, n0, split, w4, 0, lane);
   if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 0, lane);
 }
 
@@ -1818,10 +1826,19 @@ static int launch_cfg3(const GemmP& p, hipStream_t st) {
     GemmP q = p;
     q.gi_off = (smem + 15) & ~15;
     const int total = q.gi_off + gi_table_bytes(p);
-    if (GENERIC || (BM == 128 && BN == 160) || total > 163840) { tf_set_error("k_igemm<%d,%d>: no room for the GroupNorm table (%d B)", BM, BN, total); return TF_E_UNSUPPORTED; }
-    hipLaunchKernelGGL((k_igemm<BM, BN, GENERIC, WIDE, ALL8>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), total, st, q);
-    TF_LAUNCH_CHECK();
-    return TF_OK;
+    if constexpr (GENERIC || (BM == 128 && BN == 160)) {
+      tf_set_error("k_igemm<%d,%d>: this instance cannot carry the input GroupNorm", BM, BN); return TF_E_UNSUPPORTED;
+    } else {
+      if (total > 163840) { tf_set_error("k_igemm<%d,%d>: no room for the GroupNorm table (%d B)", BM, BN, total); return TF_E_UNSUPPORTED; }
+      static bool attr_gi = false;
+      if (!attr_gi) {
+        TF_HIP(hipFuncSetAttribute((const void*)k_igemm<BM, BN, GENERIC, WIDE, ALL8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        attr_gi = true;
+      }
+      hipLaunchKernelGGL((k_igemm<BM, BN, GENERIC, WIDE, ALL8, true>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), total, st, q);
+      TF_LAUNCH_CHECK();
+      return TF_OK;
+    }
   }
   hipLaunchKernelGGL((k_igemm<BM, BN, GENERIC, WIDE, ALL8>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
   TF_LAUNCH_CHECK();
@@ -1854,10 +1871,12 @@ static int launch_patch(const GemmP& p, hipStream_t st) {
   const int smem = ring > scratch + tail ? ring : scratch + tail;
   static bool attr_set = false;
   if (!attr_set) {
-    TF_HIP(hipFuncSetAttribute((const void*)k_igemm_patch<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    TF_HIP(hipFuncSetAttribute((const void*)k_igemm_patch<BM, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    TF_HIP(hipFuncSetAttribute((const void*)k_igemm_patch<BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_igemm_patch<BM, BN>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
+  if (p.gi_part) hipLaunchKernelGGL((k_igemm_patch<BM, BN, true>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
+  else hipLaunchKernelGGL((k_igemm_patch<BM, BN, false>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
@@ -1886,17 +1905,9 @@ static bool gemm_generic(const GemmP& p) { return (p.C1 % 64) != 0 || (p.C2 % 64
 template <int BM, int BN, bool WIDE_OK>
 static int launch_cfg(const GemmP& p, hipStream_t st, bool wide, bool all8 = false) {
   bool generic = gemm_generic(p);
-  // 128x160 sits at the 256-VGPR limit: its ALL8 and GENERIC forms spilled (5 / 3 VGPRs to scratch) and are not built -- ALL8 falls
-  // back to the plain deep ring there, channel counts off the 64 grid run the 128x128 tile (launch_one)
-  constexpr bool TIGHT = BM == 128 && BN == 160;
-  if constexpr (!TIGHT) {
-    if (all8 && !generic) return launch_cfg3<BM, BN, false, false, true>(p, st);
-    if (WIDE_OK && wide) return generic ? launch_cfg3<BM, BN, true, WIDE_OK>(p, st) : launch_cfg3<BM, BN, false, WIDE_OK>(p, st);
-    return generic ? launch_cfg3<BM, BN, true, false>(p, st) : launch_cfg3<BM, BN, false, false>(p, st);
-  } else {
-    if (generic) { tf_set_error("run_gemm: no 128x160 kernel for channel counts off the 64 grid"); return TF_E_UNSUPPORTED; }
-    return launch_cfg3<BM, BN, false, false>(p, st);
-  }
+  if (all8 && !generic) return launch_cfg3<BM, BN, false, false, true>(p, st);
+  if (WIDE_OK && wide) return generic ? launch_cfg3<BM, BN, true, WIDE_OK>(p, st) : launch_cfg3<BM, BN, false, WIDE_OK>(p, st);
+  return generic ? launch_cfg3<BM, BN, true, false>(p, st) : launch_cfg3<BM, BN, false, false>(p, st);
 }
 
 // GroupNorm of the input inside the launch (gi): which (tile, variant) can carry it.  3x3 / stride 1 / pad 1: the PATCH kernel only
@@ -1924,7 +1935,6 @@ static bool gi_any_ok(const GemmP& p) {
 static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspace, hipStream_t st) {
   int rc = 0;
   const bool wide = variant == 1, all8 = variant == 3;
-  if (c.bm == 128 && c.bn == 160 && gemm_generic(p)) c.bn = 128;      // (see launch_cfg: the GENERIC 128x160 instance is not built)
   if (p.gi_part && !gi_tile_ok(p, c.bm, c.bn, variant)) {
     tf_set_error("run_gemm: tile %dx%d variant %d cannot carry the input GroupNorm", c.bm, c.bn, variant);
     return TF_E_UNSUPPORTED;

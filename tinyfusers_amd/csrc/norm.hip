@@ -68,10 +68,11 @@ __global__ void k_gn_stats(float* __restrict__ partial, const half_t* __restrict
 // fixed order -> every block gets the same bits) -- cheaper than a separate finalize launch; then many small blocks
 // stream the tensor (the kernel is latency-bound otherwise).
 #define GN_APPLY_PPT 4
+template <bool OUT8>
 __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ x2, const half_t* __restrict__ gamma,
                            const half_t* __restrict__ beta, const float* __restrict__ partial, int HW, int C1, int C2, int G, float eps,
                            int do_silu, int chunks, int pix_per_block, int CV, int RPB, const float* __restrict__ partial2, int chunks2,
-                           int G1, int G2, int mr, int out8) {
+                           int G1, int G2, int mr) {
   extern __shared__ float st[];  // [G][2] : mean, rstd
   int n = blockIdx.y;
   int C = C1 + C2, cpg = C / G;
@@ -171,7 +172,7 @@ __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x,
         o[j] = (half_t)f;
         if (j < 4) q0[j] = f; else q1[j - 4] = f;
       }
-      if (out8) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(y) + (long long)n * HW * C + c + (long long)p * C) = pack8_fp8(q0, q1);   // e4m3 operand of an fp8 conv
+      if constexpr (OUT8) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(y) + (long long)n * HW * C + c + (long long)p * C) = pack8_fp8(q0, q1);   // e4m3 operand of an fp8 conv
       else *reinterpret_cast<h8*>(yo + (long long)p * C) = o;
     }
   }
@@ -335,8 +336,8 @@ int tf_group_norm_f16(void* y, const void* x, const void* x2, const void* gamma,
   hipLaunchKernelGGL(k_gn_stats, dim3(chunks, N), dim3(tl), (size_t)threads * 16 * sizeof(float), tf_hs(s), partial, (const half_t*)x,
                      (const half_t*)x2, HW, C1, C2, G, chunks, ppc, CV, RPB);
   TF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
-                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1, 0);
+  hipLaunchKernelGGL(k_gn_apply<false>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
+                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
@@ -352,8 +353,8 @@ int tf_group_norm_apply_f16(void* y, const void* x, const void* gamma, const voi
   int CV, RPB, threads, sc, ppc, ablocks, appb;
   gn_geometry(HW, C, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
   int tl = (threads + 7) & ~7;
-  hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)nullptr,
-                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1, 0);
+  hipLaunchKernelGGL(k_gn_apply<false>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)nullptr,
+                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
@@ -379,8 +380,8 @@ int tf_group_norm_apply_fp8(void* y8, const void* x, const void* x2, const void*
     int CV, RPB, threads, sc, ppc, ablocks, appb;
     gn_geometry(HW, C1, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
     int tl = (threads + 7) & ~7;
-    hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y8, (const half_t*)x, (const half_t*)nullptr,
-                       (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1, 1);
+    hipLaunchKernelGGL(k_gn_apply<true>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y8, (const half_t*)x, (const half_t*)nullptr,
+                       (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
     TF_LAUNCH_CHECK();
     return TF_OK;
   }
@@ -403,9 +404,12 @@ static int gn_apply_cat(void* y, const void* x, const void* x2, const void* gamm
   int CV, RPB, threads, sc, ppc, ablocks, appb;
   gn_geometry(HW, C, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
   int tl = (threads + 7) & ~7;
-  hipLaunchKernelGGL(k_gn_apply, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
-                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB,
-                     (const float*)partial2, chunks2, groups1, groups2, cpg / sub, out8);
+  if (out8) hipLaunchKernelGGL(k_gn_apply<true>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
+                               (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB,
+                               (const float*)partial2, chunks2, groups1, groups2, cpg / sub);
+  else hipLaunchKernelGGL(k_gn_apply<false>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
+                          (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB,
+                          (const float*)partial2, chunks2, groups1, groups2, cpg / sub);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }

@@ -15,8 +15,9 @@ from collections import namedtuple
 
 import numpy as np
 
+from .. import config
 from ..native import hip
-from ..storage.tensor import DeviceArray, Stream, _sh, asarray, pool, use_stream
+from ..storage.tensor import Branch, DeviceArray, Stream, _sh, asarray, pool, use_stream
 from ..vision.unet import SD15, StepParams, UNetModel
 
 
@@ -161,7 +162,22 @@ class StableDiffusion:
         b, c, h, w = self._latent.shape
         x2 = DeviceArray.empty((2 * b, c, h, w), np.float16, "nhwc")
         hip.tf_cfg_duplicate_f16(x2.ptr, self._latent.ptr, b, c, h, w, _sh())
-        out = self.model.diffusion_model(x2, sp, self._ctx2)
+        unet = self.model.diffusion_model
+        if config.cfg_parallel:
+            # the unconditional and the conditional half of the CFG pair (variants/sd.py:31-32) as two independent UNet chains: one runs
+            # as a side branch of the step (its own stream / graph branch), so the launch gaps and partly filled grids of one chain are
+            # covered by the other; what both share (time embedding, context K|V) is computed once in front of the fork
+            emb, emb_all, kv_all = unet.step_shared(sp, self._ctx2)
+            half = lambda a, i: a.view((b,) + a.shape[1:], a.layout, i * b * (a.size // a.shape[0])) if a is not None else None
+            br = Branch()
+            with br:
+                out_u = unet(half(x2, 0), sp, None, shared=(emb, emb_all, half(kv_all, 0)))
+            out_c = unet(half(x2, 1), sp, None, shared=(emb, emb_all, half(kv_all, 1)))
+            br.join()
+            hip.tf_cfg_ddim_step2_f32(self._latent.ptr, out_u.ptr, out_c.ptr, sp.dev.ptr, b, c, h, w, _sh())
+            self._keep = (x2, out_u, out_c, emb, emb_all, kv_all)
+            return
+        out = unet(x2, sp, self._ctx2)
         hip.tf_cfg_ddim_step_f32(self._latent.ptr, out.ptr, sp.dev.ptr, b, c, h, w, _sh())
         self._keep = (x2, out)      # graph nodes reference these blocks: keep them out of the pool
 

@@ -156,19 +156,33 @@ class UNetModel:
         self._batched = dict(key=key, emb_w=emb_w, emb_b=emb_b, emb_off=emb_off, kv_w=kv_w, kv_off=kv_off, kv_n=off)
         return self._batched
 
-    def __call__(self, x, timesteps=None, context=None):
+    def step_shared(self, timesteps, context):
+        """What one denoising step computes ONCE for every sample: the time-embedding chain (the same timestep for the whole batch) and
+        the cross-attention K|V projection of all contexts.  __call__ computes them itself unless handed the result (``shared``)."""
         cfg = self.cfg
         bt = self._prepare()
-        br = None
-        if config.parallel_branches and bt["kv_w"] is not None:
-            br = Branch()                          # the context projection is independent of the time-embedding chain
-            with br:
-                kv_all = linear_f16(context, bt["kv_w"])
         t_emb = timestep_embedding(timesteps, cfg.model_channels)
         emb = self.time_embed[2](self.time_embed[0](t_emb), silu_input=True)          # Linear -> SiLU -> Linear
         emb_all = gemv_f16(emb, bt["emb_w"], bt["emb_b"], silu_input=True)            # every ResBlock's Linear(SiLU(emb))
-        if br is None:
-            kv_all = linear_f16(context, bt["kv_w"]) if bt["kv_w"] is not None else None  # every attn2's K|V of the context
+        kv_all = linear_f16(context, bt["kv_w"]) if bt["kv_w"] is not None else None  # every attn2's K|V of the context
+        return emb, emb_all, kv_all
+
+    def __call__(self, x, timesteps=None, context=None, shared=None):
+        cfg = self.cfg
+        bt = self._prepare()
+        br = None
+        if shared is not None:
+            emb, emb_all, kv_all = shared          # kv_all: this call's rows (b, tk, kv_n) of the step-level projection
+        else:
+            if config.parallel_branches and bt["kv_w"] is not None:
+                br = Branch()                          # the context projection is independent of the time-embedding chain
+                with br:
+                    kv_all = linear_f16(context, bt["kv_w"])
+            t_emb = timestep_embedding(timesteps, cfg.model_channels)
+            emb = self.time_embed[2](self.time_embed[0](t_emb), silu_input=True)          # Linear -> SiLU -> Linear
+            emb_all = gemv_f16(emb, bt["emb_w"], bt["emb_b"], silu_input=True)            # every ResBlock's Linear(SiLU(emb))
+            if br is None:
+                kv_all = linear_f16(context, bt["kv_w"]) if bt["kv_w"] is not None else None  # every attn2's K|V of the context
 
         def run(x, bb, nxt, force_gn=0):
             # nxt = the module that reads this one's output as a single tensor (None across a concat): when it opens
