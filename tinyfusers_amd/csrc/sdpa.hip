@@ -303,6 +303,9 @@ constexpr int sdpa_v_skew(int ck) { return ck <= 18 ? 8 : ck <= 20 ? 2 : 8; }
 template <int HS>
 struct SdpaDma {
   static constexpr int DQK = (HS + 31) / 32 * 32, NKS = DQK / 32, NDT = (HS + 15) / 16, CK = HS / 8;
+  // HAS_PAD: the P.V tiles have spare columns (HS % 16 != 0, d = 40): column HS of the V image is preset to 1 in LDS and kept out of the
+  // DMA (EXEC-masked lanes write nothing), so the row sums come out of the P.V MFMAs themselves and the ones-MFMA (4 of 32 per tile) goes
+  static constexpr bool HAS_PAD = (HS % 16) != 0;
   static constexpr int KPC = sdpa_k_pitch(CK), VPC = sdpa_v_pitch(CK), VSC = sdpa_v_skew(CK);   // pitches / skew in 16-B chunks
   static constexpr int KP = KPC * 8, VP = VPC * 8, VSK = VSC * 8; // pitches / skew in halves
   static constexpr int VGC = 8 * VPC + VSC;                        // chunks per group of 8 V rows (rows + skew pad)
@@ -332,6 +335,14 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
 
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   for (int i = tid; i < S * STAGE_B / 16; i += 256) reinterpret_cast<u4*>(smem_raw)[i] = (u4){0, 0, 0, 0};
+  constexpr bool HAS_PAD = C::HAS_PAD;
+  if constexpr (HAS_PAD) {
+    __syncthreads();                     // ones column of V (column HS of every key row, every ring stage): written once
+    for (int i = tid; i < S * 64; i += 256) {
+      int st_ = i >> 6, R = i & 63;
+      reinterpret_cast<half_t*>(smem_raw + st_ * STAGE_B + C::K_BYTES)[(R >> 3) * VGC * 8 + (R & 7) * VP + HS] = (half_t)1.0f;
+    }
+  }
 
   h8 qf[QT][NKS];
 #pragma unroll
@@ -372,6 +383,7 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
       int x = 64 * (j - KPC) + lane, grp = x / VGC, rem = x - grp * VGC;
       int rr = rem / VPC, cc = rem - rr * VPC, r = 8 * grp + rr;
       voff[i] = (rr < 8 && grp < 8 && cc < CK) ? (unsigned)(r * (int)p.v_st + cc * 8) * 2u : 0x80000000u;
+      if (HAS_PAD && rr < 8 && grp < 8 && cc == CK) voff[i] = 0xFFFFFFFFu;     // the preset ones column: this lane stays out of the DMA
     }
   }
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
@@ -381,7 +393,8 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
     for (int i = 0; i < LPW; ++i) {
       int j = min(wid + 4 * i, NI - 1);
       if (j < KPC) sdpa_dma16(rs_k, voff[i] + (unsigned)tt * k_adv, base + j * 1024);
-      else sdpa_dma16(rs_v, voff[i] + (unsigned)tt * v_adv, base + j * 1024);
+      else if (!HAS_PAD) sdpa_dma16(rs_v, voff[i] + (unsigned)tt * v_adv, base + j * 1024);
+      else if (voff[i] != 0xFFFFFFFFu) sdpa_dma16(rs_v, voff[i] + (unsigned)tt * v_adv, base + j * 1024);   // (EXEC-masked: the skipped lanes write nothing)
     }
   };
 
@@ -481,10 +494,12 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) pf[kt >> 1][qt][(kt & 1) * 4 + e] = (half_t)__builtin_amdgcn_exp2f(st[kt][qt][e]);
+    if constexpr (!HAS_PAD) {
 #pragma unroll
-    for (int kc = 0; kc < 2; ++kc) {
+      for (int kc = 0; kc < 2; ++kc) {
 #pragma unroll
-      for (int q_ = 0; q_ < QT; ++q_) lt[q_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[kc][q_], lt[q_], 0, 0, 0);
+        for (int q_ = 0; q_ < QT; ++q_) lt[q_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[kc][q_], lt[q_], 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
@@ -503,7 +518,9 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
   half_t* ob = p.o + b * p.o_sb + h * p.o_sh;
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
+    // row sum: the ones-MFMA's accumulator, or row HS of O^T (the preset ones column of V): accumulator tile HS / 16, lane group (HS % 16) / 4
     float l = lt[qt][0];
+    if constexpr (HAS_PAD) l = __shfl(ot[(HS / 16) % NDT][qt][0], lr + 16 * ((HS % 16) / 4), 64);
     float inv = l > 0.f ? 1.0f / l : 0.f;
     int qi = qblk + qt * 16 + lr;
     if (qi < p.Tq) {

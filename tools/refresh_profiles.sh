@@ -21,6 +21,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_C
   -d $O/prof_sq --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-e2e > $O/prof_sq.log 2>&1
 python3 $R/tools/pmc_sq_summary.py $O/prof_sq $O/pmc_sq.json
 rm -rf $O/prof_stats $O/prof_fetch $O/prof_write $O/prof_sq
+[ -n "$QUICK" ] && { ls -la $O; exit 0; }      # QUICK=1: the bench line, kernel stats and PMC passes only
 # same-box A/B of the launch-floor fusions (ms per step, 60 graph-replayed steps each, two rounds), and of the round-1 library where a
 # worktree of it sits next to the repo (git worktree add _r01 <round-1 commit>; python -m tinyfusers_amd.build inside it)
 : > $O/ab_fusions.txt
