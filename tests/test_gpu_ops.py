@@ -784,12 +784,10 @@ def test_conv2d_split_k_reduce_applies_group_norm(tf, n, cin, hw, cout, k, force
     g = GroupNorm(32, cout, init=False); g.weight = dev(tf, gam, "row"); g.bias = dev(tf, bet, "row")
     from tinyfusers_amd import config
     lib.tf_gemm_force_config(*force)
-    config.fuse_reduce_norm = True
     try:
         y = m(dev(tf, x), bias_nc=dev(tf, e), residual=dev(tf, r), gn=32, out_norm=(g, silu))
     finally:
         lib.tf_gemm_force_config(0, 0, 0)
-        config.fuse_reduce_norm = False
     assert (y.normed is not None) == expect
     want_y = O.conv2d_bias(x, wt, b, (k // 2, k // 2)) + torch.from_numpy(e)[:, :, None, None] + torch.from_numpy(r)
     close(y.numpy(), want_y.numpy())

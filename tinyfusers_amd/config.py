@@ -51,10 +51,10 @@ fuse_group_norm_3x3 = _flag("TF_FUSE_GROUP_NORM_3X3", False)
 
 # conv -> GroupNorm (-> SiLU) behind a split-K shape: the reduce kernel that already owns the statistics also writes the normalised
 # tensor (k_splitk_reduce_gn_apply, tf_conv2d_fused_norm_f16).  False = reduce launch + GroupNorm-apply launch.
-# MEASURED (profiles/r02_ab_fusions.txt, same box, two rounds): the fused reduce runs 13.8 us against 8.0 + 10.8 us for the two launches it
-# replaces -- 33 of them per step -- yet the step is 0.03-0.05 ms SLOWER with it (64 blocks own whole (image, group) slabs and read the fp32
-# partials in 160-byte row segments; the GEMM in front is tuned with a penalty for unsplit shapes).  Kept, tested, off by default.
-fuse_reduce_norm = _flag("TF_FUSE_REDUCE_NORM", False)
+# MEASURED (profiles/r02_ab_fusions.txt, same box): 13.8 us per launch against 8.0 + 10.8 us for the two launches it replaces, 33 per step.
+# With its own tuner keys (and a penalty for unsplit shapes) the GEMMs in front moved to slower configurations and the step lost
+# 0.03-0.05 ms; with the plain keys (same tile as without it) the step gains 0.01 ms and 33 launches: on.
+fuse_reduce_norm = _flag("TF_FUSE_REDUCE_NORM", True)
 
 # Sampler: run the unconditional and the conditional half of the CFG pair as two independent UNet chains (batch B each) on two
 # streams / graph branches instead of one chain at batch 2B (StableDiffusion._eager_step).  Same arithmetic per sample.

@@ -2077,9 +2077,6 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
           }
           for (int i = 0; i < 5; ++i) for (int j = i + 1; j < 5; ++j) if (tv[j] < tv[i]) { float t = tv[i]; tv[i] = tv[j]; tv[j] = t; }
           float ms = tv[2];
-          // the output's GroupNorm is applied by the split-K reduce when there is one; a shape that runs unsplit needs the
-          // k_gn_apply launch behind it instead (8.5 us in the step, profiles/r01_kernel_stats_per_step.txt)
-          if (p.on_z && q.gn_part && sk == 1) ms += 0.0085f;
           if (ms < best) { best = ms; bc = {c, wide, order}; }
         }
       }
@@ -2109,7 +2106,7 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     if (p.gi_part) t.variant = p.S == 3 ? 2 : 0;
   } else if (g_autotune && !g_dbg) {
     std::array<int, 10> key = {p.M, p.N, p.K, p.C1, p.C2, p.S, p.stride, p.ups, p.act,
-                               (p.bias ? 1 : 0) | (p.residual ? 2 : 0) | (p.bias_nc ? 4 : 0) | (p.ln_colsum ? 8 : 0) | (p.gi_part ? 16 : 0) | (p.on_z ? 32 : 0) | (p.fp8 ? 64 : 0) | (p.out8 ? 128 : 0)};
+                               (p.bias ? 1 : 0) | (p.residual ? 2 : 0) | (p.bias_nc ? 4 : 0) | (p.ln_colsum ? 8 : 0) | (p.gi_part ? 16 : 0) | (p.fp8 ? 64 : 0) | (p.out8 ? 128 : 0)};   // (on_z shares the plain key: same tile, another reduce kernel)
     auto it = g_tuned.find(key);
     if (it != g_tuned.end()) { t = it->second; tuned = true; }
     else {
