@@ -716,7 +716,11 @@ def test_conv2d_with_input_group_norm_inside(tf, n, c1, c2, hw, cout, k, c3, sil
             continue
         x0 = rnd("gi.x" + tag, (n, 64, hw, hw)); w0 = rnd("gi.w" + tag, (c, 64, 3, 3), (64 * 9) ** -0.5); b0 = rnd("gi.b" + tag, (c,), 0.5)
         m0 = Conv2d(64, c, [3, 3], padding=[1, 1], init=False); m0.weight = dev(tf, w0); m0.bias = dev(tf, b0)
-        srcs.append(m0(dev(tf, x0), gn=(c // sub) if c2 else 32))
+        lib.tf_gemm_force_config(64, 64, 1)                # (a tile the statistics can ride on whatever the tuner would pick: m-tiles inside one image)
+        try:
+            srcs.append(m0(dev(tf, x0), gn=(c // sub) if c2 else 32))
+        finally:
+            lib.tf_gemm_force_config(0, 0, 0)
         assert srcs[-1].gn is not None
     C = c1 + c2
     gam = 1.0 + rnd("gi.g", (C,), 0.2); bet = rnd("gi.bt", (C,), 0.2)
@@ -805,3 +809,35 @@ def test_conv2d_split_k_reduce_applies_group_norm(tf, n, cin, hw, cout, k, force
     y.gn = None
     plain = g(y, silu=silu).numpy()
     np.testing.assert_allclose(plain, z.numpy(), atol=2e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("sk", [1, 2, 3])
+def test_256_row_tile_linear_and_conv(tf, sk):
+    """k_igemm<256, 128> (round 2: the tile for problems large enough to give every CU a 256 x 128 tile; fragments pipelined per 32-deep
+    k-step): exact small-integer linear with ragged M / N edges, and a 3x3 conv with bias, time embedding, residual and the GroupNorm
+    statistics of the output, vs the oracle."""
+    from oracle import ops as O
+    from tinyfusers_amd.native import hip, lib
+    from tinyfusers_amd.ff.group_norm import GroupNorm
+    from tinyfusers_amd.vision.conv2d import Conv2d
+    m, n, k = 777, 276, 448
+    rs = np.random.RandomState(6)
+    x = rs.randint(-3, 4, (m, k)).astype(np.float32); w = rs.randint(-2, 3, (n, k)).astype(np.float32); b = rs.randint(-4, 5, (n,)).astype(np.float32)
+    y = tf.DeviceArray.empty((m, n))
+    ws = tf.DeviceArray.empty((sk * m * n * 4 + 16,), np.uint8, "row")
+    lib.tf_gemm_force_config(256, 128, sk)
+    try:
+        hip.tf_linear_f16(y.ptr, dev(tf, x).ptr, dev(tf, w).ptr, dev(tf, b).ptr, None, m, n, k, 0, ws.ptr, ws.nbytes, None)
+        close(y.numpy(), x @ w.T + b, atol=0.5, rtol=1e-3)
+        nimg, cin, hw, cout = 2, 128, 32, 256
+        xc = rnd("t256.x", (nimg, cin, hw, hw)); wt = rnd("t256.w", (cout, cin, 3, 3), (cin * 9) ** -0.5); bc = rnd("t256.b", (cout,), 0.1)
+        e = rnd("t256.e", (nimg, cout), 0.5); r = rnd("t256.r", (nimg, cout, hw, hw))
+        conv = Conv2d(cin, cout, [3, 3], padding=[1, 1], init=False); conv.weight = dev(tf, wt); conv.bias = dev(tf, bc)
+        yc = conv(dev(tf, xc), bias_nc=dev(tf, e), residual=dev(tf, r), gn=32)
+    finally:
+        lib.tf_gemm_force_config(0, 0, 0)
+    want = O.conv2d_bias(xc, wt, bc, (1, 1)) + torch.from_numpy(e)[:, :, None, None] + torch.from_numpy(r)
+    close(yc.numpy(), want.numpy())
+    assert yc.gn is not None
+    g = GroupNorm(32, cout, init=False); g.weight = dev(tf, np.ones(cout, np.float32), "row"); g.bias = dev(tf, np.zeros(cout, np.float32), "row")
+    close(g(yc, silu=True).numpy(), O.silu(O.group_norm(torch.from_numpy(yc.numpy()), 32, 1e-5)).numpy())

@@ -712,7 +712,42 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
         bload_lds16(rs_cw, cw[i] != TF_OOB ? cw[i] + (unsigned)kt * 128u : TF_OOB, base + (NG - 4 * LPC + w4 + 4 * i) * 1024);
     }
   };
-  if (WIDE) {
+  if constexpr (BM == 256) {
+    // 256-row tile (large problems: every CU still gets tiles): the accumulators take 128 VGPRs, so the fragments are pipelined per
+    // 32-deep k-step instead of per K tile -- set A holds k-step 0, set B k-step 1 (48 VGPRs each): while the 32 MFMAs of one set issue,
+    // the 12 ds_read_b128 of the other are in flight.  Same barrier protocol as the deep ring (one per K tile).
+    static_assert(!WIDE && !ALL8 && !GENERIC && !GI, "the 256-row tile has the plain deep ring only");
+    h8 wfA[NI], xfA[MJ], wfB[NI], xfB[MJ];
+    auto read_k = [&](int slot, int k2, h8 (&wf)[NI], h8 (&xf)[MJ]) {
+      const char* sb = smem + slot * STAGE;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const h8*>(sb + (wa[i] ^ (k2 * 64)));
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) xf[j] = *reinterpret_cast<const h8*>(sb + (xa[j] ^ (k2 * 64)));
+    };
+    auto mma1 = [&](h8 (&wf)[NI], h8 (&xf)[MJ]) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    };
+    __builtin_amdgcn_s_barrier();                         // barrier P: tile 0 landed
+    asm volatile("" ::: "memory");
+    if (nt > 0) read_k(0, 0, wfA, xfA);
+    for (int it = 0; it < nt; ++it) {
+      read_k(it % NS, 1, wfB, xfB);                       // (it, k-step 1) in flight under the MFMAs of (it, k-step 0)
+      __builtin_amdgcn_sched_barrier(0);
+      mma1(wfA, xfA);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment of tile it is in registers: its slot may be refilled
+      __builtin_amdgcn_s_barrier();                       // barrier(it): tile it+1 landed
+      asm volatile("" ::: "memory");
+      if (it + 1 < nt) read_k((it + 1) % NS, 0, wfA, xfA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma1(wfB, xfB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if (WIDE) {
     for (int it = 0; it < nt; ++it) {
       __builtin_amdgcn_s_barrier();                       // barrier(it): tile it landed
       asm volatile("" ::: "memory");
@@ -1826,7 +1861,7 @@ static int launch_cfg3(const GemmP& p, hipStream_t st) {
     GemmP q = p;
     q.gi_off = (smem + 15) & ~15;
     const int total = q.gi_off + gi_table_bytes(p);
-    if constexpr (GENERIC || (BM == 128 && BN == 160)) {
+    if constexpr (GENERIC || (BM == 128 && BN == 160) || BM == 256) {
       tf_set_error("k_igemm<%d,%d>: this instance cannot carry the input GroupNorm", BM, BN); return TF_E_UNSUPPORTED;
     } else {
       if (total > 163840) { tf_set_error("k_igemm<%d,%d>: no room for the GroupNorm table (%d B)", BM, BN, total); return TF_E_UNSUPPORTED; }
@@ -1965,6 +2000,10 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
     else if (c.bm == 128 && c.bn == 128) rc = launch_patch<128, 128>(p, st);
     else rc = launch_patch<64, 128>(p, st);
   }
+  else if (c.bm == 256 && c.bn == 128) {
+    if (gemm_generic(p) || p.gi_part) { tf_set_error("run_gemm: the 256x128 tile needs channel counts on the 64 grid and no input GroupNorm"); return TF_E_UNSUPPORTED; }
+    rc = launch_cfg3<256, 128, false, false>(p, st);
+  }
   else if (c.bm == 128 && c.bn == 160) rc = launch_cfg<128, 160, false>(p, st, wide, all8);     // scratch 86 KB: one block per CU only
   else if (c.bm == 64 && c.bn == 160) rc = launch_cfg<64, 160, true>(p, st, wide, all8);
   else if (c.bm == 128 && c.bn == 128) rc = launch_cfg<128, 128, true>(p, st, wide, all8);
@@ -2033,24 +2072,26 @@ static TunedCfg gi_default(const GemmP& p) {
 static void* g_flush = nullptr;
 static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hipStream_t st, TunedCfg* out) {
   if (!g_flush) TF_HIP(hipMalloc(&g_flush, TF_FLUSH_BYTES));
-  static const int cand[][2] = {{128, 160}, {64, 160}, {128, 128}, {64, 128}, {128, 64}, {64, 64}};
+  static const int cand[][2] = {{128, 160}, {64, 160}, {128, 128}, {64, 128}, {128, 64}, {64, 64}, {256, 128}};
   hipEvent_t a, b;
   TF_HIP(hipEventCreate(&a)); TF_HIP(hipEventCreate(&b));
   float best = 1e30f;
   TunedCfg bc = {choose_tiles(p.M, p.N, p.K, p.act, true), 0, 0};
   if (p.gi_part) bc = gi_default(p);
-  for (int ci = 0; ci < (p.fp8 ? kNumTiles8 : 6); ++ci) {
+  for (int ci = 0; ci < (p.fp8 ? kNumTiles8 : 7); ++ci) {
     int bm = p.fp8 ? kTiles8[ci][0] : cand[ci][0], bn = p.fp8 ? kTiles8[ci][1] : cand[ci][1];
     if (p.act == 1 && (bn % 64) != 0) continue;
     if (bm >= 128 && p.M <= 64) continue;
     if (bm == 256 && p.M <= 128) continue;
+    // the 256x128 fp16 tile: plain deep ring, channel counts on the 64 grid, and only where it still leaves every CU a tile
+    if (!p.fp8 && bm == 256 && (gemm_generic(p) || p.gi_part || p.ln_colsum || (long long)((p.M + 255) / 256) * ((p.N + 127) / 128) < 256)) continue;
     if (bn >= 128 && p.N <= 64) continue;
     for (int sk = 1; sk <= 32; sk *= 2) {
       if (sk > 1 && (p.act == 1 || p.ln_colsum || p.ktiles / sk < 4 || !workspace || (size_t)sk * p.M * p.N * 4 > workspace_bytes)) break;
       long long blocks = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * sk;
       if (sk > 1 && blocks > 1024) break;
       for (int wide = 0; wide < 4; ++wide) {                // the launch_one variants
-        if (p.fp8 && wide != 0) continue;                  // k_igemm8 has the deep ring only
+        if ((p.fp8 || bm == 256) && wide != 0) continue;   // k_igemm8 and the 256-row tile have the deep ring only
         if (wide == 3 && gemm_generic(p)) continue;
         if (wide == 1 && (bm == 128 && bn == 160)) continue;
         if (wide == 1 && blocks <= 256) continue;          // two blocks per CU need more blocks than CUs
@@ -2199,8 +2240,9 @@ int tf_gemm_tune_load(const char* path) {
     n += fscanf(f, "%d %d %d %d %d", &bm, &bn, &sk, &wide, &order);
     if (n != 15) break;
     const bool f8 = (k[9] & 64) != 0;
-    bool ok = (bm == 64 || bm == 128 || (f8 && bm == 256 && bn == 64)) && (bn == 64 || bn == 128 || (!f8 && bn == 160)) && sk >= 1 && sk <= 32;
-    if (f8 && wide != 0) ok = false;
+    bool ok = (bm == 64 || bm == 128 || (f8 && bm == 256 && bn == 64) || (!f8 && bm == 256 && bn == 128)) && (bn == 64 || bn == 128 || (!f8 && bn == 160)) &&
+              sk >= 1 && sk <= 32;
+    if ((f8 || bm == 256) && wide != 0) ok = false;
     // rows the tuner itself never emits: GEGLU (act = 1) pairs 16-row value|gate blocks inside a wave tile (bn % 64 == 0), and
     // neither GEGLU nor the LayerNorm fold (flag bit 8) can be split along K
     const int act = k[8], ln = k[9] & 8;
