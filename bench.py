@@ -191,8 +191,8 @@ def build_weight_arena(unet, rank, world, device_index):
                 hip.tf_memcpy(base + offs[k], w.ctypes.data, w.nbytes, 1)
     t_gen = time.time() - t0
     t_bcast = 0.0
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         torch.cuda.synchronize()
         dist.barrier()
         t1 = time.time()
@@ -323,7 +323,7 @@ def main(argv=None):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` or give torch.distributed.run the same N")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
-    use_dist = in_group and world > 1
+    use_dist = in_group and (world > 1 or bool(os.environ.get("TF_BENCH_FORCE_DIST")))    # (FORCE: rehearse the RCCL path with one rank on a one-GPU box)
     if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)

@@ -42,7 +42,7 @@ def pack_tensor(w):
 def broadcast_arena(arena, src=0):
     """The one collective of the path: broadcast the packed weight arena (a 1-D uint8 torch tensor)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("TF_BENCH_FORCE_DIST")):
         dist.broadcast(arena, src=src)
     return arena
 
