@@ -84,6 +84,15 @@ __device__ __forceinline__ void bload_lds16(rsrc_t rsrc, unsigned voffset_bytes,
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset_bytes, 0, 0, 0);
 }
 
+// s_waitcnt lgkmcnt(0) of the consumers' K loop as the BUILTIN (simm16 0xC07F: vmcnt 63, expcnt 7, lgkmcnt 0), not inline asm: the
+// compiler's own wait-count pass cannot see inside an asm string, so with the asm form it assumed the fragments read one tile earlier
+// could still be in flight and put s_waitcnt lgkmcnt(8 / 1 / 0) INSIDE the MFMA block -- which waits for the ds_reads of the NEXT tile
+// issued just before it (LDS returns in order) and serialises the LDS reads with the MFMAs they were meant to hide under.
+__device__ __forceinline__ void wait_lds_reads() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  asm volatile("" ::: "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -739,7 +748,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
       __builtin_amdgcn_sched_barrier(0);
       mma1(wfA, xfA);
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment of tile it is in registers: its slot may be refilled
+      wait_lds_reads();  // every fragment of tile it is in registers: its slot may be refilled
       __builtin_amdgcn_s_barrier();                       // barrier(it): tile it+1 landed
       asm volatile("" ::: "memory");
       if (it + 1 < nt) read_k((it + 1) % NS, 0, wfA, xfA);
@@ -816,7 +825,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   asm volatile("" ::: "memory");
   if (nt > 0) read_frags(0, wfA, xfA);
   for (int it = 0; it < nt; it += 2) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // fragments of tile it are in registers: its slot may be refilled
+    wait_lds_reads();    // fragments of tile it are in registers: its slot may be refilled
     if constexpr (ALL8) { if (it + 1 < nt) wait_stages<LPC, NS - 2>(nt - 2 - it); }   // ... and this wave's pieces of tile it+1 landed
     __builtin_amdgcn_s_barrier();                         // barrier(it): tile it+1 landed
     asm volatile("" ::: "memory");
@@ -826,7 +835,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
     mma(wfA, xfA);
     __builtin_amdgcn_sched_barrier(0);
     if (it + 1 >= nt) break;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_lds_reads();
     if constexpr (ALL8) { if (it + 2 < nt) wait_stages<LPC, NS - 2>(nt - 3 - it); }
     __builtin_amdgcn_s_barrier();                         // barrier(it+1)
     asm volatile("" ::: "memory");
@@ -1224,7 +1233,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
   int rslot = 0;
   if (nt > 0) { read_frags(0, wfA, xfA); rslot = 1; }
   for (int it = 0; it < nt; it += 2) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_lds_reads();
     __builtin_amdgcn_s_barrier();                         // barrier(it): tile it+1 landed
     asm volatile("" ::: "memory");
     if (it + 1 < nt) { read_frags(rslot, wfB, xfB); if (++rslot == NS) rslot = 0; }
@@ -1232,7 +1241,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
     mma(wfA, xfA);
     __builtin_amdgcn_sched_barrier(0);
     if (it + 1 >= nt) break;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_lds_reads();
     __builtin_amdgcn_s_barrier();                         // barrier(it+1)
     asm volatile("" ::: "memory");
     if (it + 2 < nt) { read_frags(rslot, wfA, xfA); if (++rslot == NS) rslot = 0; }
@@ -1432,7 +1441,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm8(const GemmP p) {
   asm volatile("" ::: "memory");
   if (nt > 0) read_frags(0, wfA, xfA);
   for (int it = 0; it < nt; it += 2) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_lds_reads();
     __builtin_amdgcn_s_barrier();                         // barrier(it): tile it+1 landed
     asm volatile("" ::: "memory");
     if (it + 1 < nt) read_frags((it + 1) % NS, wfB, xfB);
@@ -1440,7 +1449,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm8(const GemmP p) {
     mma(wfA, xfA);
     __builtin_amdgcn_sched_barrier(0);
     if (it + 1 >= nt) break;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_lds_reads();
     __builtin_amdgcn_s_barrier();                         // barrier(it+1)
     asm volatile("" ::: "memory");
     if (it + 2 < nt) read_frags((it + 2) % NS, wfA, xfA);

@@ -34,7 +34,7 @@ if [ -d $R/_r01 ]; then
   done
 fi
 for i in 1 2; do
-  for cfg in "" "TF_FUSE_GROUP_NORM=0" "TF_FUSE_REDUCE_NORM=1" "TF_FUSE_GROUP_NORM_3X3=1" "TF_CFG_PARALLEL=1"; do
+  for cfg in "" "TF_FUSE_GROUP_NORM=0" "TF_FUSE_REDUCE_NORM=0" "TF_FUSE_GROUP_NORM_3X3=1" "TF_CFG_PARALLEL=1"; do
     v=$(env $cfg python3 $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-roofline --no-e2e 2>/dev/null | tail -1 | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])")
     echo "round $i  ${cfg:-default (GroupNorm inside the 1x1 convs only)}: $v ms/step" >> $O/ab_fusions.txt
   done
