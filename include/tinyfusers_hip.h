@@ -289,6 +289,22 @@ int tf_group_norm_apply_cat_f16(void* y, const void* x, const void* x2, const vo
 /* LayerNorm over the last dim (ff/layer_norm.py:8-32, :34-49; semantics = F.layer_norm, tests/layer_norm.py:38) */
 int tf_layer_norm_f16(void* y, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s);
 
+/* ---- bfloat16 forms ---------------------------------------------------------------------------
+ * The reference's op tests run every case in bfloat16 as well as float16 (tests/group_norm.py:12-19 and
+ * tests/layer_norm.py:13-27 with atol = rtol = 0.125; tests/linear.py:13 lists it): the same four operators with every
+ * 16-bit tensor (x, x2, w, gamma, beta, bias, residual, y) holding bfloat16.  Statistics and accumulation are fp32 as
+ * in the float16 forms; the GEMMs use the gfx950 bf16 MFMA (v_mfma_f32_16x16x32_bf16), one launch, no split-K.
+ * The UNet step itself stays float16 (the reference's weights and activations are float16, storage/tensor.py). */
+int tf_group_norm_bf16(void* y, const void* x, const void* x2, const void* gamma, const void* beta, int N, int HW,
+                       int C1, int C2, int G, float eps, int silu, void* workspace, size_t workspace_bytes, tfStream_t s);
+int tf_layer_norm_bf16(void* y, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s);
+/* y(M,N) = x(M,K) . w(N,K)^T + bias(N) + residual(M,N)   (ff/linear.py:112-121) */
+int tf_linear_bf16(void* y, const void* x, const void* w, const void* bias, const void* residual, int M, int N, int K, tfStream_t s);
+/* tf_conv2d_f16's arguments without the workspace (vision/conv2d.py:9-28): NHWC x (+ concat x2), w (Cout, R, S, C1 + C2) */
+int tf_conv2d_bf16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
+                   const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
+                   tfStream_t s);
+
 /* ---- elementwise (storage/tensor.py:64-86; ff/nn.py:10-12; vision/unet.py:72, :81-83) ---------- */
 int tf_silu_f16(void* y, const void* x, long long n, tfStream_t s);
 int tf_sigmoid_f16(void* y, const void* x, long long n, tfStream_t s);

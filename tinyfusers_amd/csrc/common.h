@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 typedef _Float16 half_t;
+typedef __bf16 bf16_t;     // bfloat16 elements of the tf_*_bf16 entries
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));

@@ -16,6 +16,7 @@
 // The weight tile is the MFMA "A" operand and the activation tile the "B" operand, so each lane ends up
 // with 4 consecutive output channels of one pixel: 8-byte stores, vector bias/residual loads.
 #include "common.h"
+#include <type_traits>
 #include "../../include/tinyfusers_hip.h"
 #include <vector>
 
@@ -63,9 +64,12 @@ struct GemmP {
   // weight scale applied to the fp32 accumulators in the epilogue (activations use scale 1: normalised tensors); out8: y is stored as
   // e4m3 as well (the GEGLU output that feeds the next fp8 GEMM)
   const float* wscale; int out8, fp8;
+  // bfloat16 operands, bias, residual and output (tf_linear_bf16 / tf_conv2d_bf16): the plain deep ring with the bf16 MFMA, no split-K
+  int bf16;
 };
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;   // 128-bit buffer resource
+typedef bf16_t b8v __attribute__((ext_vector_type(8)));   // MFMA operand of the bfloat16 instances (same register image as h8)
 
 // n / d for n < 2^31 via a precomputed multiplier: q = (umulhi(mul, n) + n) >> shr   (round-up method)
 __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
@@ -240,8 +244,14 @@ __device__ __forceinline__ void igemm_scratch_write(const GemmP& p, f4 (&acc)[BN
 }
 
 // all 8 waves: wave (w4, half) stores rows [half*TM/2, (half+1)*TM/2) of consumer w4's tile
-template <int BM, int BN, bool OUT8 = false>     // OUT8: the output is stored as e4m3 (k_igemm8 only; a template parameter keeps it out of the fp16 kernels)
+template <int BM, int BN, bool OUT8 = false, bool BF = false>     // OUT8: the output is stored as e4m3 (k_igemm8 only; a template parameter keeps it out of the fp16 kernels); BF: bias / residual / output are bfloat16
 __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m0, int n0, int split, int w4, int half, int lane) {
+  typedef typename std::conditional<BF, bf16_t, half_t>::type E;
+  typedef E E8 __attribute__((ext_vector_type(8)));
+  const E* const e_bias = reinterpret_cast<const E*>(p.bias);
+  const E* const e_bias_nc = reinterpret_cast<const E*>(p.bias_nc);
+  const E* const e_res = reinterpret_cast<const E*>(p.residual);
+  E* const e_y = reinterpret_cast<E*>(p.y);
   constexpr int TM = BM / 2, TN = BN / 2;
   const int wave_m = w4 & 1, wave_n = w4 >> 1;
   constexpr int RS = TN + 4, ROWS = TM / 2;
@@ -262,24 +272,24 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
       const float* r = sc + row * RS + pc;
       f4 a0 = *reinterpret_cast<const f4*>(r), a1 = *reinterpret_cast<const f4*>(r + 4);
       f4 g0 = *reinterpret_cast<const f4*>(r + 16), g1 = *reinterpret_cast<const f4*>(r + 20);
-      h8 ba = *reinterpret_cast<const h8*>(p.bias + n), bg = *reinterpret_cast<const h8*>(p.bias + n + 16);
-      h8 o;
+      E8 ba = *reinterpret_cast<const E8*>(e_bias + n), bg = *reinterpret_cast<const E8*>(e_bias + n + 16);
+      E8 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        o[e] = (half_t)((a0[e] + (float)ba[e]) * gelu_f(g0[e] + (float)bg[e]));
-        o[4 + e] = (half_t)((a1[e] + (float)ba[4 + e]) * gelu_f(g1[e] + (float)bg[4 + e]));
+        o[e] = (E)((a0[e] + (float)ba[e]) * gelu_f(g0[e] + (float)bg[e]));
+        o[4 + e] = (E)((a1[e] + (float)ba[4 + e]) * gelu_f(g1[e] + (float)bg[4 + e]));
       }
       if (p.residual) {
-        h8 rv = *reinterpret_cast<const h8*>(p.residual + (long long)m * No + no);
+        E8 rv = *reinterpret_cast<const E8*>(e_res + (long long)m * No + no);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rv[e]);
+        for (int e = 0; e < 8; ++e) o[e] = (E)((float)o[e] + (float)rv[e]);
       }
       if constexpr (OUT8) {
         f4 q0, q1;
         for (int e = 0; e < 4; ++e) { q0[e] = (float)o[e]; q1[e] = (float)o[4 + e]; }
         *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.y) + (long long)m * No + no) = pack8_fp8(q0, q1);
       } else {
-        *reinterpret_cast<h8*>(p.y + (long long)m * No + no) = o;
+        *reinterpret_cast<E8*>(e_y + (long long)m * No + no) = o;
       }
     }
     return;
@@ -301,13 +311,13 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
     }
     const long long bo = p.bias_nc ? (long long)(m / p.HoWo) * p.bias_nc_stride + n : 0;
     if (vec) {
-      if (p.bias) { h8 b = *reinterpret_cast<const h8*>(p.bias + n); for (int e = 0; e < 4; ++e) { v0[e] += (float)b[e]; v1[e] += (float)b[4 + e]; } }
-      if (p.bias_nc) { h8 b = *reinterpret_cast<const h8*>(p.bias_nc + bo); for (int e = 0; e < 4; ++e) { v0[e] += (float)b[e]; v1[e] += (float)b[4 + e]; } }
-      if (p.residual) { h8 b = *reinterpret_cast<const h8*>(p.residual + o); for (int e = 0; e < 4; ++e) { v0[e] += (float)b[e]; v1[e] += (float)b[4 + e]; } }
-      h8 out;
-      for (int e = 0; e < 4; ++e) { out[e] = (half_t)v0[e]; out[4 + e] = (half_t)v1[e]; }
+      if (p.bias) { E8 b = *reinterpret_cast<const E8*>(e_bias + n); for (int e = 0; e < 4; ++e) { v0[e] += (float)b[e]; v1[e] += (float)b[4 + e]; } }
+      if (p.bias_nc) { E8 b = *reinterpret_cast<const E8*>(e_bias_nc + bo); for (int e = 0; e < 4; ++e) { v0[e] += (float)b[e]; v1[e] += (float)b[4 + e]; } }
+      if (p.residual) { E8 b = *reinterpret_cast<const E8*>(e_res + o); for (int e = 0; e < 4; ++e) { v0[e] += (float)b[e]; v1[e] += (float)b[4 + e]; } }
+      E8 out;
+      for (int e = 0; e < 4; ++e) { out[e] = (E)v0[e]; out[4 + e] = (E)v1[e]; }
       if constexpr (OUT8) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.y) + o) = pack8_fp8(v0, v1);
-      else *reinterpret_cast<h8*>(p.y + o) = out;
+      else *reinterpret_cast<E8*>(e_y + o) = out;
       if (p.gn_part) {   // the statistics pass below sums what the consumer will read: the fp16-rounded outputs
         float* rw = sc + row * RS + c8 * 8;
         for (int e = 0; e < 4; ++e) { v0[e] = (float)out[e]; v1[e] = (float)out[4 + e]; }
@@ -316,10 +326,10 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
     } else {
       for (int e = 0; e < 8 && n + e < p.N; ++e) {
         float f = e < 4 ? v0[e] : v1[e - 4];
-        if (p.bias) f += (float)p.bias[n + e];
-        if (p.bias_nc) f += (float)p.bias_nc[bo + e];
-        if (p.residual) f += (float)p.residual[o + e];
-        p.y[o + e] = (half_t)f;
+        if (p.bias) f += (float)e_bias[n + e];
+        if (p.bias_nc) f += (float)e_bias_nc[bo + e];
+        if (p.residual) f += (float)e_res[o + e];
+        e_y[o + e] = (E)f;
       }
     }
   }
@@ -396,8 +406,9 @@ __device__ __forceinline__ void igemm_gn_stats(const GemmP& p, char* smem, int m
 // lose in MFMA issue slots; one of the autotuned variants.
 // GI = true: the instance that can normalise its input (GemmP::gi_*); a template parameter so that the launches without it run the very
 // code they ran before the feature existed (its branches and SGPRs cost 3 % of the step when they sat in every instance)
-template <int BM, int BN, bool GENERIC, bool WIDE, bool ALL8 = false, bool GI = false>
+template <int BM, int BN, bool GENERIC, bool WIDE, bool ALL8 = false, bool GI = false, bool BF = false>   // BF: bfloat16 operands / outputs (plain deep ring only)
 __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
+  static_assert(!BF || (!WIDE && !ALL8 && !GI && BM != 256), "the bfloat16 instances use the plain deep ring");
   constexpr int TM = BM / 2, TN = BN / 2, MJ = TM / 16, NI = TN / 16;
   constexpr int NG = (BM + BN) / 8;                       // 8-row staging groups: activation rows first, then weight rows
   // weight pieces per CONSUMER wave per stage (the last 4 LPC groups); one more per wave measured 1-3 % slower on every shape
@@ -660,7 +671,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
     }
     __builtin_amdgcn_s_barrier();                         // barrier Y: the consumers' tiles are in the LDS scratch
     asm volatile("" ::: "memory");
-    igemm_epilogue<BM, BN>(p, smem, m0, n0, split, w4, 1, lane);
+    igemm_epilogue<BM, BN, false, BF>(p, smem, m0, n0, split, w4, 1, lane);
     if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 1, lane);
     return;
   }
@@ -813,7 +824,10 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[k2][i], xf[k2][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < MJ; ++j) {
+          if constexpr (BF) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8v, wf[k2][i]), __builtin_bit_cast(b8v, xf[k2][j]), acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[k2][i], xf[k2][j], acc[i][j], 0, 0, 0);
+        }
   };
   if constexpr (ALL8) {
 #pragma unroll
@@ -864,7 +878,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                           // barrier Y
   asm volatile("" ::: "memory");
-  igemm_epilogue<BM, BN>(p, smem, m0, n0, split, w4, 0, lane);
+  igemm_epilogue<BM, BN, false, BF>(p, smem, m0, n0, split, w4, 0, lane);
   if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 0, lane);
 }
 
@@ -1946,6 +1960,19 @@ static const int kTiles8[][2] = {{128, 128}, {64, 128}, {128, 64}, {256, 64}, {6
 static const int kNumTiles8 = 5;
 
 static bool gemm_generic(const GemmP& p) { return (p.C1 % 64) != 0 || (p.C2 % 64) != 0 || (p.C3 % 64) != 0 || (p.C4 % 64) != 0; }
+// bfloat16 instances: plain deep ring, one launch (no split-K: the reduce kernels are fp16), no statistics, no input GroupNorm
+template <int BM, int BN, bool GENERIC>
+static int launch_bf(const GemmP& p, hipStream_t st) {
+  const int smem = igemm_lds_bytes(BM, BN, false);
+  static bool attr_set = false;
+  if (!attr_set) {
+    TF_HIP(hipFuncSetAttribute((const void*)k_igemm<BM, BN, GENERIC, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_igemm<BM, BN, GENERIC, false, false, false, true>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
 template <int BM, int BN, bool WIDE_OK>
 static int launch_cfg(const GemmP& p, hipStream_t st, bool wide, bool all8 = false) {
   bool generic = gemm_generic(p);
@@ -1995,7 +2022,13 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
     if (p.splitk > 1) { p.gn_chunks = gn_reduce_chunks(p.HoWo); p.gn_part = nullptr; }
     else p.gn_chunks = gn_pieces(p, c.bn) * (p.HoWo / c.bm);
   }
-  if (p.fp8) {
+  if (p.bf16) {
+    const bool g = gemm_generic(p);
+    if (c.bm == 128 && c.bn == 128) rc = g ? launch_bf<128, 128, true>(p, st) : launch_bf<128, 128, false>(p, st);
+    else if (c.bm == 64 && c.bn == 64) rc = g ? launch_bf<64, 64, true>(p, st) : launch_bf<64, 64, false>(p, st);
+    else { tf_set_error("run_gemm: no bfloat16 kernel for tile %dx%d", c.bm, c.bn); return TF_E_UNSUPPORTED; }
+  }
+  else if (p.fp8) {
     if (c.bm == 128 && c.bn == 128) rc = launch8<128, 128>(p, st);
     else if (c.bm == 64 && c.bn == 128) rc = launch8<64, 128>(p, st);
     else if (c.bm == 128 && c.bn == 64) rc = launch8<128, 64>(p, st);
@@ -2150,7 +2183,12 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     t.c = {p.M >= 128 ? 128 : 64, p.act == 1 || p.N >= 128 ? 128 : 64, b128 >= 128 ? 1 : t.c.splitk};
     t.variant = 0; tuned = true;
   }
-  if (force_bm) {
+  if (p.bf16) {                                           // two tiles, no tuner: 128 x 128 once that gives every CU a block, else 64 x 64
+    long long b128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    t.c = b128 >= 256 ? TileCfg{128, 128, 1} : TileCfg{64, 64, 1};
+    t.variant = 0; t.order = 0; tuned = true;
+  }
+  else if (force_bm) {
     t.c = {force_bm, force_bn, force_split > 0 ? force_split : 1};
     t.order = g_force_order > 0 ? 1 : 0;
     if (p.gi_part) t.variant = p.S == 3 ? 2 : 0;
@@ -2377,6 +2415,7 @@ static int conv2d_impl(void* y, const void* x, const void* x2, const void* w, co
       p.gn_part = gn_partial; p.gn_G = gn_groups; p.gn_cpg = cpg;
     }
   }
+  if (gi && gi->bf16) p.bf16 = 1;
   if (gi && gi->on_z && p.gn_part) {                       // (groups the epilogue cannot fold: no statistics, no apply -- *z_written stays 0)
     p.on_z = gi->on_z; p.on_gamma = gi->on_gamma; p.on_beta = gi->on_beta; p.on_eps = gi->on_eps; p.on_silu = gi->on_silu; p.on_applied = gi->on_applied;
   }
@@ -2483,6 +2522,31 @@ int tf_linear_f16(void* y, const void* x, const void* w, const void* bias, const
     p.x_bytes = (unsigned)xb; p.x2_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
   }
   return run_gemm(p, workspace, workspace_bytes, g_force_bm, g_force_bn, g_force_split, tf_hs(s));
+}
+
+// ---- bfloat16 entries: the reference's op tests parametrise bfloat16 next to float16 (tests/linear.py:13, tests/layer_norm.py:13,
+// tests/group_norm.py:12) -- same tensors and semantics as the _f16 entries with every 16-bit tensor holding bfloat16 ----------------
+int tf_linear_bf16(void* y, const void* x, const void* w, const void* bias, const void* residual, int M, int N, int K, tfStream_t s) {
+  TF_REQUIRE(y && x && w, "tf_linear_bf16: null tensor");
+  TF_REQUIRE(M >= 0 && N >= 1 && K >= 8 && K % 8 == 0, "tf_linear_bf16: K=%d must be a positive multiple of 8", K);
+  if (M == 0) return TF_OK;
+  GemmP p = {};
+  p.x = (const half_t*)x; p.w = (const half_t*)w; p.y = (half_t*)y; p.bias = (const half_t*)bias; p.residual = (const half_t*)residual;
+  p.M = M; p.N = N; p.K = K; p.Kc = K; p.C1 = K; p.C2 = 0; p.C = K;
+  p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.HoWo = M; p.S = 1; p.stride = 1; p.pad = 0; p.ups = 0; p.act = 0; p.bf16 = 1;
+  {
+    long long xb = (long long)M * K * 2, wb = (long long)p.N * K * 2;
+    TF_REQUIRE(xb < (1LL << 31) && wb < (1LL << 31), "tf_linear_bf16: tensors must be < 2 GiB each");
+    p.x_bytes = (unsigned)xb; p.x2_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+  }
+  return run_gemm(p, nullptr, 0, 0, 0, 0, tf_hs(s));
+}
+int tf_conv2d_bf16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
+                   const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample, tfStream_t s) {
+  GemmP ex = {};
+  ex.bf16 = 1;
+  return conv2d_impl(y, x, x2, w, bias, bias_nc, bias_nc_stride, residual, N, H, W, C1, C2, Cout, R, S, stride, pad, upsample, nullptr, 0,
+                     nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, s, &ex);
 }
 
 // ---- fp8 entries (config 5) ---------------------------------------------------------------------------------------------------

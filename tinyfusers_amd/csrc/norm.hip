@@ -4,12 +4,17 @@
 #include "../../include/tinyfusers_hip.h"
 
 #define GN_MAX_CHUNKS 64
+// element type of the 16-bit kernels: half_t (fp16, the UNet path) or bf16_t (tf_*_bf16: the reference's norm tests also run bfloat16,
+// tests/group_norm.py:12-19, tests/layer_norm.py:13-27); statistics and arithmetic are fp32 either way
+template <typename T> struct vec8 { typedef T type __attribute__((ext_vector_type(8))); };
 
 // ---- GroupNorm pass 1: per-(image, pixel-chunk) partial sums per group ---------------------------
 // block = CV * RPB threads (CV = C/8 channel vectors, RPB rows per sweep); thread owns one channel vector.
 // partial layout: [N][chunks][G][2] fp32 (sum, sum of squares)
-__global__ void k_gn_stats(float* __restrict__ partial, const half_t* __restrict__ x, const half_t* __restrict__ x2, int HW, int C1, int C2,
+template <typename T = half_t>
+__global__ void k_gn_stats(float* __restrict__ partial, const T* __restrict__ x, const T* __restrict__ x2, int HW, int C1, int C2,
                            int G, int chunks, int pix_per_chunk, int CV, int RPB) {
+  typedef typename vec8<T>::type V8;
   extern __shared__ float red[];  // [RPB*CV][16]: per-thread channel sums, then reduced in a fixed order
   int n = blockIdx.y, chunk = blockIdx.x;
   int C = C1 + C2, cpg = C / G;
@@ -17,7 +22,7 @@ __global__ void k_gn_stats(float* __restrict__ partial, const half_t* __restrict
   int cv = t % CV, rr = t / CV;
   int c = cv * 8;
   if (rr < RPB) {
-    const half_t* base;
+    const T* base;
     int ld;
     if (c < C1) { base = x + (long long)n * HW * C1 + c; ld = C1; }
     else { base = x2 + (long long)n * HW * C2 + (c - C1); ld = C2; }
@@ -26,11 +31,11 @@ __global__ void k_gn_stats(float* __restrict__ partial, const half_t* __restrict
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
     int p0 = chunk * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
     for (int p = p0 + rr; p < p1; p += 4 * RPB) {          // four independent loads in flight per thread
-      h8 v[4];
+      V8 v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         int q = p + u * RPB;
-        v[u] = q < p1 ? *reinterpret_cast<const h8*>(base + (long long)q * ld) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+        v[u] = q < p1 ? *reinterpret_cast<const V8*>(base + (long long)q * ld) : (V8){0, 0, 0, 0, 0, 0, 0, 0};
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -68,11 +73,12 @@ __global__ void k_gn_stats(float* __restrict__ partial, const half_t* __restrict
 // fixed order -> every block gets the same bits) -- cheaper than a separate finalize launch; then many small blocks
 // stream the tensor (the kernel is latency-bound otherwise).
 #define GN_APPLY_PPT 4
-template <bool OUT8>
-__global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ x2, const half_t* __restrict__ gamma,
-                           const half_t* __restrict__ beta, const float* __restrict__ partial, int HW, int C1, int C2, int G, float eps,
+template <bool OUT8, typename T = half_t>
+__global__ void k_gn_apply(T* __restrict__ y, const T* __restrict__ x, const T* __restrict__ x2, const T* __restrict__ gamma,
+                           const T* __restrict__ beta, const float* __restrict__ partial, int HW, int C1, int C2, int G, float eps,
                            int do_silu, int chunks, int pix_per_block, int CV, int RPB, const float* __restrict__ partial2, int chunks2,
                            int G1, int G2, int mr) {
+  typedef typename vec8<T>::type V8;
   extern __shared__ float st[];  // [G][2] : mean, rstd
   int n = blockIdx.y;
   int C = C1 + C2, cpg = C / G;
@@ -82,20 +88,20 @@ __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x,
   const int cv = t % CV, rr = t / CV;
   const bool active = rr < RPB;
   const int c = cv * 8;
-  const half_t* base = x;
+  const T* base = x;
   int ld = C1;
   if (active) {
     if (c < C1) { base = x + (long long)n * HW * C1 + c; ld = C1; }
     else { base = x2 + (long long)n * HW * C2 + (c - C1); ld = C2; }
   }
   const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
-  h8 gm, bt, v[GN_APPLY_PPT];                            // pix_per_block == GN_APPLY_PPT * RPB (gn_geometry)
+  V8 gm, bt, v[GN_APPLY_PPT];                            // pix_per_block == GN_APPLY_PPT * RPB (gn_geometry)
   if (active) {
-    if (gamma) { gm = *reinterpret_cast<const h8*>(gamma + c); bt = *reinterpret_cast<const h8*>(beta + c); }
+    if (gamma) { gm = *reinterpret_cast<const V8*>(gamma + c); bt = *reinterpret_cast<const V8*>(beta + c); }
 #pragma unroll
     for (int i = 0; i < GN_APPLY_PPT; ++i) {
       int p = p0 + rr + i * RPB;
-      if (p < p1) v[i] = *reinterpret_cast<const h8*>(base + (long long)p * ld);
+      if (p < p1) v[i] = *reinterpret_cast<const V8*>(base + (long long)p * ld);
     }
   }
   {
@@ -158,22 +164,22 @@ __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x,
       b[j] = btj - mean * a[j];
     }
   }
-  half_t* yo = y + (long long)n * HW * C + c;
+  T* yo = y + (long long)n * HW * C + c;
 #pragma unroll
   for (int i = 0; i < GN_APPLY_PPT; ++i) {
     int p = p0 + rr + i * RPB;
     if (p < p1) {
-      h8 o;
+      V8 o;
       f4 q0, q1;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float f = (float)v[i][j] * a[j] + b[j];
         f = do_silu ? silu_f(f) : f;
-        o[j] = (half_t)f;
+        o[j] = (T)f;
         if (j < 4) q0[j] = f; else q1[j - 4] = f;
       }
       if constexpr (OUT8) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(y) + (long long)n * HW * C + c + (long long)p * C) = pack8_fp8(q0, q1);   // e4m3 operand of an fp8 conv
-      else *reinterpret_cast<h8*>(yo + (long long)p * C) = o;
+      else *reinterpret_cast<V8*>(yo + (long long)p * C) = o;
     }
   }
 }
@@ -181,23 +187,24 @@ __global__ void k_gn_apply(half_t* __restrict__ y, const half_t* __restrict__ x,
 // ---- LayerNorm: LPR lanes per row (8/16/32/64 so that a lane holds <= 5 vectors), 64/LPR rows per wave: several
 // independent 16-B loads in flight per lane and only log2(LPR) shuffle steps per reduction.
 #define LN_MAXV 5
-template <int LPR>
-__global__ void __launch_bounds__(256) k_layer_norm(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ gamma,
-                                                    const half_t* __restrict__ beta, int rows, int C, float eps, int out8) {
+template <int LPR, typename T = half_t>
+__global__ void __launch_bounds__(256) k_layer_norm(T* __restrict__ y, const T* __restrict__ x, const T* __restrict__ gamma,
+                                                    const T* __restrict__ beta, int rows, int C, float eps, int out8) {
+  typedef typename vec8<T>::type V8;
   constexpr int RPW = 64 / LPR;                          // rows per wave
   int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   int row = (blockIdx.x * 4 + w) * RPW + l / LPR;
   int li = l % LPR;
   int CV = C >> 3;
   bool live = row < rows;
-  const half_t* xr = x + (long long)(live ? row : 0) * C;
-  h8 v[LN_MAXV];
+  const T* xr = x + (long long)(live ? row : 0) * C;
+  V8 v[LN_MAXV];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     int cv = li + LPR * i;
     if (cv < CV) {
-      v[i] = *reinterpret_cast<const h8*>(xr + cv * 8);
+      v[i] = *reinterpret_cast<const V8*>(xr + cv * 8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += (float)v[i][j];
     }
@@ -218,23 +225,23 @@ __global__ void __launch_bounds__(256) k_layer_norm(half_t* __restrict__ y, cons
   for (int o = 1; o < LPR; o <<= 1) q += __shfl_xor(q, o, 64);
   float rstd = rsqrtf(q / (float)C + eps);
   if (!live) return;
-  half_t* yr = y + (long long)row * C;
+  T* yr = y + (long long)row * C;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     int cv = li + LPR * i;
     if (cv < CV) {
-      h8 o;
+      V8 o;
       f4 q0, q1;
       if (gamma) {
-        h8 gm = *reinterpret_cast<const h8*>(gamma + cv * 8), bt = *reinterpret_cast<const h8*>(beta + cv * 8);
+        V8 gm = *reinterpret_cast<const V8*>(gamma + cv * 8), bt = *reinterpret_cast<const V8*>(beta + cv * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { float f = ((float)v[i][j] - mean) * rstd * (float)gm[j] + (float)bt[j]; o[j] = (half_t)f; if (j < 4) q0[j] = f; else q1[j - 4] = f; }
+        for (int j = 0; j < 8; ++j) { float f = ((float)v[i][j] - mean) * rstd * (float)gm[j] + (float)bt[j]; o[j] = (T)f; if (j < 4) q0[j] = f; else q1[j - 4] = f; }
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { float f = ((float)v[i][j] - mean) * rstd; o[j] = (half_t)f; if (j < 4) q0[j] = f; else q1[j - 4] = f; }
+        for (int j = 0; j < 8; ++j) { float f = ((float)v[i][j] - mean) * rstd; o[j] = (T)f; if (j < 4) q0[j] = f; else q1[j - 4] = f; }
       }
       if (out8) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(y) + (long long)row * C + cv * 8) = pack8_fp8(q0, q1);
-      else *reinterpret_cast<h8*>(yr + cv * 8) = o;
+      else *reinterpret_cast<V8*>(yr + cv * 8) = o;
     }
   }
 }
@@ -242,15 +249,16 @@ __global__ void __launch_bounds__(256) k_layer_norm(half_t* __restrict__ y, cons
 // ---- LayerNorm for any row length (C not a multiple of 8, or beyond what k_layer_norm keeps in registers): the reference's own
 // tests normalise 10-element rows and (C, 10, 10) = 76 800 ... 160 000-element slabs (tests/layer_norm.py:22-71).  WAVE = true: one
 // wave per row (4 rows per block); false: one 256-thread block per row.  Two-pass variance; the second and third sweeps hit L2.
-template <bool WAVE>
-__global__ void __launch_bounds__(256) k_layer_norm_any(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ gamma,
-                                                        const half_t* __restrict__ beta, int rows, long long C, float eps) {
+template <bool WAVE, typename T = half_t>
+__global__ void __launch_bounds__(256) k_layer_norm_any(T* __restrict__ y, const T* __restrict__ x, const T* __restrict__ gamma,
+                                                        const T* __restrict__ beta, int rows, long long C, float eps) {
+  typedef typename vec8<T>::type V8;
   __shared__ float red[8];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const long long row = WAVE ? (long long)blockIdx.x * 4 + w : blockIdx.x;
   const int t = WAVE ? l : threadIdx.x, nt = WAVE ? 64 : 256;
   const bool live = row < rows;
-  const half_t* xr = x + (live ? row : 0) * C;
+  const T* xr = x + (live ? row : 0) * C;
   const bool vec = (C & 7) == 0;
   auto block_sum = [&](float v, int slot) {
     v = wave_sum(v);
@@ -261,35 +269,35 @@ __global__ void __launch_bounds__(256) k_layer_norm_any(half_t* __restrict__ y, 
   };
   float s = 0.f;
   if (vec) {
-    for (long long i = (long long)t * 8; i < C; i += nt * 8) { h8 v = *reinterpret_cast<const h8*>(xr + i); for (int j = 0; j < 8; ++j) s += (float)v[j]; }
+    for (long long i = (long long)t * 8; i < C; i += nt * 8) { V8 v = *reinterpret_cast<const V8*>(xr + i); for (int j = 0; j < 8; ++j) s += (float)v[j]; }
   } else {
     for (long long i = t; i < C; i += nt) s += (float)xr[i];
   }
   const float mean = block_sum(s, 0) / (float)C;
   float q = 0.f;
   if (vec) {
-    for (long long i = (long long)t * 8; i < C; i += nt * 8) { h8 v = *reinterpret_cast<const h8*>(xr + i); for (int j = 0; j < 8; ++j) { float d = (float)v[j] - mean; q += d * d; } }
+    for (long long i = (long long)t * 8; i < C; i += nt * 8) { V8 v = *reinterpret_cast<const V8*>(xr + i); for (int j = 0; j < 8; ++j) { float d = (float)v[j] - mean; q += d * d; } }
   } else {
     for (long long i = t; i < C; i += nt) { float d = (float)xr[i] - mean; q += d * d; }
   }
   const float rstd = rsqrtf(block_sum(q, 1) / (float)C + eps);
   if (!live) return;
-  half_t* yr = y + row * C;
+  T* yr = y + row * C;
   if (vec) {
     for (long long i = (long long)t * 8; i < C; i += nt * 8) {
-      h8 v = *reinterpret_cast<const h8*>(xr + i), o;
+      V8 v = *reinterpret_cast<const V8*>(xr + i), o;
       if (gamma) {
-        h8 gm = *reinterpret_cast<const h8*>(gamma + i), bt = *reinterpret_cast<const h8*>(beta + i);
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)(((float)v[j] - mean) * rstd * (float)gm[j] + (float)bt[j]);
+        V8 gm = *reinterpret_cast<const V8*>(gamma + i), bt = *reinterpret_cast<const V8*>(beta + i);
+        for (int j = 0; j < 8; ++j) o[j] = (T)(((float)v[j] - mean) * rstd * (float)gm[j] + (float)bt[j]);
       } else {
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)(((float)v[j] - mean) * rstd);
+        for (int j = 0; j < 8; ++j) o[j] = (T)(((float)v[j] - mean) * rstd);
       }
-      *reinterpret_cast<h8*>(yr + i) = o;
+      *reinterpret_cast<V8*>(yr + i) = o;
     }
   } else {
     for (long long i = t; i < C; i += nt) {
       float f = ((float)xr[i] - mean) * rstd;
-      yr[i] = (half_t)(gamma ? f * (float)gamma[i] + (float)beta[i] : f);
+      yr[i] = (T)(gamma ? f * (float)gamma[i] + (float)beta[i] : f);
     }
   }
 }
@@ -309,14 +317,38 @@ static void gn_geometry(int HW, int C, int N, int* CV, int* RPB, int* threads, i
   *appb = q; *ablocks = (HW + q - 1) / q;
 }
 
-extern "C" {
-
-size_t tf_group_norm_workspace(int N, int HW, int C, int G) {
-  (void)HW; (void)C;
-  return (size_t)N * GN_MAX_CHUNKS * G * 2 * sizeof(float);   // per-chunk partial (sum, sum of squares) per group
+template <typename T>
+static int layer_norm_impl(void* y, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, int out8, tfStream_t s) {
+  TF_REQUIRE(y && x && rows >= 0, "tf_layer_norm_f16: null tensor");
+  TF_REQUIRE((gamma == nullptr) == (beta == nullptr), "tf_layer_norm_f16: gamma and beta must both be given or both NULL");
+  TF_REQUIRE(C > 0, "tf_layer_norm_f16: C=%d", C);
+  if (rows == 0) return TF_OK;
+  if (C % 8 != 0 || C > 64 * 8 * LN_MAXV) {
+    // any row length: a wave per row while the row is short, a block per row beyond
+    if (C <= 4096) hipLaunchKernelGGL((k_layer_norm_any<true, T>), dim3(ceil_div(rows, 4)), dim3(256), 0, tf_hs(s), (T*)y, (const T*)x,
+                                      (const T*)gamma, (const T*)beta, rows, (long long)C, eps);
+    else hipLaunchKernelGGL((k_layer_norm_any<false, T>), dim3(rows), dim3(256), 0, tf_hs(s), (T*)y, (const T*)x, (const T*)gamma,
+                            (const T*)beta, rows, (long long)C, eps);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+  }
+  int cv = C / 8;
+#define LN_LAUNCH(LPR_)                                                                                                            \
+  hipLaunchKernelGGL((k_layer_norm<LPR_, T>), dim3(ceil_div(rows, 4 * (64 / LPR_))), dim3(256), 0, tf_hs(s), (T*)y, (const T*)x, \
+                     (const T*)gamma, (const T*)beta, rows, C, eps, out8)
+  // few rows: one wave per row (most waves in flight); many rows: several rows per wave (more loads per lane)
+  if (rows < 8192 || cv > 32 * LN_MAXV) LN_LAUNCH(64);
+  else if (cv <= 8 * LN_MAXV) LN_LAUNCH(8);
+  else if (cv <= 16 * LN_MAXV) LN_LAUNCH(16);
+  else LN_LAUNCH(32);
+#undef LN_LAUNCH
+  TF_LAUNCH_CHECK();
+  return TF_OK;
 }
 
-int tf_group_norm_f16(void* y, const void* x, const void* x2, const void* gamma, const void* beta, int N, int HW, int C1, int C2, int G,
+extern "C" size_t tf_group_norm_workspace(int N, int HW, int C, int G);
+template <typename T>
+static int group_norm_impl(void* y, const void* x, const void* x2, const void* gamma, const void* beta, int N, int HW, int C1, int C2, int G,
                       float eps, int silu, void* workspace, size_t workspace_bytes, tfStream_t s) {
   int C = C1 + C2;
   TF_REQUIRE(y && x && (C2 == 0 || x2), "tf_group_norm_f16: null tensor");
@@ -333,13 +365,30 @@ int tf_group_norm_f16(void* y, const void* x, const void* x2, const void* gamma,
   gn_geometry(HW, C, N, &CV, &RPB, &threads, &chunks, &ppc, &ablocks, &appb);
   float* partial = (float*)workspace;
   int tl = (threads + 7) & ~7;                         // the folds work in groups of 8 lanes
-  hipLaunchKernelGGL(k_gn_stats, dim3(chunks, N), dim3(tl), (size_t)threads * 16 * sizeof(float), tf_hs(s), partial, (const half_t*)x,
-                     (const half_t*)x2, HW, C1, C2, G, chunks, ppc, CV, RPB);
+  hipLaunchKernelGGL(k_gn_stats<T>, dim3(chunks, N), dim3(tl), (size_t)threads * 16 * sizeof(float), tf_hs(s), partial, (const T*)x,
+                     (const T*)x2, HW, C1, C2, G, chunks, ppc, CV, RPB);
   TF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_gn_apply<false>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
-                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
+  hipLaunchKernelGGL((k_gn_apply<false, T>), dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (T*)y, (const T*)x, (const T*)x2,
+                     (const T*)gamma, (const T*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
   TF_LAUNCH_CHECK();
   return TF_OK;
+}
+
+extern "C" {
+
+size_t tf_group_norm_workspace(int N, int HW, int C, int G) {
+  (void)HW; (void)C;
+  return (size_t)N * GN_MAX_CHUNKS * G * 2 * sizeof(float);   // per-chunk partial (sum, sum of squares) per group
+}
+
+int tf_group_norm_f16(void* y, const void* x, const void* x2, const void* gamma, const void* beta, int N, int HW, int C1, int C2, int G,
+                      float eps, int silu, void* workspace, size_t workspace_bytes, tfStream_t s) {
+  return group_norm_impl<half_t>(y, x, x2, gamma, beta, N, HW, C1, C2, G, eps, silu, workspace, workspace_bytes, s);
+}
+/* bfloat16 in and out (tests/group_norm.py:12-19 runs bfloat16 next to float16); fp32 statistics, same workspace */
+int tf_group_norm_bf16(void* y, const void* x, const void* x2, const void* gamma, const void* beta, int N, int HW, int C1, int C2, int G,
+                       float eps, int silu, void* workspace, size_t workspace_bytes, tfStream_t s) {
+  return group_norm_impl<bf16_t>(y, x, x2, gamma, beta, N, HW, C1, C2, G, eps, silu, workspace, workspace_bytes, s);
 }
 
 int tf_group_norm_apply_f16(void* y, const void* x, const void* gamma, const void* beta, const void* partial, int chunks, int N, int HW, int C, int G,
@@ -420,41 +469,17 @@ int tf_group_norm_apply2_f16(void* y, const void* x, const void* x2, const void*
   return tf_group_norm_apply_cat_f16(y, x, x2, gamma, beta, partial, chunks, G, partial2, chunks2, G, N, HW, C1, C1, G, eps, silu, s);
 }
 
-static int layer_norm_impl(void* y, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, int out8, tfStream_t s);
 int tf_layer_norm_f16(void* y, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s) {
-  return layer_norm_impl(y, x, gamma, beta, rows, C, eps, 0, s);
+  return layer_norm_impl<half_t>(y, x, gamma, beta, rows, C, eps, 0, s);
+}
+/* bfloat16 in and out (tests/layer_norm.py:13-27 runs bfloat16 next to float16); fp32 statistics */
+int tf_layer_norm_bf16(void* y, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s) {
+  return layer_norm_impl<bf16_t>(y, x, gamma, beta, rows, C, eps, 0, s);
 }
 /* LayerNorm with an e4m3 (fp8) output: the operand of an fp8 Linear (config 5's FeedForward); C a multiple of 8, <= 2560 */
 int tf_layer_norm_fp8(void* y8, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s) {
   TF_REQUIRE(C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXV, "tf_layer_norm_fp8: C=%d must be a multiple of 8 and <= %d", C, 64 * 8 * LN_MAXV);
-  return layer_norm_impl(y8, x, gamma, beta, rows, C, eps, 1, s);
-}
-static int layer_norm_impl(void* y, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, int out8, tfStream_t s) {
-  TF_REQUIRE(y && x && rows >= 0, "tf_layer_norm_f16: null tensor");
-  TF_REQUIRE((gamma == nullptr) == (beta == nullptr), "tf_layer_norm_f16: gamma and beta must both be given or both NULL");
-  TF_REQUIRE(C > 0, "tf_layer_norm_f16: C=%d", C);
-  if (rows == 0) return TF_OK;
-  if (C % 8 != 0 || C > 64 * 8 * LN_MAXV) {
-    // any row length: a wave per row while the row is short, a block per row beyond
-    if (C <= 4096) hipLaunchKernelGGL(k_layer_norm_any<true>, dim3(ceil_div(rows, 4)), dim3(256), 0, tf_hs(s), (half_t*)y, (const half_t*)x,
-                                      (const half_t*)gamma, (const half_t*)beta, rows, (long long)C, eps);
-    else hipLaunchKernelGGL(k_layer_norm_any<false>, dim3(rows), dim3(256), 0, tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)gamma,
-                            (const half_t*)beta, rows, (long long)C, eps);
-    TF_LAUNCH_CHECK();
-    return TF_OK;
-  }
-  int cv = C / 8;
-#define LN_LAUNCH(LPR_)                                                                                                            \
-  hipLaunchKernelGGL(k_layer_norm<LPR_>, dim3(ceil_div(rows, 4 * (64 / LPR_))), dim3(256), 0, tf_hs(s), (half_t*)y, (const half_t*)x, \
-                     (const half_t*)gamma, (const half_t*)beta, rows, C, eps, out8)
-  // few rows: one wave per row (most waves in flight); many rows: several rows per wave (more loads per lane)
-  if (rows < 8192 || cv > 32 * LN_MAXV) LN_LAUNCH(64);
-  else if (cv <= 8 * LN_MAXV) LN_LAUNCH(8);
-  else if (cv <= 16 * LN_MAXV) LN_LAUNCH(16);
-  else LN_LAUNCH(32);
-#undef LN_LAUNCH
-  TF_LAUNCH_CHECK();
-  return TF_OK;
+  return layer_norm_impl<half_t>(y8, x, gamma, beta, rows, C, eps, 1, s);
 }
 
 }  // extern "C"

@@ -5,7 +5,7 @@ import numpy as np
 
 from .. import config
 from ..native import hip
-from ..storage.tensor import DeviceArray, _sh, asarray
+from ..storage.tensor import DeviceArray, _sh, asarray, is_bfloat16
 from .linear import workspace
 
 
@@ -15,6 +15,14 @@ def _gn(x, num_groups, eps, gamma, beta, silu):
         x, x2 = x
     n, c1, h, w = x.shape
     c2 = x2.shape[1] if x2 is not None else 0
+    if is_bfloat16(x.dtype):                           # bfloat16 tensors (tests/group_norm.py:12-19): the stand-alone two-pass form
+        y = DeviceArray.empty((n, c1 + c2, h, w), x.dtype, "nhwc")
+        nb = hip.tf_group_norm_workspace(n, h * w, c1 + c2, num_groups)
+        ws = workspace(nb)
+        hip.tf_group_norm_bf16(y.ptr, x.ptr, x2.ptr if x2 is not None else None, gamma.ptr if gamma is not None else None,
+                               beta.ptr if beta is not None else None, n, h * w, c1, c2, num_groups, float(eps), 1 if silu else 0,
+                               ws.ptr, nb, _sh())
+        return y
     y = DeviceArray.empty((n, c1 + c2, h, w), np.float16, "nhwc")
     if x2 is None and x.gn is not None and x.gn[2] == num_groups:
         part, chunks, _ = x.gn                         # statistics came with x from the conv that produced it

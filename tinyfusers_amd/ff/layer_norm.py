@@ -4,13 +4,16 @@ tests/layer_norm.py:38-41).  One wave per row, row held in registers.
 import numpy as np
 
 from ..native import hip
-from ..storage.tensor import DeviceArray, _sh, asarray
+from ..storage.tensor import DeviceArray, _sh, asarray, is_bfloat16
 
 
 def layer_norm(x, scale, bias, eps):
     """ff/layer_norm.py:8-32.  Normalises over as many trailing dims as ``scale`` spans (one by default): the reference's own tests
     use a (C, H, W) slab and a 10-element last dim (tests/layer_norm.py:22-71).  x, scale and bias must share their storage order over
     the normalised dims (all 'nhwc' 4-D arrays, or all row-major)."""
+    x = asarray(x)                                     # (the reference's test hands torch tensors, tests/layer_norm.py:38-41)
+    scale = asarray(scale, x.dtype) if scale is not None else None
+    bias = asarray(bias, x.dtype) if bias is not None else None
     c = x.shape[-1]
     if scale is not None and scale.size != c:
         c = scale.size
@@ -20,9 +23,10 @@ def layer_norm(x, scale, bias, eps):
             tail *= x.shape[-n]
         assert tail == c and (n == 1 or (scale.layout == x.layout)), (x.shape, scale.shape)
     rows = x.size // c
-    y = DeviceArray.empty(x.shape, np.float16, x.layout)
+    y = DeviceArray.empty(x.shape, x.dtype, x.layout)
     e = float(np.asarray(eps).reshape(-1)[0])
-    hip.tf_layer_norm_f16(y.ptr, x.ptr, scale.ptr if scale is not None else None, bias.ptr if bias is not None else None, rows, c, e, _sh())
+    fn = hip.tf_layer_norm_bf16 if is_bfloat16(x.dtype) else hip.tf_layer_norm_f16
+    fn(y.ptr, x.ptr, scale.ptr if scale is not None else None, bias.ptr if bias is not None else None, rows, c, e, _sh())
     return y
 
 

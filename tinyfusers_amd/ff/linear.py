@@ -4,7 +4,7 @@ GEMV (tf_gemv_f16) for <= 8 rows (time-embedding MLP, ResBlock emb_layers)."""
 import numpy as np
 
 from ..native import hip
-from ..storage.tensor import DeviceArray, _sh, asarray
+from ..storage.tensor import DeviceArray, _sh, asarray, is_bfloat16
 
 
 def workspace(nbytes):
@@ -21,6 +21,17 @@ def linear_f16(x, w, b=None, residual=None, act=0, out_features=None):
     ws = workspace(nb)
     hip.tf_linear_f16(y.ptr, x.ptr, w.ptr, b.ptr if b is not None else None, residual.ptr if residual is not None else None,
                       rows, n_out, K, act, ws.ptr if ws else None, nb, _sh())
+    return y
+
+
+def linear_bf16(x, w, b=None, residual=None):
+    """y = x . w^T + b + residual with every tensor bfloat16 (tests/linear.py:13 lists the type): one bf16-MFMA launch."""
+    K = x.shape[-1]
+    rows = x.size // K
+    assert is_bfloat16(w.dtype) and (b is None or is_bfloat16(b.dtype)) and (residual is None or is_bfloat16(residual.dtype))
+    y = DeviceArray.empty(x.shape[:-1] + (w.shape[0],), x.dtype, "row")
+    hip.tf_linear_bf16(y.ptr, x.ptr, w.ptr, b.ptr if b is not None else None, residual.ptr if residual is not None else None,
+                       rows, w.shape[0], K, _sh())
     return y
 
 
@@ -122,6 +133,9 @@ class Linear:
     def __call__(self, x, residual=None, silu_input=False):
         assert x.layout == "row" and x.shape[-1] == self.weight.shape[1], (x.shape, self.weight.shape)
         rows = x.size // x.shape[-1]
+        if is_bfloat16(x.dtype):
+            assert not silu_input
+            return linear_bf16(x, self.weight, self.bias, residual)
         if rows <= 8 and residual is None:
             return gemv_f16(x, self.weight, self.bias, silu_input)
         assert not silu_input

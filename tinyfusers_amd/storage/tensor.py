@@ -247,6 +247,29 @@ def _pool_free(ptr, n):
 _NP = {"f16": np.float16, "f32": np.float32}
 
 
+# bfloat16: numpy has no such type, so a DeviceArray of bfloat16 elements carries this tagged uint16 dtype (2-byte items; the tag lives
+# in the dtype's metadata, which numpy ignores in comparisons -- use is_bfloat16).  The reference's op tests run bfloat16 next to
+# float16 (tests/group_norm.py:12-19, tests/layer_norm.py:13-27, tests/linear.py:13); here it selects the tf_*_bf16 entries.
+bfloat16 = np.dtype(np.uint16, metadata={"bfloat16": True})
+
+
+def is_bfloat16(dtype):
+    md = getattr(dtype, "metadata", None)
+    return bool(md and md.get("bfloat16"))
+
+
+def f32_to_bf16_bits(x):
+    """float array -> uint16 bfloat16 bit patterns, round-to-nearest-even (what v_cvt_pk_bf16_f32 does); NaN stays NaN."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = ((u + (((u >> 16) & 1) + np.uint32(0x7FFF))) >> 16).astype(np.uint16)
+    nan = (u & np.uint32(0x7FFFFFFF)) > np.uint32(0x7F800000)
+    return np.where(nan, ((u >> 16) | np.uint32(0x40)).astype(np.uint16), r)
+
+
+def bf16_bits_to_f32(b):
+    return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
 class DeviceArray:
     """(ptr, logical shape, dtype, layout) handle.  layout: 'nhwc' (4-D, logical NCHW) or 'row'."""
     __slots__ = ("ptr", "shape", "dtype", "layout", "_base", "_fin", "gn", "normed", "_uid", "_version", "__weakref__")
@@ -289,7 +312,7 @@ class DeviceArray:
         """Synchronous host -> device copy into this array (same logical shape; cast / laid out on the host first).
         Use this instead of ``tf_memcpy(ptr, some_expression.ctypes.data, ...)``: an address taken from a temporary
         array is dangling by the time the call runs, the staging array here stays referenced until the copy returned."""
-        host = np.asarray(x).astype(self.dtype, copy=False)
+        host = f32_to_bf16_bits(np.asarray(x)) if is_bfloat16(self.dtype) else np.asarray(x).astype(self.dtype, copy=False)
         if host.shape != self.shape:
             raise ValueError(f"copy_from_numpy: host shape {host.shape} != device shape {self.shape}")
         if self.layout == "nhwc":
@@ -334,6 +357,8 @@ class DeviceArray:
             hip.tf_memcpy(host.ctypes.data, self.ptr, host.nbytes, D2H)
         if self.layout == "nhwc":
             host = host.transpose(0, 3, 1, 2)
+        if is_bfloat16(self.dtype):
+            return bf16_bits_to_f32(np.ascontiguousarray(host))
         return np.ascontiguousarray(host).astype(np.float32)
 
     def view(self, shape, layout="row", offset_elems=0):
@@ -390,7 +415,10 @@ def asarray(x, dtype=np.float16, layout=None):
     if isinstance(x, DeviceArray):
         return x
     if hasattr(x, "detach"):
-        x = x.detach().cpu().numpy()
+        x = x.detach().cpu()
+        if str(x.dtype) == "torch.bfloat16":           # (numpy cannot hold it: go through float32, exact)
+            x, dtype = x.float(), bfloat16
+        x = x.numpy()
     return DeviceArray.from_numpy(np.asarray(x), dtype, layout)
 
 

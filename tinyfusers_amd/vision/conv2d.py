@@ -10,7 +10,7 @@ import numpy as np
 
 from .. import config
 from ..native import hip, lib
-from ..storage.tensor import DeviceArray, _sh, asarray
+from ..storage.tensor import DeviceArray, _sh, asarray, is_bfloat16
 from ..ff.linear import workspace, linear_f16
 
 
@@ -176,9 +176,25 @@ def _conv_small_c(x, w, bias, padding, stride, cache, gn=0):
 
 def conv_2d(X_gpu, W_gpu, padding, stride, dilation):
     """vision/conv2d.py:9-28: NCHW cross-correlation, no bias.  X (N,C,H,W) and W (K,C,R,S) logical shapes."""
+    if is_bfloat16(X_gpu.dtype):
+        return conv2d_bf16(X_gpu, W_gpu, None, padding, stride, dilation)
     if X_gpu.shape[1] % 8 != 0:
         return _conv_small_c(X_gpu, W_gpu, None, padding, stride, {})
     return _conv(X_gpu, W_gpu, None, padding, stride, dilation)
+
+
+def conv2d_bf16(x, w, bias, padding, stride, dilation, residual=None):
+    """The same operator on bfloat16 tensors (x NHWC, w (K, R, S, C) stored): tf_conv2d_bf16, channels a multiple of 8."""
+    n, c, h, wd = x.shape
+    k, cw, r, s_ = w.shape
+    assert c == cw and c % 8 == 0 and is_bfloat16(w.dtype), (x.shape, w.shape)
+    assert list(dilation) == [1, 1] and stride[0] == stride[1] and padding[0] == padding[1]
+    ho = (h + 2 * padding[0] - r) // stride[0] + 1
+    wo = (wd + 2 * padding[1] - s_) // stride[1] + 1
+    y = DeviceArray.empty((n, k, ho, wo), x.dtype, "nhwc")
+    hip.tf_conv2d_bf16(y.ptr, x.ptr, None, w.ptr, bias.ptr if bias is not None else None, None, 0,
+                       residual.ptr if residual is not None else None, n, h, wd, c, 0, k, r, s_, stride[0], padding[0], 0, _sh())
+    return y
 
 
 class Conv2d:
