@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 kernel_stats.csv per step: prof_summary.py <dir> <steps_in_run>"""
-import csv, glob, sys
+"""Summarise a rocprofv3 kernel_stats.csv per step: prof_summary.py <dir> <steps_in_run> [family.json]
+family.json: the k_igemm family's launches / ms per step / average launch, stamped with the hash of the kernel sources (bench.py quotes it next
+to its live HIP-event figure while the hash still matches)."""
+import csv, glob, json, os, sys
 d, steps = sys.argv[1], float(sys.argv[2])
 f = (glob.glob(d + "/*/*kernel_stats.csv") + glob.glob(d + "/*kernel_stats.csv"))[0]
 rows = list(csv.DictReader(open(f)))
@@ -14,3 +16,12 @@ for r in rows:
     out.append("%-64s calls/step %6.1f  ms/step %7.3f  avg_us %8.2f" % (n[:64], int(r["Calls"]) / steps, ms, float(r["AverageNs"]) / 1e3))
 print("\n".join(out))
 print("sum of kernel durations: %.3f ms/step over %d kernel launches/step" % (tot, sum(int(r["Calls"]) for r in rows if "rocclr" not in r["Name"]) / steps))
+if len(sys.argv) > 3:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bench import csrc_hash
+    fam = [r for r in rows if "k_igemm" in r["Name"]]
+    calls = sum(int(r["Calls"]) for r in fam)
+    ns = sum(float(r["TotalDurationNs"]) for r in fam)
+    json.dump({"csrc_sha16": csrc_hash(), "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e",
+               "k_igemm": {"launches_per_step": calls / steps, "ms_per_step": ns / 1e6 / steps, "avg_launch_us": ns / 1e3 / max(1, calls)}},
+              open(sys.argv[3], "w"), indent=1)

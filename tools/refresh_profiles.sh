@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_n1.json
 rm -rf $O/prof_stats $O/prof_fetch $O/prof_write $O/prof_sq
 rocprofv3 --kernel-trace --stats -d $O/prof_stats --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e > $O/prof_stats.log 2>&1
-python3 $R/tools/prof_summary.py $O/prof_stats 32 > $O/kernel_stats_per_step.txt      # steps executed: 2 in compile() + 5 warm-up + 20 timed + 5 instrumented
+python3 $R/tools/prof_summary.py $O/prof_stats 32 $O/kernel_family.json > $O/kernel_stats_per_step.txt      # steps executed: 2 in compile() + 5 warm-up + 20 timed + 5 instrumented
 cp $(ls $O/prof_stats/*/*kernel_stats.csv $O/prof_stats/*kernel_stats.csv 2>/dev/null | head -1) $O/kernel_stats.csv
 python3 $R/tools/step_profile.py $O/gemm_shapes.csv > $O/gemm_shapes.txt
 rocprofv3 --pmc FETCH_SIZE -d $O/prof_fetch --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-e2e > $O/prof_fetch.log 2>&1
