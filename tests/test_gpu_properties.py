@@ -98,3 +98,34 @@ def test_group_norm_invariances_at_96x96(tf):
     per_group = y.reshape(4, 32, -1)
     np.testing.assert_allclose(per_group.mean(-1), 0.0, atol=2e-3)
     np.testing.assert_allclose(per_group.var(-1), 1.0, atol=4e-3)
+
+
+def test_empty_inputs_are_accepted_and_bad_ones_rejected(tf):
+    """zero-size batches go through every hot entry as a no-op (status 0, nothing launched, nothing written); malformed arguments come
+    back as an error status with a message, never as a launch (the reference raises from CuPy / cuDNN in both cases)."""
+    import ctypes
+    from tinyfusers_amd.native import hip, lib
+    buf = tf.DeviceArray.zeros((4096,), np.float16, "row")
+    canary = buf.numpy().copy()
+    p = buf.ptr
+    st = None
+    hip.tf_linear_f16(p, p, p, None, None, 0, 320, 320, 0, None, 0, st)                                  # M = 0
+    hip.tf_linear_bf16(p, p, p, None, None, 0, 320, 320, st)
+    hip.tf_conv2d_f16(p, p, None, p, None, None, 0, None, 0, 8, 8, 64, 0, 64, 3, 3, 1, 1, 0, None, 0, st)   # N = 0
+    hip.tf_conv2d_bf16(p, p, None, p, None, None, 0, None, 0, 8, 8, 64, 0, 64, 3, 3, 1, 1, 0, st)
+    hip.tf_group_norm_f16(p, p, None, None, None, 0, 64, 64, 0, 8, 1e-5, 0, p, 1 << 20, st)               # N = 0
+    hip.tf_group_norm_bf16(p, p, None, None, None, 0, 64, 64, 0, 8, 1e-5, 0, p, 1 << 20, st)
+    hip.tf_layer_norm_f16(p, p, None, None, 0, 320, 1e-5, st)                                            # rows = 0
+    hip.tf_layer_norm_bf16(p, p, None, None, 0, 320, 1e-5, st)
+    hip.tf_sdpa_f16(p, p, p, p, 0, 8, 64, 64, 40, 0, 0, 40, 0, 0, 40, 0, 0, 40, 0, 0, 40, 0, st)          # B = 0
+    hip.tf_silu_f16(p, p, 0, st)
+    hip.tf_device_sync()
+    assert np.array_equal(buf.numpy(), canary)
+    for call in (lambda: lib.tf_linear_f16(p, p, p, None, None, 16, 320, 321, 0, None, 0, st),           # K not a multiple of 8
+                 lambda: lib.tf_linear_bf16(None, p, p, None, None, 16, 320, 320, st),                   # null output
+                 lambda: lib.tf_group_norm_f16(p, p, None, None, None, 1, 64, 60, 0, 8, 1e-5, 0, p, 1 << 20, st),   # C not divisible by G / by 8
+                 lambda: lib.tf_sdpa_f16(p, p, p, p, 1, 8, 64, 64, 44, 0, 0, 44, 0, 0, 44, 0, 0, 44, 0, 0, 44, 0, st),   # head size not a multiple of 8
+                 lambda: lib.tf_layer_norm_f16(p, p, p, None, 4, 320, 1e-5, st)):                        # gamma without beta
+        assert call() != 0 and lib.tf_last_error()
+    hip.tf_device_sync()
+    assert np.array_equal(buf.numpy(), canary)
