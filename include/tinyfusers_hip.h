@@ -261,6 +261,14 @@ int tf_softmax_rows_f32(void* out, const void* inp, int N, int C, tfStream_t s);
  * rows are ldc apart (ldc >= C; out's pad columns are zero-filled); mask_f32: (mask_rows, C) fp32 additive or NULL. */
 int tf_softmax_mask_rows_f16(void* out, const void* inp, const void* mask_f32, long long rows, int C, int ldc, float scale, long long mask_rows,
                              tfStream_t s);
+/* The same two steps with the scores kept in fp32 between them, as the reference keeps them (attention/sdpa.py:63-66: fp32 cp.matmul
+ * into `preatt`, softmax kernel native/cuda/softmax.cu:24-112 on fp32): tf_linear_f32out_f16 stores the raw fp32 accumulators
+ * y32(M,N) = x(M,K) . w(N,K)^T (fp16 operands, no bias / activation), tf_softmax_mask_rows_f32in_f16 reads them (rows ldi floats apart)
+ * and writes fp16 probabilities (rows ldo halves apart, pad columns C..ldo-1 zero-filled).  A scaled logit of several hundred -- the
+ * d = 512 single-head AttnBlock on real weights -- would lose 0.1 ... 1 in fp16 in front of the exp. */
+int tf_linear_f32out_f16(void* y_f32, const void* x, const void* w, int M, int N, int K, tfStream_t s);
+int tf_softmax_mask_rows_f32in_f16(void* out, int ldo, const void* inp_f32, int ldi, const void* mask_f32, long long rows, int C, float scale,
+                                   long long mask_rows, tfStream_t s);
 
 /* ---- normalisation ---------------------------------------------------------------------------
  * group_norm + GroupNorm affine (+ the SiLU that always follows it in ResBlock / UNet.out)

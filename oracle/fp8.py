@@ -3,8 +3,10 @@
 The reference has no fp8 path (it runs fp32 throughout, example/sd1.py:33); config 5 asks for one, gated at UNet rel-L2 <= 0.1 against
 the fp32 oracle.  This module restates the quantisation the HIP path applies so that (a) single ops can be
 checked tightly -- same e4m3 operands on both sides, fp32 accumulate -- and (b) the layer policy can be evaluated on the CPU:
-e4m3 weights with one scale per output channel (max|w| / 448), e4m3 activations with scale 1 (saturating), for the 3x3 convolutions
-with Cin, Cout >= 64 and the FeedForward linears; everything else as in oracle.unet."""
+e4m3 weights with one scale per output channel (max|w| / 448), e4m3 activations with scale 1 (saturating), for the two 3x3 convolutions
+of every ResBlock (Cin, Cout >= 64: their input is a GroupNorm + SiLU output) and the FeedForward linears (LayerNorm / GEGLU outputs);
+everything else as in oracle.unet -- in particular the up / down-sampling convs, whose input is the raw residual stream and has no
+business being cut to e4m3 at a fixed scale of 1 (saturation at 448, nothing below 2e-3)."""
 import numpy as np
 import torch
 
@@ -33,19 +35,28 @@ def decode_e4m3(raw_u8):
 
 
 class policy:
-    """``with oracle.fp8.policy():`` makes oracle.unet_forward evaluate the fp8 layer policy (3x3 convs with Cin, Cout >= 64 and the
-    FeedForward linears on e4m3 operands).  Restores the fp32 functions on exit."""
+    """``with oracle.fp8.policy():`` makes oracle.unet_forward evaluate the fp8 layer policy (the ResBlocks' 3x3 convs with
+    Cin, Cout >= 64 and the FeedForward linears on e4m3 operands).  Restores the fp32 functions on exit."""
 
     def __enter__(self):
         from . import unet as U
-        self._conv, self._ff = ops.conv2d_bias, U.feed_forward
-        conv0, lin0, geglu0 = ops.conv2d_bias, ops.linear, ops.geglu
+        self._conv, self._ff, self._res = ops.conv2d_bias, U.feed_forward, U.resblock
+        conv0, lin0, geglu0, res0 = ops.conv2d_bias, ops.linear, ops.geglu, U.resblock
+        inside = [0]                                       # > 0 while a ResBlock body runs
 
         def conv(x, w, b, padding=(0, 0), stride=(1, 1), dilation=(1, 1)):
             w_ = ops.as_t(w)
-            if w_.shape[-1] == 3 and w_.shape[0] >= 64 and w_.shape[1] >= 64 and w_.shape[1] % 64 == 0:
+            if inside[0] and w_.shape[-1] == 3 and w_.shape[0] >= 64 and w_.shape[1] >= 64 and w_.shape[1] % 64 == 0:
                 return conv0(quant_act(x), quant_weight(w_)[0], b, padding, stride, dilation)
             return conv0(x, w, b, padding, stride, dilation)
+
+        def res(*a, **k):
+            inside[0] += 1
+            try:
+                return res0(*a, **k)
+            finally:
+                inside[0] -= 1
+        U.resblock = res
 
         def ff(x, W, p):
             h = geglu0(quant_act(x), quant_weight(W[p + ".net.0.proj.weight"])[0], W[p + ".net.0.proj.bias"])
@@ -55,4 +66,4 @@ class policy:
 
     def __exit__(self, *a):
         from . import unet as U
-        ops.conv2d_bias, U.feed_forward = self._conv, self._ff
+        ops.conv2d_bias, U.feed_forward, U.resblock = self._conv, self._ff, self._res

@@ -166,28 +166,69 @@ def _sd_fp8(tf, images, latent, seed):
 @pytest.mark.parametrize("images,latent", [(1, 64), (4, 96)])
 def test_unet_fp8_policy_within_the_config5_gate(tf, images, latent):
     """The SD-1.x UNet forward with the fp8 layer policy vs the fp32 oracle: rel-L2 <= 0.1 -- at config 2's
-    shape and at config 5's per-GPU shape (96 x 96 latents, 4 images = UNet batch 8; the oracle runs image 0).  The fp16 path at the
-    same config-5 shape is checked against the same oracle output with its own gate (rel-L2 <= 5e-3)."""
+    shape and at config 5's per-GPU shape (96 x 96 latents, 4 images = UNet batch 8).  EVERY image of the batch is compared: the images
+    carry distinct latents and contexts, and image i's pair sits at rows (i, B + i) of the [uncond x B ; cond x B] batch (the D8
+    generalisation of variants/sd.py:31-44), so an indexing slip at B > 1 shows; the oracle runs one CFG pair at a time.  The fp16 path
+    at the same shapes is checked against the same oracle outputs with its own gate (rel-L2 <= 5e-3)."""
     import oracle
     from tinyfusers_amd import config
     sd, W, lat, ctx, unc = _sd_fp8(tf, images, latent, 77)
     Wt = {k: torch.from_numpy(v.astype(np.float32)) for k, v in W.items()}
-    x2 = np.concatenate([lat[:1], lat[:1]]); c2 = np.concatenate([unc[:1], ctx[:1]]).astype(np.float16).astype(np.float32)
     torch.set_num_threads(16)
-    ref = oracle.unet_forward(torch.from_numpy(x2.astype(np.float16).astype(np.float32)), np.array([981.0], np.float32), torch.from_numpy(c2), Wt).numpy()
+    assert images == 1 or not np.array_equal(lat[0], lat[1])
+    refs = []
+    for i in range(images):
+        x2 = np.concatenate([lat[i:i + 1], lat[i:i + 1]]).astype(np.float16).astype(np.float32)
+        c2 = np.concatenate([unc[i:i + 1], ctx[i:i + 1]]).astype(np.float16).astype(np.float32)
+        refs.append(oracle.unet_forward(torch.from_numpy(x2), np.array([981.0], np.float32), torch.from_numpy(c2), Wt).numpy())
 
     def run():
         ud, cd = tf.DeviceArray.from_numpy(unc), tf.DeviceArray.from_numpy(ctx)
         out = sd.get_model_output(ud, cd, sd.latent_from_numpy(lat), np.array([981.0]), np.array([7.5])).numpy()   # (2B,4,H,W): [uncond x B ; cond x B]
-        return np.stack([out[0], out[images]])
+        return [np.stack([out[i], out[images + i]]) for i in range(images)]
     got16 = run()
     config.set_dtype("fp8")
     try:
         got8 = run()
     finally:
         config.set_dtype("fp16")
-    rl = lambda a: float(np.linalg.norm(a - ref) / np.linalg.norm(ref))
-    assert np.isfinite(got8).all() and np.isfinite(got16).all()
-    assert rl(got16) <= 5e-3, rl(got16)
-    assert rl(got8) <= 0.1, rl(got8)
-    assert rl(got8) > 5e-3                                 # (the fp8 kernels really ran)
+    rl = lambda a, ref: float(np.linalg.norm(a - ref) / np.linalg.norm(ref))
+    for i in range(images):
+        assert np.isfinite(got8[i]).all() and np.isfinite(got16[i]).all()
+        assert rl(got16[i], refs[i]) <= 5e-3, (i, rl(got16[i], refs[i]))
+        assert rl(got8[i], refs[i]) <= 0.1, (i, rl(got8[i], refs[i]))
+        assert rl(got8[i], refs[i]) > 5e-3                    # (the fp8 kernels really ran)
+        for j in range(images):                            # ... and image i's output is not some other image's
+            assert j == i or rl(got16[i], refs[j]) > 0.05
+
+
+def test_fp8_policy_leaves_raw_inputs_and_foreign_modules_in_fp16(tf):
+    """with config.set_dtype('fp8') a conv whose input is NOT a normalised tensor (up / down-sampling convs: the raw residual
+    stream) and every module outside the UNet's ResBlocks must stay fp16: e4m3 at a fixed scale of 1 saturates at 448.  A raw input
+    with |x| far beyond 448 goes through a Downsample-style conv and a VAE-style ResnetBlock conv bit-identically in both modes."""
+    from tinyfusers_amd import config
+    from tinyfusers_amd.vision.conv2d import Conv2d
+    from tinyfusers_amd.vision.resnet import ResBlock
+    from tinyfusers_amd.ff.group_norm import GroupNorm
+    c = 64
+    conv = Conv2d(c, c, [3, 3], stride=[2, 2], padding=[1, 1], init=False)
+    conv.weight = tf.DeviceArray.from_numpy(rnd("p8.w", (c, c, 3, 3), 0.05), np.float16)
+    conv.bias = tf.DeviceArray.from_numpy(rnd("p8.b", (c,), 0.1), np.float16, "row")
+    x = rnd("p8.x", (2, c, 16, 16), 300.0)                    # |x| up to ~1200: e4m3 would clip a quarter of it
+    assert (np.abs(x) > 448).mean() > 0.1
+    xd = tf.DeviceArray.from_numpy(x, np.float16, "nhwc")
+    y16 = conv(xd).numpy()
+    gnm = GroupNorm(32, c, init=False)
+    gnm.weight = tf.DeviceArray.from_numpy(np.ones(c, np.float32), np.float16, "row"); gnm.bias = tf.DeviceArray.from_numpy(np.zeros(c, np.float32), np.float16, "row")
+    z16 = conv(xd, gn_in=(gnm, True)).numpy()                 # normalised input, but the module never opted in (a VAE conv)
+    config.set_dtype("fp8")
+    try:
+        np.testing.assert_array_equal(conv(xd).numpy(), y16)
+        np.testing.assert_array_equal(conv(xd, gn_in=(gnm, True)).numpy(), z16)
+        rb = ResBlock(c, 128, c, init=False)
+        assert rb.in_layers[2]._fp8_ok and rb.out_layers[3]._fp8_ok and not conv._fp8_ok
+    finally:
+        config.set_dtype("fp16")
+    from oracle import ops as O
+    want = O.conv2d_bias(x, rnd("p8.w", (c, c, 3, 3), 0.05), rnd("p8.b", (c,), 0.1), (1, 1), (2, 2)).numpy()
+    np.testing.assert_allclose(y16, want, rtol=1e-2, atol=0.5)

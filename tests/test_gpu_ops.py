@@ -349,6 +349,18 @@ def test_softmax_rows_and_own_runtime_kernels(tf):
         (d.transpose4d if len(shape) == 4 else d.transpose)(dst, src, axes)
         out = dst.to("cpu").data.reshape([shape[i] for i in axes])
         close(out, np.transpose(a, axes), atol=0, rtol=0)
+    # Tensor.T (storage/tensor.py:90-92 of the reference, driven as its tests/device.py:60-67 does): default axes (1, 0), then a 3-D permutation
+    a = rnd("trT", (13, 87))
+    a_t = tf.Tensor.from_np(a).eval(); out_t = tf.Tensor.zeros((13, 87), np.float32).eval()
+    a_t.T(out_t)
+    assert tuple(out_t.shape) == (87, 13)
+    got = out_t.to("cpu").data
+    assert got.shape == (87, 13)
+    close(got, a.T, atol=0, rtol=0)
+    a3 = rnd("trT3", (5, 7, 9))
+    o3 = tf.Tensor.zeros((5, 7, 9), np.float32).eval()
+    tf.Tensor.from_np(a3).eval().T(o3, axes=(2, 0, 1))
+    close(o3.to("cpu").data, np.transpose(a3, (2, 0, 1)), atol=0, rtol=0)
 
 
 @pytest.mark.parametrize("m,n,k,act", [(8192, 960, 320, 0), (2048, 640, 640, 0), (512, 1280, 1280, 0), (300, 128, 64, 0), (8192, 1280, 320, 1), (154, 64, 128, 1)])
@@ -373,6 +385,20 @@ def test_linear_with_folded_layer_norm(tf, m, n, k, act):
         w, bias = rnd("lnf.w", (2 * n, k), k ** -0.5), rnd("lnf.bias", (2 * n,), 0.1)
         ge = GEGLU(k, n, init=False); ge.proj.weight = dev(tf, w); ge.proj.bias = dev(tf, bias)
         close(ge(dev(tf, x), ln=ln).numpy(), O.geglu(xn, w, bias).numpy())
+
+
+@pytest.mark.parametrize("M,N,K,dt", [(500, 50, 8, torch.float16), (1000, 2000, 104, torch.float16), (64, 768, 768, torch.bfloat16), (37, 24, 40, torch.float32)])
+def test_linear_matmul_bias_half_output(tf, M, N, K, dt):
+    """ff/linear.py:66-80 `linear(X, W, B)` driven as tests/linear.py:15-60 drives it: torch tensors X (1, M, K), W (1, K, N), B (1, 1, N);
+    compared with torch.matmul(X, W) + B at the reference's atol = rtol = 1e-2."""
+    from tinyfusers_amd.ff.linear import linear
+    g = torch.Generator().manual_seed(0)
+    mat1 = torch.randn(1, M, K, generator=g).to(dt); mat2 = (torch.randn(1, K, N, generator=g) / K ** 0.5).to(dt); bias1 = torch.randn(1, 1, N, generator=g).to(dt)
+    got = linear(mat1, mat2, bias1)
+    assert got.shape == (M, N) and got.dtype == np.float16
+    h = lambda t: t.to(torch.float16).float()              # the operands as the fp16 kernel holds them
+    want = (torch.matmul(h(mat1).squeeze(0), h(mat2).squeeze(0)) + h(bias1).squeeze()).numpy()
+    close(got.numpy(), want)
 
 
 def test_linear_cublas_and_gemm_batch_fp32(tf):
@@ -659,6 +685,49 @@ def test_sdpa_masks_and_large_heads(tf, b, nh, tq, tk, hs, kind):
         mask = None
     got = scaled_dot_product_attention(dev(tf, q, "row"), dev(tf, k, "row"), dev(tf, v, "row"), mask).numpy()
     close(got, O.scaled_dot_product_attention(q, k, v, mask).numpy())
+
+
+@pytest.mark.parametrize("b,nh,tq,tk,hs", [(1, 1, 128, 256, 512), (1, 2, 96, 77, 256)])
+def test_sdpa_unfused_large_logits_keep_fp32_scores(tf, b, nh, tq, tk, hs):
+    """Scaled logits in the hundreds (what a d = 512 head sees on real weights): the scores must reach the softmax in fp32, as the
+    reference's do (attention/sdpa.py:63-66).  Stored as fp16 they would carry errors of 0.1 ... 0.25 at this size, i.e. 10 - 25 %
+    on every probability; rows are built so that several keys stay within a few units of the maximum (a one-hot row hides the error)."""
+    from oracle import ops as O
+    from tinyfusers_amd.attention.sdpa import scaled_dot_product_attention
+    q, k, v = rnd("big.q", (b, nh, tq, hs), 4.0), rnd("big.k", (b, nh, tk, hs), 4.0), rnd("big.v", (b, nh, tk, hs))
+    base = rnd("big.dir", (hs,), 4.0)
+    k = (k * 0.08 + base[None, None, None, :]).astype(np.float16).astype(np.float32)     # keys share a large common direction
+    q = (q * 0.25 + base[None, None, None, :]).astype(np.float16).astype(np.float32)
+    s = np.einsum("bhqd,bhkd->bhqk", q, k) / np.sqrt(hs)
+    assert np.abs(s).max() > 250 and np.median(s.max(-1) - np.sort(s, -1)[..., -4]) < 8.0, (np.abs(s).max(), np.median(s.max(-1) - np.sort(s, -1)[..., -4]))
+    got = scaled_dot_product_attention(dev(tf, q, "row"), dev(tf, k, "row"), dev(tf, v, "row")).numpy()
+    close(got, O.scaled_dot_product_attention(q, k, v).numpy())
+
+
+def test_clip_attention_general_mask(tf):
+    """attention/attention.py:88-104 with a mask that is not the causal one (a key-padding mask on top of it, additive form):
+    the reference hands any mask to sdpa.py:67-68; here it runs the unfused path on gathered heads."""
+    import oracle
+    from oracle import clip as OC
+    from tinyfusers_amd.attention.attention import CLIPAttention
+    from tinyfusers_amd.storage.state import update_state
+    from tinyfusers_amd.storage.synth import synth_tensor
+    t = 77
+    names = {f"{n}.{w}": ((768, 768) if w == "weight" else (768,)) for n in ("q_proj", "k_proj", "v_proj", "out_proj") for w in ("weight", "bias")}
+    W = {k_: synth_tensor(3, "clipattn." + k_, s_) for k_, s_ in names.items()}
+    m = CLIPAttention(init=False)
+    update_state(m, W, "")
+    x = rnd("clipattn.x", (2, t, 768))
+    mask = OC.causal_mask(t).numpy().copy()
+    mask[..., 40:] = -np.inf                                       # keys 40 .. 76 are padding
+    mask[..., np.arange(t), np.arange(t)] = np.where(np.arange(t) >= 40, 0.0, mask[..., np.arange(t), np.arange(t)])   # a padded query still sees itself
+    got = m(dev(tf, x, "row"), mask).numpy()
+    Wt = {"p." + k_: torch.from_numpy(v_.astype(np.float32)) for k_, v_ in W.items()}
+    want = OC.clip_attention(torch.from_numpy(x), Wt, "p.", torch.from_numpy(mask), 12).numpy()
+    close(got, want, atol=2e-2)
+    # ... and the causal mask itself still takes the fused kernel and agrees with the same oracle
+    cm = OC.causal_mask(t).numpy()
+    close(m(dev(tf, x, "row"), cm).numpy(), OC.clip_attention(torch.from_numpy(x), Wt, "p.", torch.from_numpy(cm), 12).numpy(), atol=2e-2)
 
 
 @pytest.mark.parametrize("c,hw", [(64, 8), (512, 16), (512, 64)])

@@ -225,20 +225,32 @@ class CLIPAttention:
         return self._fused[1]
 
     def __call__(self, hidden_states, causal_attention_mask=None, residual=None, ln=None):
-        """causal_attention_mask: None or the causal mask of vae/encoder.py:79 (host array); anything else is refused."""
-        from .sdpa import _is_causal_mask
+        """causal_attention_mask: None, the causal mask of vae/encoder.py:79 (host array) -- both on the fused flash kernel -- or any
+        other boolean / additive mask broadcastable to (b, heads, t, t) (attention/attention.py:94 hands it to sdpa.py:67-68 unchanged),
+        which runs the unfused matmul / softmax / matmul path on heads gathered to the contiguous (b, heads, t, d) layout."""
+        from .sdpa import _additive_mask, _is_causal_mask, sdpa_unfused
         b, t, c = hidden_states.shape
         nh, hs = self.num_heads, self.head_dim
         causal = causal_attention_mask is not None
-        if causal and not _is_causal_mask(causal_attention_mask, t, t):
-            raise NotImplementedError("CLIPAttention supports no mask or the causal mask")
+        general = causal and not _is_causal_mask(causal_attention_mask, t, t)
         if ln is not None:
             qkv = linear_ln_f16(hidden_states, self._qkv(ln), ln.eps)
         else:
             w, bias = self._qkv(None)
             qkv = linear_f16(hidden_states, w, bias)
+        o = DeviceArray.empty((b, t, c), np.float16, "row")
+        if general:
+            def heads_of(off):                                     # columns off .. off + c of qkv -> (b, heads, t, d), contiguous
+                out = DeviceArray.empty((b, nh, t, hs), np.float16, "row")
+                for i in range(b * nh):
+                    hip.tf_memcpy_2d_async(out.ptr + i * t * hs * 2, hs * 2, qkv.ptr + ((i // nh) * t * 3 * c + off + (i % nh) * hs) * 2, 3 * c * 2,
+                                           hs * 2, t, _sh())
+                return out
+            oh = sdpa_unfused(heads_of(0), heads_of(c), heads_of(2 * c), _additive_mask(causal_attention_mask, b, nh, t, t))
+            for i in range(b * nh):                                # heads back WITH the transpose (attention.py:96): (b, t, heads * d)
+                hip.tf_memcpy_2d_async(o.ptr + ((i // nh) * t * c + (i % nh) * hs) * 2, c * 2, oh.ptr + i * t * hs * 2, hs * 2, hs * 2, t, _sh())
+            return self.out_proj(o, residual=residual)
         q, k, v = qkv, qkv.view((b, t, 3 * c), "row", c), qkv.view((b, t, 3 * c), "row", 2 * c)
         st = (t * 3 * c, hs, 3 * c)
-        o = DeviceArray.empty((b, t, c), np.float16, "row")
         sdpa_strided(o, q, k, v, b, nh, t, t, hs, st, st, st, (t * c, hs, c), causal)
         return self.out_proj(o, residual=residual)

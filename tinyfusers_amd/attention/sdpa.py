@@ -41,45 +41,36 @@ def _additive_mask(attn_mask, B, NH, Tq, Tk):
 
 def sdpa_unfused(q, k, v, mask=None, scale=None):
     """The reference's own op sequence (attention/sdpa.py:63-76): scale * (q k^T) [+ mask] -> row softmax -> . v, per (batch, head)
-    on the MFMA GEMM kernel, scores in HBM as fp16.  q (B,NH,Tq,HS), k / v (B,NH,Tk,HS) contiguous row-major; any HS % 8 == 0, any mask.
-    The fused flash kernel (tf_sdpa_f16) is the hot path; this one covers masks other than causal and head sizes beyond 160."""
-    from ..ff.linear import linear_f16
+    on the MFMA GEMM kernel.  The scores stay in fp32 between the GEMM and the softmax as they do in the reference (its `preatt` is an
+    fp32 CuPy array): an fp16 score would be rounded at 1 / scale times the size the exp sees (22.6x at HS = 512).
+    q (B,NH,Tq,HS), k / v (B,NH,Tk,HS) contiguous row-major; any HS % 8 == 0, any mask.  The fused flash kernel (tf_sdpa_f16) is the hot
+    path; this one covers masks other than causal and head sizes beyond 160.  Everything that does not depend on the head -- padding
+    the keys to a multiple of 8, transposing V -- is done once for all heads; the per-head loop is GEMM, softmax, GEMM."""
     B, NH, Tq, HS = q.shape
     Tk = k.shape[-2]
     assert HS % 8 == 0, "sdpa_unfused: head size must be a multiple of 8"
     scale = float(1.0 / np.sqrt(HS)) if scale is None else float(scale)
     Tkp = (Tk + 7) // 8 * 8
+    heads = B * NH
+    if Tkp != Tk:                                                  # zero value rows beyond Tk: they meet zero probabilities (pad columns)
+        vp = DeviceArray.zeros((heads, Tkp, HS), np.float16, "row")
+        hip.tf_memcpy_2d_async(vp.ptr, Tkp * HS * 2, v.ptr, Tk * HS * 2, Tk * HS * 2, heads, _sh())
+    else:
+        vp = v
+    vt = DeviceArray.empty((heads, HS, Tkp), np.float16, "row")
+    hip.tf_nhwc_to_nchw_f16(vt.ptr, vp.ptr, heads, HS, 1, Tkp, _sh())         # (Tkp, HS) -> (HS, Tkp) for every head
     o = DeviceArray.empty((B, NH, Tq, HS), np.float16, "row")
+    s32 = DeviceArray.empty((Tq, Tk), np.float32, "row")            # one head's scores / probabilities, reused (stream order)
+    pr = DeviceArray.empty((Tq, Tkp), np.float16, "row")
     mrows = mask.shape[0] if mask is not None else 1
-    for bh in range(B * NH):
-        qi = q.view((Tq, HS), "row", bh * Tq * HS)
-        ki = k.view((Tk, HS), "row", bh * Tk * HS)
-        vi = v.view((Tk, HS), "row", bh * Tk * HS)
-        s = DeviceArray.zeros((Tq, Tkp), np.float16, "row") if Tkp != Tk else DeviceArray.empty((Tq, Tkp), np.float16, "row")
-        if Tkp == Tk:
-            hip.tf_linear_f16(s.ptr, qi.ptr, ki.ptr, None, None, Tq, Tk, HS, 0, None, 0, _sh())
-        else:
-            s = linear_f16(qi, _pad_rows(ki, Tkp))                 # zero key rows: their scores never reach the softmax (C = Tk)
+    for bh in range(heads):
+        hip.tf_linear_f32out_f16(s32.ptr, q.ptr + bh * Tq * HS * 2, k.ptr + bh * Tk * HS * 2, Tq, Tk, HS, _sh())
         mk = None
         if mask is not None:
             mk = mask.ptr + (bh * Tq * Tk * 4 if mrows != Tq else 0)
-        hip.tf_softmax_mask_rows_f16(s.ptr, s.ptr, mk, Tq, Tk, Tkp, scale, Tq, _sh())
-        vt = DeviceArray.zeros((HS, Tkp), np.float16, "row") if Tkp != Tk else DeviceArray.empty((HS, Tkp), np.float16, "row")
-        if Tkp == Tk:
-            hip.tf_nhwc_to_nchw_f16(vt.ptr, vi.ptr, 1, HS, 1, Tk, _sh())     # (Tk, HS) -> (HS, Tk)
-        else:
-            vp = _pad_rows(vi, Tkp)
-            hip.tf_nhwc_to_nchw_f16(vt.ptr, vp.ptr, 1, HS, 1, Tkp, _sh())
-        oi = o.view((Tq, HS), "row", bh * Tq * HS)
-        hip.tf_linear_f16(oi.ptr, s.ptr, vt.ptr, None, None, Tq, HS, Tkp, 0, None, 0, _sh())
+        hip.tf_softmax_mask_rows_f32in_f16(pr.ptr, Tkp, s32.ptr, Tk, mk, Tq, Tk, scale, Tq, _sh())
+        hip.tf_linear_f16(o.ptr + bh * Tq * HS * 2, pr.ptr, vt.ptr + bh * HS * Tkp * 2, None, None, Tq, HS, Tkp, 0, None, 0, _sh())
     return o
-
-
-def _pad_rows(a, rows):
-    r, c = a.shape
-    out = DeviceArray.zeros((rows, c), np.float16, "row")
-    hip.tf_memcpy_async(out.ptr, a.ptr, a.nbytes, 3, _sh())
-    return out
 
 
 def scaled_dot_product_attention(q_cp, k_cp, v_cp, attn_mask=None):

@@ -251,11 +251,12 @@ __global__ void __launch_bounds__(256) k_softmax_rows(float* __restrict__ out, c
 // matmul) that serves what the flash kernels do not: arbitrary additive / boolean masks (:67-68) and head sizes beyond 160
 // (the single-head d = 512 attention of the VAE's AttnBlock).  y[r, c] = softmax_c(scale * x[r, c] + mask[r % mask_rows, c]);
 // columns [C, ldc) of y are zero-filled (the P.V GEMM runs over the padded width).  fp32 math, one block per row.
-__global__ void __launch_bounds__(256) k_softmax_mask_rows_f16(half_t* __restrict__ y, const half_t* __restrict__ x, const float* __restrict__ mask,
-                                                               int C, int ldc, float scale, long long mask_rows) {
+template <typename TIN>                                  // TIN = half_t (in place on fp16 scores) or float (fp32 scores, rows ldi apart)
+__global__ void __launch_bounds__(256) k_softmax_mask_rows_f16(half_t* __restrict__ y, const TIN* __restrict__ x, const float* __restrict__ mask,
+                                                               int C, int ldc, int ldi, float scale, long long mask_rows) {
   __shared__ float red[8];
   const long long r = blockIdx.x;
-  const half_t* xr = x + r * ldc;
+  const TIN* xr = x + r * ldi;
   half_t* yr = y + r * ldc;
   const float* mr = mask ? mask + (r % mask_rows) * C : nullptr;
   int t = threadIdx.x, w = t >> 6, l = t & 63;
@@ -565,8 +566,18 @@ int tf_softmax_mask_rows_f16(void* out, const void* inp, const void* mask_f32, l
   TF_REQUIRE(out && inp && rows >= 0 && C >= 1 && ldc >= C && rows < (1LL << 31), "tf_softmax_mask_rows_f16: bad arguments (rows=%lld C=%d ldc=%d)", rows, C, ldc);
   TF_REQUIRE(!mask_f32 || mask_rows >= 1, "tf_softmax_mask_rows_f16: mask_rows=%lld", mask_rows);
   if (rows == 0) return TF_OK;
-  hipLaunchKernelGGL(k_softmax_mask_rows_f16, dim3((unsigned)rows), dim3(256), 0, tf_hs(s), (half_t*)out, (const half_t*)inp, (const float*)mask_f32, C, ldc,
-                     scale, mask_rows > 0 ? mask_rows : 1);
+  hipLaunchKernelGGL(k_softmax_mask_rows_f16<half_t>, dim3((unsigned)rows), dim3(256), 0, tf_hs(s), (half_t*)out, (const half_t*)inp, (const float*)mask_f32, C, ldc,
+                     ldc, scale, mask_rows > 0 ? mask_rows : 1);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_softmax_mask_rows_f32in_f16(void* out, int ldo, const void* inp_f32, int ldi, const void* mask_f32, long long rows, int C, float scale, long long mask_rows,
+                                   tfStream_t s) {
+  TF_REQUIRE(out && inp_f32 && rows >= 0 && C >= 1 && ldo >= C && ldi >= C && rows < (1LL << 31), "tf_softmax_mask_rows_f32in_f16: bad arguments (rows=%lld C=%d ldo=%d ldi=%d)", rows, C, ldo, ldi);
+  TF_REQUIRE(!mask_f32 || mask_rows >= 1, "tf_softmax_mask_rows_f32in_f16: mask_rows=%lld", mask_rows);
+  if (rows == 0) return TF_OK;
+  hipLaunchKernelGGL(k_softmax_mask_rows_f16<float>, dim3((unsigned)rows), dim3(256), 0, tf_hs(s), (half_t*)out, (const float*)inp_f32, (const float*)mask_f32, C, ldo,
+                     ldi, scale, mask_rows > 0 ? mask_rows : 1);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }

@@ -66,6 +66,9 @@ struct GemmP {
   const float* wscale; int out8, fp8;
   // bfloat16 operands, bias, residual and output (tf_linear_bf16 / tf_conv2d_bf16): the plain deep ring with the bf16 MFMA, no split-K
   int bf16;
+  // tf_linear_f32out_f16: the raw fp32 accumulators go to out32[m, n] (no bias / residual / activation, never split along K) -- the
+  // q k^T scores of the unfused attention path, which must not be rounded to fp16 before the softmax; NULL = off
+  float* out32;
 };
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;   // 128-bit buffer resource
@@ -177,7 +180,7 @@ __device__ __forceinline__ void gi_prologue(const GemmP& p, char* smem, int img,
   asm volatile("" ::: "memory");
   for (int c = t; c < C; c += 256) {
     f2 m = st[c / cpg];
-    float gm = p.gi_gamma ? (float)p.gi_gamma[c] : 1.0f, bt = p.gi_gamma ? (float)p.gi_beta[c] : 0.0f;
+    float gm = p.gi_gamma ? (float)p.gi_gamma[c] : 1.0f, bt = p.gi_beta ? (float)p.gi_beta[c] : 0.0f;
     float a = m[1] * gm;
     ab[c] = (f2){a, bt - m[0] * a};
   }
@@ -296,7 +299,7 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
   }
   constexpr int CPR = TN / 8;
   const bool vec = (p.N & 7) == 0;
-  float* part = p.splitk > 1 ? p.partial + (long long)split * p.M * p.N : nullptr;
+  float* part = p.splitk > 1 ? p.partial + (long long)split * p.M * p.N : p.out32;
   for (int idx = lane; idx < ROWS * CPR; idx += 64) {
     int row = idx / CPR, c8 = idx - row * CPR;
     int m = mb + row, n = nb + c8 * 8;
@@ -2131,7 +2134,7 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
     if (!p.fp8 && bm == 256 && (gemm_generic(p) || p.gi_part || p.ln_colsum || (long long)((p.M + 255) / 256) * ((p.N + 127) / 128) < 256)) continue;
     if (bn >= 128 && p.N <= 64) continue;
     for (int sk = 1; sk <= 32; sk *= 2) {
-      if (sk > 1 && (p.act == 1 || p.ln_colsum || p.ktiles / sk < 4 || !workspace || (size_t)sk * p.M * p.N * 4 > workspace_bytes)) break;
+      if (sk > 1 && (p.act == 1 || p.ln_colsum || p.out32 || p.ktiles / sk < 4 || !workspace || (size_t)sk * p.M * p.N * 4 > workspace_bytes)) break;
       long long blocks = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * sk;
       if (sk > 1 && blocks > 1024) break;
       for (int wide = 0; wide < 4; ++wide) {                // the launch_one variants
@@ -2196,9 +2199,14 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     if (p.gi_part) t.variant = p.S == 3 ? 2 : 0;
   } else if (g_autotune && !g_dbg) {
     std::array<int, 10> key = {p.M, p.N, p.K, p.C1, p.C2, p.S, p.stride, p.ups, p.act,
-                               (p.bias ? 1 : 0) | (p.residual ? 2 : 0) | (p.bias_nc ? 4 : 0) | (p.ln_colsum ? 8 : 0) | (p.gi_part ? 16 : 0) | (p.fp8 ? 64 : 0) | (p.out8 ? 128 : 0)};   // (on_z shares the plain key: same tile, another reduce kernel)
+                               (p.bias ? 1 : 0) | (p.residual ? 2 : 0) | (p.bias_nc ? 4 : 0) | (p.ln_colsum ? 8 : 0) | (p.gi_part ? 16 : 0) | (p.fp8 ? 64 : 0) | (p.out8 ? 128 : 0) | (p.out32 ? 256 : 0)};   // (on_z shares the plain key: same tile, another reduce kernel)
     auto it = g_tuned.find(key);
-    if (it != g_tuned.end()) { t = it->second; tuned = true; }
+    if (it != g_tuned.end()) {
+      t = it->second; tuned = true;
+      // a table row (shipped, or loaded from a user's file) whose tile cannot carry this launch's input GroupNorm -- the key holds
+      // only a gi flag, not HoWo / H / W -- falls back to the first admissible tile instead of failing the forward
+      if (p.gi_part && !gi_tile_ok(p, t.c.bm, t.c.bn, t.variant)) t = gi_default(p);
+    }
     else {
       hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
       (void)hipStreamIsCapturing(st, &cs);
@@ -2210,7 +2218,7 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
       }
     }
   }
-  if (p.ln_colsum) t.c.splitk = 1;                       // row statistics need the whole K range in one block
+  if (p.ln_colsum || p.out32) t.c.splitk = 1;            // row statistics need the whole K range in one block; so does the raw fp32 output
   if (t.c.splitk > 1) {
     size_t need = (size_t)t.c.splitk * p.M * p.N * sizeof(float);
     if (!workspace || workspace_bytes < need) t.c.splitk = 1;   // degrade gracefully: correctness does not depend on split-K
@@ -2298,7 +2306,7 @@ int tf_gemm_tune_load(const char* path) {
     // neither GEGLU nor the LayerNorm fold (flag bit 8) can be split along K
     const int act = k[8], ln = k[9] & 8;
     if (act == 1 && (bn % 64) != 0) ok = false;
-    if ((act == 1 || ln) && sk > 1) ok = false;
+    if ((act == 1 || ln || (k[9] & 256)) && sk > 1) ok = false;
     if (ok) g_tuned[k] = {{bm, bn, sk}, wide < 0 || wide > 3 ? 0 : wide, order != 0 ? 1 : 0};
   }
   fclose(f);
@@ -2526,6 +2534,24 @@ int tf_linear_f16(void* y, const void* x, const void* w, const void* bias, const
     p.x_bytes = (unsigned)xb; p.x2_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
   }
   return run_gemm(p, workspace, workspace_bytes, g_force_bm, g_force_bn, g_force_split, tf_hs(s));
+}
+
+// scores of the unfused attention path (attention/sdpa.py:66 of the reference: cp.matmul(q, k^T) in fp32): y32[m, n] = sum_k x[m, k] w[n, k],
+// fp16 operands, fp32 accumulators stored as they are
+int tf_linear_f32out_f16(void* y_f32, const void* x, const void* w, int M, int N, int K, tfStream_t s) {
+  TF_REQUIRE(y_f32 && x && w, "tf_linear_f32out_f16: null tensor");
+  TF_REQUIRE(M >= 0 && N >= 1 && K >= 8 && K % 8 == 0, "tf_linear_f32out_f16: K=%d must be a positive multiple of 8", K);
+  if (M == 0) return TF_OK;
+  GemmP p = {};
+  p.x = (const half_t*)x; p.w = (const half_t*)w; p.y = (half_t*)y_f32; p.out32 = (float*)y_f32;
+  p.M = M; p.N = N; p.K = K; p.Kc = K; p.C1 = K; p.C2 = 0; p.C = K;
+  p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.HoWo = M; p.S = 1; p.stride = 1; p.pad = 0; p.ups = 0; p.act = 0;
+  {
+    long long xb = (long long)M * K * 2, wb = (long long)N * K * 2;
+    TF_REQUIRE(xb < (1LL << 31) && wb < (1LL << 31), "tf_linear_f32out_f16: tensors must be < 2 GiB each");
+    p.x_bytes = (unsigned)xb; p.x2_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb; p.x3_bytes = p.x4_bytes = (unsigned)xb;
+  }
+  return run_gemm(p, nullptr, 0, g_force_bm, g_force_bn, g_force_split > 1 ? 1 : g_force_split, tf_hs(s));
 }
 
 // ---- bfloat16 entries: the reference's op tests parametrise bfloat16 next to float16 (tests/linear.py:13, tests/layer_norm.py:13,

@@ -65,6 +65,28 @@ def linear_ln_f16(x, folded, eps, residual=None, act=0, out_features=None):
     return y
 
 
+def linear(X_gpu, W_gpu, B_gpu):
+    """ff/linear.py:66-80, the reference's fused matmul + bias graph with a HALF output (tests/linear.py:15-60 calls it with torch
+    tensors): ``X_gpu`` (1, M, K), ``W_gpu`` (1, K, N) -- stored K-major, i.e. y = X @ W, not X @ W^T -- and ``B_gpu`` (1, 1, N), any of
+    torch / numpy / DeviceArray in fp16 / bf16 / fp32; returns the (M, N) fp16 DeviceArray the reference allocates as ``Y_actual``
+    (its (M, N) output holds one batch, so batch 1 is what the call means).  One MFMA GEMM launch with the bias in the epilogue; the
+    (K, N) weight is turned into the (N, K) rows the kernel streams by one device transpose."""
+    def f16(t):
+        if isinstance(t, DeviceArray):
+            assert t.dtype == np.float16, t.dtype
+            return t
+        if hasattr(t, "detach"):
+            t = t.detach().cpu().float().numpy()
+        return DeviceArray.from_numpy(np.ascontiguousarray(np.asarray(t, dtype=np.float32)), np.float16, "row")
+    xs, ws, bs = tuple(X_gpu.shape), tuple(W_gpu.shape), tuple(B_gpu.shape)
+    assert len(xs) == 3 and len(ws) == 3 and xs[0] == 1 and ws[0] == 1 and xs[2] == ws[1] and bs[-1] == ws[2], (xs, ws, bs)
+    M, K, N = xs[1], xs[2], ws[2]
+    x, w, b = f16(X_gpu), f16(W_gpu), f16(B_gpu)
+    wt = DeviceArray.empty((N, K), np.float16, "row")
+    hip.tf_nhwc_to_nchw_f16(wt.ptr, w.ptr, 1, N, 1, K, _sh())      # (K, N) -> (N, K)
+    return linear_f16(x.view((M, K), "row"), wt, b.view((N,), "row"))
+
+
 # cublasOperation_t (native/cublas/ops.py:55-58)
 CUBLAS_OP_N, CUBLAS_OP_T, CUBLAS_OP_C = 0, 1, 2
 

@@ -71,9 +71,10 @@ class FeedForward:
     def __call__(self, x, residual=None, ln=None):
         from . import fp8
         g, l2 = self.net[0], self.net[2]
-        if fp8.enabled() and x.shape[-1] % 64 == 0 and g.dim_out % 64 == 0 and g.proj.bias is not None:
-            # config 5: LayerNorm -> e4m3, GEGLU projection in fp8 with an e4m3 output, second Linear in fp8 (+ bias + residual, fp16 out)
-            h8 = fp8.layer_norm_fp8(x, ln) if ln is not None else fp8.quantize(x)
+        if fp8.enabled() and ln is not None and x.shape[-1] % 64 == 0 and g.dim_out % 64 == 0 and g.proj.bias is not None:
+            # config 5: LayerNorm -> e4m3, GEGLU projection in fp8 with an e4m3 output, second Linear in fp8 (+ bias + residual, fp16 out);
+            # only behind a LayerNorm (a raw input has no fixed scale)
+            h8 = fp8.layer_norm_fp8(x, ln)
             if getattr(g, "_cache8", None) is None:
                 g._cache8, l2._cache8 = {}, {}
             wp, bp = g._pack()                              # value | gate rows interleaved in 16-row blocks, then quantised row by row

@@ -1,89 +1,98 @@
-"""update_state -- mirrors tinyfusers/storage/state.py:4-23: recursive walk over __dict__ / namedtuple / list /
-dict building dotted LDM checkpoint names and replacing each ``weight`` / ``bias`` leaf.  The leaf becomes an
-fp16 DeviceArray (4-D conv weights are stored KRSC by the NHWC rule), uploaded once."""
-from collections import OrderedDict
-
+"""update_state -- the weight-name contract of tinyfusers/storage/state.py:4-23: attribute paths of the module tree ARE the
+LDM checkpoint keys, and the leaves named ``weight`` / ``bias`` are what a checkpoint fills.  Both entry points of this file
+(``update_state``: install tensors; ``param_shapes``: list names and shapes without touching the device) ride on one walker,
+``_slots``.  An installed leaf becomes an fp16 DeviceArray (4-D conv weights are stored KRSC by the NHWC rule), uploaded once."""
 import types
 
 import numpy as np
 
 from .tensor import DeviceArray, asarray
 
+_LEAVES = ("weight", "bias")
+_OPAQUE = (DeviceArray, np.ndarray, int, float, str, bool, bytes, type, types.FunctionType, types.BuiltinFunctionType, types.MethodType)
+
+
+def _children(node):
+    """(name, child, owner) of everything below ``node`` that can hold parameters, in the reference's visiting order: attributes
+    of an object, fields of a namedtuple, items of a list / tuple (named by index), entries of a dict.  ``owner`` is the dict a
+    leaf of that name must be written back into (None where the container cannot be assigned through: tuples)."""
+    if isinstance(node, dict):
+        return [(str(k), v, node) for k, v in list(node.items())]
+    if hasattr(node, "_asdict"):
+        return [(k, v, None) for k, v in node._asdict().items()]
+    if isinstance(node, (list, tuple)):
+        return [(str(i), v, None) for i, v in enumerate(node)]
+    if hasattr(node, "__dict__"):
+        return [(k, v, node.__dict__) for k, v in list(node.__dict__.items())]
+    return []
+
+
+def _slots(root, prefix=""):
+    """Yield (dotted name, owner dict, key, current value, module) for every ``weight`` / ``bias`` slot below ``root``.  Private
+    attributes (``_x``), scalars and arrays that are not such leaves are not descended into; ``module`` is the object the slot
+    belongs to (``param_shapes`` reads the shape off it)."""
+    stack = [(prefix, root)]
+    while stack:
+        pre, node = stack.pop()
+        below = []
+        for name, child, owner in _children(node):
+            dotted = f"{pre}.{name}" if pre else name
+            if name in _LEAVES and owner is not None:
+                yield dotted, owner, name, child, node
+            elif name.startswith("_") or child is None or isinstance(child, _OPAQUE):
+                continue
+            else:
+                below.append((dotted, child))
+        stack.extend(reversed(below))                      # depth first, siblings in declaration order
+
 
 def _to_numpy(v):
     if hasattr(v, "numpy") and not isinstance(v, np.ndarray):
-        v = v.numpy()                      # torch tensor, as in state.py:20
+        v = v.numpy()                                      # a torch tensor, as the reference's loader hands over (state.py:20)
     return np.asarray(v)
 
 
 def update_state(obj, state_dict, prefix=''):
-    if isinstance(obj, DeviceArray) or isinstance(obj, np.ndarray):
-        return
-    if hasattr(obj, '__dict__') and not isinstance(obj, type):
-        update_state(obj.__dict__, state_dict, f"{prefix}")
-    elif hasattr(obj, '_asdict'):
-        update_state(obj._asdict(), state_dict, prefix)
-    elif isinstance(obj, OrderedDict):
-        update_state(dict(obj), state_dict, prefix)
-    elif isinstance(obj, (list, tuple)):
-        for i, x in enumerate(obj):
-            update_state(x, state_dict, f"{prefix}.{str(i)}")
-    elif isinstance(obj, dict):
-        for k, v in list(obj.items()):
-            if k in {"weight", "bias"}:
-                if f"{prefix}.{k}" not in state_dict:
-                    if v is not None or not prefix.endswith((".to_q", ".to_k", ".to_v")):
-                        print(f"skipped: {prefix}.{k}")
-                    continue
-                obj[k] = asarray(_to_numpy(state_dict[f"{prefix}.{k}"]), np.float16)
-            elif k.startswith("_") or v is None or isinstance(v, (int, float, str, bool)):
-                continue
-            else:
-                pre = f"{prefix}.{k}" if prefix != '' else f"{k}"
-                update_state(v, state_dict, f"{pre}")
+    """Install ``state_dict[name]`` into every weight / bias slot below ``obj`` (storage/state.py:4-23: same names, same
+    ``skipped: <name>`` line for a key the checkpoint lacks -- except the bias probes of the bias-free q / k / v projections,
+    which the reference prints on every load)."""
+    for name, owner, key, cur, _ in _slots(obj, prefix):
+        if name not in state_dict:
+            if cur is not None or not name.endswith((".to_q.bias", ".to_k.bias", ".to_v.bias")):
+                print(f"skipped: {name}")
+            continue
+        owner[key] = asarray(_to_numpy(state_dict[name]), np.float16)
 
 
-def param_shapes(obj, prefix=""):
-    """name -> logical shape of every weight/bias leaf below ``obj`` (any of the package's modules, lists / namedtuples of
-    them, or the whole StableDiffusion), by the same attribute walk as update_state; nothing needs to be initialised."""
+def _leaf_shape(module, key):
     from ..ff.embedding import Embedding
     from ..ff.group_norm import GroupNorm
     from ..ff.layer_norm import LayerNorm
     from ..ff.linear import Linear
     from ..vision.conv2d import Conv2d
-    shapes = {}
+    if isinstance(module, Linear):
+        if key == "weight":
+            return (module.out_features, module.in_features)
+        return (module.out_features,) if module._has_bias else None
+    if isinstance(module, Conv2d):
+        return tuple(module._shape) if key == "weight" else (module._shape[0],)
+    if isinstance(module, GroupNorm):
+        return (module.num_channels,)
+    if isinstance(module, LayerNorm):
+        return tuple(module.normalized_shape)
+    if isinstance(module, Embedding):
+        return (module.vocab_sz, module.embed_sz) if key == "weight" else None
+    return None
 
-    def visit(o, pre):
-        if o is None or isinstance(o, (DeviceArray, np.ndarray, int, float, str, bool)):
-            return
-        if isinstance(o, Linear):
-            shapes[pre + ".weight"] = (o.out_features, o.in_features)
-            if o._has_bias:
-                shapes[pre + ".bias"] = (o.out_features,)
-        elif isinstance(o, Conv2d):
-            shapes[pre + ".weight"] = tuple(o._shape)
-            shapes[pre + ".bias"] = (o._shape[0],)
-        elif isinstance(o, GroupNorm):
-            shapes[pre + ".weight"] = (o.num_channels,); shapes[pre + ".bias"] = (o.num_channels,)
-        elif isinstance(o, LayerNorm):
-            shapes[pre + ".weight"] = tuple(o.normalized_shape); shapes[pre + ".bias"] = tuple(o.normalized_shape)
-        elif isinstance(o, Embedding):
-            shapes[pre + ".weight"] = (o.vocab_sz, o.embed_sz)
-        elif hasattr(o, "_asdict"):
-            for k, v in o._asdict().items():
-                visit(v, f"{pre}.{k}" if pre else k)
-        elif isinstance(o, (list, tuple)):
-            for i, x in enumerate(o):
-                visit(x, f"{pre}.{i}")
-        elif isinstance(o, dict):
-            for k, v in o.items():
-                visit(v, f"{pre}.{k}" if pre else str(k))
-        elif hasattr(o, "__dict__") and not isinstance(o, (type, types.FunctionType, types.BuiltinFunctionType, types.MethodType)):
-            for k, v in o.__dict__.items():
-                if k.startswith("_") or k in ("cfg", "alphas_cumprod"):
-                    continue
-                visit(v, f"{pre}.{k}" if pre else k)
-    visit(obj, prefix)
+
+def param_shapes(obj, prefix=""):
+    """name -> logical shape of every weight / bias leaf below ``obj`` (any of the package's modules, lists / namedtuples of
+    them, or the whole StableDiffusion), by the walk update_state makes; nothing needs to be initialised."""
+    shapes = {}
+    for name, _, key, _, module in _slots(obj, prefix):
+        shape = _leaf_shape(module, key)
+        if shape is not None:
+            shapes[name] = shape
     return shapes
 
 

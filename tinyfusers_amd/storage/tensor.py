@@ -473,6 +473,14 @@ class Tensor:
         from .device import Device
         return Device("hip")
 
+    def T(self, out_tensor, axes=(1, 0)):
+        """storage/tensor.py:90-92: permute this tensor's axes into ``out_tensor`` through the owning Device (the reference's
+        Device.transpose launch); ``out_tensor`` takes the permuted shape, and so does its host array for the ``to('cpu')`` that follows."""
+        self.device.transpose(out_tensor, self, tuple(axes))
+        if out_tensor.data is not None:
+            out_tensor.data = np.ascontiguousarray(out_tensor.data).reshape(out_tensor.shape)
+        return out_tensor
+
     @staticmethod
     def from_np(data):
         return Tensor(data.shape, data.dtype, data=data)

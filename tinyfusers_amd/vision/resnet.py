@@ -26,6 +26,7 @@ class ResBlock:
             Conv2d(out_channels, out_channels, kernel_size=[3, 3], padding=[1, 1], init=init),
         ]
         self.skip_connection = Conv2d(channels, out_channels, kernel_size=[1, 1], init=init) if channels != out_channels else lambda x: x
+        self.in_layers[2]._fp8_ok = self.out_layers[3]._fp8_ok = True     # config 5: both read GroupNorm + SiLU outputs (ff/fp8.py)
 
     def __call__(self, x, emb, emb_out=None, out_gn=0, out_norm=None):
         """out_gn = G: the block's output is read next by a GroupNorm(G); its statistics ride on the last conv.

@@ -1,3 +1,9 @@
+"""Per-row diagnostic of the fused SDPA kernel against the CPU oracle (GPU box only):  python tools/diag_sdpa.py
+
+For a handful of d = 40 shapes (the UNet's 64 x 64 level: self-attention 4096 x 4096, cross-attention 4096 x 77, plus small ragged
+ones) prints the max error, the per-row scale factor <got, want> / <want, want> (a row whose softmax denominator or running maximum
+went wrong shows as a factor != 1 while its direction is still right) and the first rows that are off by more than 2 %.  Written to
+run down the 16-deep-tail variant of round 2 (wrong rows at Tk = 77); kept as the first thing to run when an SDPA test fails."""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np, torch

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Register / spill / LDS census of every kernel in the built library (code-object metadata).
-usage: tools/kernel_regs.py [name-substring]     (TF_LIB=<path> for another build)"""
+usage: tools/kernel_regs.py [name-substring]     (TF_LIBDIR=<directory holding the .o files> for another build)"""
 import os, re, subprocess, sys, tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBDIR = os.environ.get("TF_LIBDIR", os.path.join(HERE, "..", "tinyfusers_amd", "lib"))
