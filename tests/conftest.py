@@ -17,5 +17,5 @@ def pytest_configure(config):
 def golden():
     import numpy as np
     d = os.path.join(ROOT, "tests", "golden")
-    return {n: np.load(os.path.join(d, n + ".npz")) for n in ("ops", "blocks", "unet_sd15")
+    return {n: np.load(os.path.join(d, n + ".npz")) for n in ("ops", "blocks", "unet_sd15", "unet50_sd15")
             if os.path.exists(os.path.join(d, n + ".npz"))}

@@ -15,7 +15,12 @@ so it is imported under stand-in modules, exactly as SURVEY 8(c) describes:
   * ``tinyfusers.tensor.tensor`` aliased to ``tinyfusers.storage.tensor`` (D1).
 Nothing from the reference is written anywhere: outputs are numeric arrays only.
 
-Usage:  python tests/golden/make_golden.py [ops] [blocks] [unet] [vae] [clip] [tokenizer]
+Usage:  python tests/golden/make_golden.py [ops] [blocks] [unet] [unet50] [vae] [clip] [tokenizer]
+
+``unet50`` runs the reference's StableDiffusion.__call__ over the WHOLE schedule of example/sd1.py:54-73 (50 steps) and keeps the
+latent after every tenth step and the final one (unet50_sd15.npz).  For that long run the cupy stand-in sends the five array functions
+that dominate the reference glue's CPU time (exp, tanh, matmul, dot, sqrt on large fp32 arrays) through multi-threaded torch instead of
+single-threaded numpy (TF_GOLDEN_FAST=0 keeps plain numpy); the reference's code is what runs either way.
 """
 import os
 import sys
@@ -42,6 +47,29 @@ def install_stubs():
                 pass
     cp.asnumpy = lambda a: np.asarray(a)
     cp.single = np.single
+    if os.environ.get("TF_GOLDEN_FAST", "0") != "0":
+        def _big(a):
+            return isinstance(a, np.ndarray) and a.dtype == np.float32 and a.size >= (1 << 16)
+
+        def _unary(name):
+            npf, tf_ = getattr(np, name), getattr(torch, name)
+
+            def f(a, *r, **k):
+                if _big(a) and not r and not k:
+                    return tf_(torch.from_numpy(np.ascontiguousarray(a))).numpy()
+                return npf(a, *r, **k)
+            return f
+        for name in ("exp", "tanh", "sqrt"):
+            setattr(cp, name, _unary(name))
+
+        def _mm(npf):
+            def f(a, b, *r, **k):
+                if _big(a) and isinstance(b, np.ndarray) and b.dtype == np.float32 and not r and not k and a.ndim >= 2 and b.ndim >= 2:
+                    return torch.matmul(torch.from_numpy(np.ascontiguousarray(a)), torch.from_numpy(np.ascontiguousarray(b))).numpy()
+                return npf(a, b, *r, **k)
+            return f
+        cp.matmul = _mm(np.matmul)
+        cp.dot = _mm(np.dot)
     rnd = types.ModuleType("cupy.random")
     rnd.uniform = lambda lo, hi, size=None, dtype=np.float32: np.random.uniform(lo, hi, size).astype(dtype)
     rnd.randn = lambda *s: np.random.randn(*s)
@@ -291,6 +319,39 @@ def gen_unet():
     print("unet_sd15.npz written (inputs: synth seed 1234 by name; weights: synth seed 0)")
 
 
+def gen_unet50():
+    """The whole 50-step schedule of example/sd1.py:54-73 through the reference's StableDiffusion.__call__ (variants/sd.py:56-59) and
+    UNetModel, same seeds / weights / contexts as gen_unet: the latent after every tenth step and the final one."""
+    from collections import namedtuple
+    from tinyfusers.vision.unet import UNetModel
+    from tinyfusers.variants.sd import StableDiffusion, get_alphas_cumprod
+    from oracle.unet import unet_param_shapes, SD15
+    W = synth(unet_param_shapes(SD15), seed=0)
+    unet = UNetModel(); install(unet, W, "")
+    del W
+    sd = StableDiffusion.__new__(StableDiffusion)
+    sd.alphas_cumprod = get_alphas_cumprod()
+    sd.model = namedtuple("DiffusionModel", ["diffusion_model"])(diffusion_model=unet)
+    latent = rnd("sd.latent", (1, 4, 64, 64), seed=1234)
+    ctx = rnd("sd.context", (1, 77, 768), seed=1234); unc = rnd("sd.uncond", (1, 77, 768), seed=1234)
+    timesteps = list(range(1, 1000, 1000 // 50))
+    alphas = sd.alphas_cumprod[timesteps]
+    alphas_prev = np.concatenate((np.array([1.0]), alphas[:-1])).astype(np.float32)
+    G = dict(timesteps=np.array(timesteps, dtype=np.float32), alphas=alphas, alphas_prev=alphas_prev)
+    x = latent
+    out = os.path.join(HERE, "unet50_sd15.npz")
+    for n, index in enumerate(range(49, -1, -1)):          # example/sd1.py:68: indices high -> low
+        t1 = time.time()
+        tid = np.array([index])
+        x = sd(unc, ctx, x, np.array([timesteps[index]]), alphas[tid], alphas_prev[tid], np.array([7.5]))
+        x = np.asarray(x, dtype=np.float32)
+        if (n + 1) % 10 == 0 or n < 2:
+            G[f"x_after_step{n}"] = np.array(x)
+            np.savez_compressed(out, **{k: np.asarray(v, dtype=np.float32) for k, v in G.items()})
+        print("step", n, "index", index, "%.1fs" % (time.time() - t1), "mean|x| %.4f" % float(np.abs(x).mean()), flush=True)
+    print("unet50_sd15.npz written (inputs: synth seed 1234 by name; weights: synth seed 0)")
+
+
 def gen_vae():
     """StableDiffusion.decode (variants/sd.py:48-54) through the reference's Decoder / AttnBlock / ResnetBlock."""
     from types import SimpleNamespace
@@ -406,6 +467,7 @@ def gen_tokenizer():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["ops", "blocks"]
     import_reference()
+    if "unet50" in what: gen_unet50()
     if "ops" in what: gen_ops()
     if "blocks" in what: gen_blocks()
     if "unet" in what: gen_unet()

@@ -118,6 +118,22 @@ def test_unet_full_sd15(golden):
     assert err < 2e-4, err
 
 
+def test_unet50_fixture_agrees_with_the_two_step_fixture(golden):
+    """unet50_sd15.npz (the reference's StableDiffusion.__call__ over all 50 steps, make_golden.py unet50 -- with exp / tanh / matmul
+    of the cupy stand-in on torch instead of numpy for speed) starts with the very two steps unet_sd15.npz holds (plain numpy stand-in):
+    same reference code, same inputs, results equal to float round-off; and it holds the checkpoints the GPU test gates."""
+    if "unet50_sd15" not in golden or "unet_sd15" not in golden:
+        pytest.skip("fixtures not generated")
+    g50, g2 = golden["unet50_sd15"], golden["unet_sd15"]
+    for n in (0, 1):
+        a, b = g50[f"x_after_step{n}"], g2[f"x_after_step{n}"]
+        assert float(np.abs(a - b).max()) < 2e-5 * (1 + float(np.abs(b).max())), n
+    for n in (9, 19, 29, 39, 49):
+        x = g50[f"x_after_step{n}"]
+        assert x.shape == (1, 4, 64, 64) and np.isfinite(x).all()
+    np.testing.assert_array_equal(g50["timesteps"], g2["timesteps"])
+
+
 @pytest.mark.slow
 def test_vae_decode_sd15(golden):
     """decode() of the reference (VAE decoder incl. its per-channel AttnBlock) on the golden latent (~40 s on 8 cores)."""

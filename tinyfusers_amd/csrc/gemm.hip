@@ -1492,6 +1492,364 @@ __global__ void __launch_bounds__(512, 2) k_igemm8(const GemmP p) {
   if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 0, lane);
 }
 
+// =====================================================================================================================
+// PING-PONG variant for problems that fill the chip with 256-row tiles (more images per GPU, 96 x 96 latents: BASELINE config 5):
+// ALL EIGHT waves load and compute.  The loader / consumer split of k_igemm leaves the matrix pipe to four waves and tops out at
+// ~1.1 PFLOP/s; here the block tile is 256 x BN (BN = 128 / 160 / 256), the waves form a 4 (pixels) x 2 (channels) grid of 64 x BN/2
+// accumulator tiles (64 ... 128 VGPRs), and the two halves of the workgroup -- waves 0-3 and 4-7, one of each per SIMD -- run the same
+// program ONE BARRIER APART: while one half issues its 16-40 MFMAs of a 32-deep k-step, the other half reads the fragments of its
+// next k-step from LDS and issues its share of the LDS-DMA for a later K tile; at the next s_barrier they swap.  So the matrix pipe
+// of every SIMD always has a wave feeding it and the DMA issue cost (60-180 cycles per 1-KiB piece) hides under the partner's MFMAs.
+//   ring: NS = 3 slots (BN <= 160) or 2 (BN = 256) of (256 + BN) x 128 B, tile t in slot t % NS; during tile t every wave issues its
+//     pieces of tile t + NS - 1 (activation pieces with k-step 0, weight pieces with k-step 1) into the slot of tile t - 1.
+//   RAW: a wave's counted s_waitcnt vmcnt for its pieces of tile t+1 sits in the last half-phase before the barrier that precedes the
+//     FIRST half's k-step 0 of tile t+1 (first half: behind its MFMAs of (t, k1); second half: at the end of its load segment of
+//     (t, k1)); every read of tile t+1 comes behind that barrier.
+//   WAR: every load segment ends with s_waitcnt lgkmcnt(0) IN FRONT OF its barrier, so behind a barrier all reads issued before it
+//     are done; the second half's last reads of tile t-1 end before the barrier in front of the first half's (t, k0) segment, which is
+//     the earliest place a DMA into that slot is issued.
+//   LDS-DMA is issued from inline asm (M0 + buffer_load ... lds): the compiler does not see an LDS write and therefore puts no
+//     s_waitcnt vmcnt(0) in front of the fragment reads; all vmcnt bookkeeping is the counted waits above.
+// Epilogue: the accumulators go through the 2 x 2-wave-tile scratch of k_igemm in two passes of 128 rows (igemm_epilogue<128, BN>), so
+// bias / time embedding / residual / GEGLU / split-K partials / GroupNorm statistics are the shared code, chunked as a 128-row tile.
+// Channel counts on the 64 grid (taps and concat sources advance as wave-uniform scalars), no LayerNorm fold, no input GroupNorm.
+typedef int i4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i4v raw_rsrc(const void* base, unsigned bytes) {
+  unsigned long long a = (unsigned long long)base;
+  i4v r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void dma16(i4v rsrc, unsigned voffset_bytes, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(__builtin_amdgcn_readfirstlane((int)lds_base)), "v"(voffset_bytes), "s"(rsrc) : "memory");   // M0 has no other user in this kernel
+}
+
+// NP = half-phases per K tile and wave group: 2 = one per 32-deep k-step (fragments of one k-step in registers), 1 = the whole K tile per
+//   phase (both k-steps' fragments in registers, half the barriers; needs the 3-slot ring: with two slots the second half would issue a
+//   tile's pieces and wait for them in the same segment).
+// FASTA = the lean activation addressing for stride-1 convolutions without up-sampling (and linears): per piece a pixel index and a
+//   bit mask of the taps that fall inside the image, so a tile's source offset is one mad + one mask test instead of the bounds
+//   arithmetic of the general gather (the load segments, not the MFMAs, set this kernel's pace: every VALU / SALU instruction in them counts).
+// DBG: the ablation build (p.dbg: 1 no epilogue, 2 no MFMA, 4 no staging in the loop, 8 no fragment reads)
+template <int BN, int NP, bool FASTA, bool DBG = false>
+__global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
+  constexpr int BM = 256, TN = BN / 2, MJ = 4, NI = TN / 16;
+  constexpr int NWG = BN / 8;                             // weight pieces (8 rows x 128 B) of a stage; 32 activation pieces in front of them
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int NS = (163840 / STAGE) >= 3 ? 3 : 2;
+  constexpr int D = NS - 1;                               // K tiles in flight ahead of the one being multiplied
+  constexpr int WPW = (NWG + 7) / 8;                      // weight pieces per wave (the last one only on waves < NWG % 8 where that is not 0)
+  constexpr int WREM = NWG % 8;
+  constexpr int KF = NP == 1 ? 2 : 1;                     // k-steps whose fragments are held at once
+  static_assert(TN % 16 == 0 && BN % 32 == 0, "tile shape");
+  static_assert(NP == 2 || (NP == 1 && NS >= 3), "one phase per K tile needs the 3-slot ring");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2;                               // 0: first half (runs one barrier ahead), 1: second half
+  const int wm = wid & 3, wn = wid >> 2;                  // wave tile: pixels 64 wm .., channels TN wn ..
+  const int ntiles = p.ntm * p.ntn;
+  const int nblk = ntiles * p.splitk;
+  int bid = blockIdx.x;
+  {
+    int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;      // XCD-aware order, as in k_igemm
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int split = bid / ntiles;
+  const int tid_ = bid - split * ntiles;
+  int tile_m, tile_n;
+  if (p.order == 0) { tile_m = tid_ / p.ntn; tile_n = tid_ - tile_m * p.ntn; }
+  else { tile_n = tid_ / p.ntm; tile_m = tid_ - tile_n * p.ntm; }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kt_begin = split * p.ktiles_per_split;
+  const int kt_end = min(p.ktiles, kt_begin + p.ktiles_per_split);
+  const int nt = kt_end - kt_begin;
+
+  // ---- staging state: wave w owns activation pieces w + 8 i (i < 4) and weight pieces w + 8 i (i < WPW, below NWG)
+  const i4v rs_w = raw_rsrc(p.w, p.w_bytes);
+  const int sub = lane >> 3;
+  const int cs = (lane & 7) ^ ((4 * (wid & 1) + (sub >> 1)) & 7);       // source chunk of this lane: XOR swizzle on the SOURCE side (see k_igemm)
+  // general gather: (hi0, wi0, first pixel of the image) per piece; FASTA: (pixel index of the output position, tap-validity mask, -)
+  int g_a[4], g_b[4], g_c[4];
+  unsigned gw[WPW];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + 8 * (wid + 8 * i) + sub;
+    g_a[i] = FASTA ? 0 : -(1 << 28); g_b[i] = 0; g_c[i] = 0;
+    if (m < p.M) {
+      int img = fast_div(m, p.dv_howo_mul, p.dv_howo_shr), rem = m - img * p.HoWo;
+      int ho = fast_div(rem, p.dv_wo_mul, p.dv_wo_shr), wo = rem - ho * p.Wo;
+      if constexpr (FASTA) {
+        // stride 1, no up-sampling: input pixel of tap (r, s) = output position + (r - pad) W + (s - pad); bit r S + s of the mask tells
+        // whether it lies inside the image, bit 31 marks a live row (the extra 1x1 segment and 1x1 convolutions read the position itself)
+        g_a[i] = img * p.H * p.W + ho * p.W + wo;
+        unsigned mask = 0x80000000u;
+        for (int r = 0; r < p.S; ++r)
+          for (int s_ = 0; s_ < p.S; ++s_)
+            if ((unsigned)(ho - p.pad + r) < (unsigned)p.H && (unsigned)(wo - p.pad + s_) < (unsigned)p.W) mask |= 1u << (r * p.S + s_);
+        g_b[i] = (int)mask;
+      } else {
+        g_a[i] = ho * p.stride - p.pad;
+        g_b[i] = wo * p.stride - p.pad;
+        g_c[i] = img * p.H * p.W;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) {
+    const int g = wid + 8 * i, n = n0 + 8 * g + sub;
+    gw[i] = (g < NWG && n < p.N) ? (unsigned)(n * p.K + cs * 8) * 2u : TF_OOB;
+  }
+  const int Hl = p.H << p.ups, Wl = p.W << p.ups;
+  const unsigned lds0 = lds_off(smem);
+  int st_r, st_s, st_c;                                    // wave-uniform (tap, channel) of the next tile whose activation pieces are staged
+  {
+    int kg0 = kt_begin * 64;
+    if (kg0 < p.Kc) {
+      int tap = kg0 / p.C;
+      st_c = kg0 - tap * p.C;
+      st_r = tap / p.S;
+      st_s = tap - st_r * p.S;
+    } else { st_r = -1; st_s = 0; st_c = kg0 - p.Kc; }
+  }
+  // The scalars of a tile's activation pieces are prepared one half-phase early, in the MFMA shadow: kernel-argument loads and the tap
+  // bookkeeping would otherwise sit between the fragment reads and the DMA issue of a load segment (and their s_waitcnt lgkmcnt(0)
+  // would wait for the LDS reads as well).  General gather: (r, s, first channel, row pitch); FASTA: (tap bit, byte offset of the tap
+  // + first channel, row pitch in bytes).
+  int a_r = 0, a_s = 0, a_c0 = 0, a_ld = 0;
+  int a_lo = 0, a_hi = 0, a_nb = 0;                        // descriptor words of the tile's source tensor (base low / high, bytes)
+  const int ups = p.ups, Wd = p.W, pad_ = p.pad, S_ = p.S;
+  // every kernel argument the per-tile bookkeeping needs, read ONCE: an s_load inside the K loop costs its full latency in a wave that
+  // has nothing else to issue
+  const int C1_ = p.C1, C2_ = p.C2, C3_ = p.C3, C4_ = p.C4, Cc_ = p.C, Kc_ = p.Kc;
+  const unsigned long long px1 = (unsigned long long)p.x, px2 = (unsigned long long)(p.x2 ? p.x2 : p.x);
+  const unsigned long long px3 = (unsigned long long)(p.x3 ? p.x3 : p.x), px4 = (unsigned long long)(p.x4 ? p.x4 : p.x);
+  const int nb1 = (int)p.x_bytes, nb2 = (int)p.x2_bytes, nb3 = (int)p.x3_bytes, nb4 = (int)p.x4_bytes;
+  // Tiles come in runs: the 64-channel tiles of one (tap, source tensor) differ only in the first channel.  run_left = tiles of the
+  // current run still to be prepared after the last one; inside a run the bookkeeping is one add (a few SALU instructions instead of
+  // ~60: they sit in the MFMA half of a phase and lengthen it one for one).  (st_r, st_s, st_c) is normalised lazily: at the head of a run.
+  int run_left = 0;
+  auto prep_act = [&]() {
+    if (run_left > 0) {
+      --run_left;
+      st_c += 64;
+      a_c0 += FASTA ? 128 : 64;
+    } else {
+      bool second;
+      int r, s_, c0, ld, seg_end;
+      unsigned long long px;
+      if (st_r >= 0 && st_c >= Cc_) { st_c = 0; if (++st_s == S_) { st_s = 0; if ((++st_r) * S_ * Cc_ >= Kc_) st_r = -1; } }
+      const bool extra = st_r < 0;
+      if (!extra) {
+        r = st_r; s_ = st_s;
+        second = st_c >= C1_;
+        ld = second ? C2_ : C1_;
+        c0 = second ? st_c - C1_ : st_c;
+        seg_end = second ? Cc_ : C1_;
+        px = second ? px2 : px1; a_nb = second ? nb2 : nb1;
+      } else {
+        r = pad_; s_ = pad_;                               // the extra 1x1 segment reads the output pixel itself
+        second = st_c >= C3_;
+        ld = second ? C4_ : C3_;
+        c0 = second ? st_c - C3_ : st_c;
+        seg_end = second ? C3_ + C4_ : C3_;
+        px = second ? px4 : px3; a_nb = second ? nb4 : nb3;
+      }
+      a_lo = (int)(unsigned)px; a_hi = (int)((unsigned)(px >> 32) & 0xffffu);
+      run_left = ((seg_end - st_c) >> 6) - 1;
+      st_c += 64;
+      if constexpr (FASTA) {
+        a_r = extra ? (int)0x80000000u : (1 << (r * S_ + s_));
+        a_c0 = (((r - pad_) * Wd + (s_ - pad_)) * ld + c0) * 2;
+        a_ld = ld * 2;
+      } else { a_r = r; a_s = s_; a_c0 = c0; a_ld = ld; }
+    }
+  };
+  auto stage_act = [&](int slot) {
+    const unsigned base = lds0 + (unsigned)slot * STAGE + (unsigned)wid * 1024u;
+    // (the scalars are wave-uniform by construction; the readfirstlanes are no-ops that keep them in SGPRs whatever the compiler's
+    // divergence analysis makes of the bookkeeping's control flow)
+    i4v rs;
+    rs[0] = __builtin_amdgcn_readfirstlane(a_lo); rs[1] = __builtin_amdgcn_readfirstlane(a_hi);
+    rs[2] = __builtin_amdgcn_readfirstlane(a_nb); rs[3] = 0x00020000;
+    const int s_r = __builtin_amdgcn_readfirstlane(a_r), s_c0 = __builtin_amdgcn_readfirstlane(a_c0), s_ld = __builtin_amdgcn_readfirstlane(a_ld);
+    if constexpr (FASTA) {
+      const int vc = s_c0 + cs * 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned off = __umul24((unsigned)g_a[i], (unsigned)s_ld) + (unsigned)vc;
+        dma16(rs, (g_b[i] & s_r) ? off : TF_OOB, base + (unsigned)i * 8192u);
+      }
+    } else {
+      const int s_s = __builtin_amdgcn_readfirstlane(a_s);
+      const int cc = s_c0 + cs * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int hi = g_a[i] + s_r, wi = g_b[i] + s_s;
+        bool ok = (unsigned)hi < (unsigned)Hl && (unsigned)wi < (unsigned)Wl;
+        int pix = g_c[i] + (hi >> ups) * Wd + (wi >> ups);
+        dma16(rs, ok ? (unsigned)(pix * s_ld + cc) * 2u : TF_OOB, base + (unsigned)i * 8192u);
+      }
+    }
+  };
+  auto stage_w = [&](int slot, int kt) {
+    const unsigned base = lds0 + (unsigned)slot * STAGE + (unsigned)(32 + wid) * 1024u;
+    const unsigned kb = (unsigned)kt * 128u;
+#pragma unroll
+    for (int i = 0; i < WPW; ++i)
+      if (WREM == 0 || i < WPW - 1 || wid < WREM) dma16(rs_w, gw[i] != TF_OOB ? gw[i] + kb : TF_OOB, base + (unsigned)i * 8192u);
+  };
+  // "this wave's pieces of every tile but the newest one (NEWEST) / of every tile (!NEWEST) have landed"
+  auto wait_landed = [&](auto newest) {
+    if constexpr (decltype(newest)::value && D >= 2) {
+      if (WREM == 0 || wid < WREM) wait_vm<4 + WPW>(); else wait_vm<4 + WPW - 1>();
+    } else wait_vm<0>();
+  };
+
+  // ---- fragment addresses inside a stage: the swizzle term depends on lane only (tile offsets are multiples of 16 rows)
+  const int lr = lane & 15, lg = lane >> 4;
+  const int fo = lr * 128 + ((lg ^ ((lr >> 1) & 7)) << 4);
+  const int xo = wm * 64 * 128 + fo;                       // + j * 2048
+  const int wo_ = (BM + wn * TN) * 128 + fo;               // + i * 2048
+  f4 acc[NI][MJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+  h8 wf[KF][NI], xf[KF][MJ];
+  if constexpr (DBG) {
+#pragma unroll
+    for (int f = 0; f < KF; ++f) {
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) xf[f][j] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < NI; ++i) wf[f][i] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  auto read_k = [&](const char* sb, int k2, int f) {      // fragments of k-step k2 into register set f
+    if constexpr (DBG) { if (p.dbg & 8) return; }
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) xf[f][j] = *reinterpret_cast<const h8*>(sb + ((xo + j * 2048) ^ (k2 * 64)));
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wf[f][i] = *reinterpret_cast<const h8*>(sb + ((wo_ + i * 2048) ^ (k2 * 64)));
+  };
+  auto mma = [&]() {                                       // the MFMAs of every k-step held in registers
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DBG) {
+      if (p.dbg & 2) {
+#pragma unroll
+        for (int f = 0; f < KF; ++f) {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(wf[f][i]));
+#pragma unroll
+          for (int j = 0; j < MJ; ++j) asm volatile("" ::"v"(xf[f][j]));
+        }
+        return;
+      }
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int f = 0; f < KF; ++f)
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[f][i], xf[f][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto barrier = [&]() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  // ---- prologue: the first D tiles, whole
+#pragma unroll
+  for (int s_ = 0; s_ < D; ++s_)
+    if (s_ < nt) { prep_act(); stage_act(s_); stage_w(s_, kt_begin + s_); }
+  if (D < nt) prep_act();                                  // the scalars of tile D: its pieces ride on tile 0
+  if (D >= 2 && nt >= 2) wait_landed(std::true_type{}); else wait_landed(std::false_type{});     // tile 0 landed
+  barrier();                                               // P: tile 0 is visible to every wave
+  if (grp == 1) barrier();                                 // the second half falls one barrier behind
+  int rs = 0, ws = D % NS;                                 // ring slot of tile t / of tile t + D
+  int ktw = kt_begin + D;                                  // K tile whose weight pieces are staged next
+  // one K tile.  MORE: tile t + D exists (its pieces are issued during this tile, and the wait for tile t + 1 leaves them in flight);
+  // NEXT: tile t + 1 exists (it must have landed before the barrier in front of the first half's next load segment).
+  auto tile = [&](auto more_c, auto next_c) {
+    constexpr bool MORE = decltype(more_c)::value, NEXT = decltype(next_c)::value;
+    const char* sb = smem + rs * STAGE;
+    bool more = MORE;
+    if constexpr (DBG) { if (p.dbg & 4) more = false; }
+    if constexpr (NP == 1) {
+      read_k(sb, 0, 0);
+      read_k(sb, 1, 1);
+      if (more) { stage_act(ws); stage_w(ws, ktw); }
+      if constexpr (NEXT) { if (grp == 1) wait_landed(more_c); }
+      wait_lds_reads();
+      barrier();
+      mma();
+      if constexpr (MORE) prep_act();                      // scalars of tile t + 1 + D (harmless past the end: arguments only)
+      if constexpr (NEXT) { if (grp == 0) wait_landed(more_c); }
+      barrier();
+    } else {
+      read_k(sb, 0, 0);
+      if (more) stage_act(ws);
+      wait_lds_reads();
+      barrier();
+      mma();
+      barrier();
+      read_k(sb, 1, 0);
+      if (more) stage_w(ws, ktw);
+      if constexpr (NEXT) { if (grp == 1) wait_landed(more_c); }
+      wait_lds_reads();
+      barrier();
+      mma();
+      if constexpr (MORE) prep_act();
+      if constexpr (NEXT) { if (grp == 0) wait_landed(more_c); }
+      barrier();
+    }
+    if (++rs == NS) rs = 0;
+    if (++ws == NS) ws = 0;
+    ++ktw;
+  };
+  {
+    int t = 0;
+    for (; t + D < nt; ++t) tile(std::true_type{}, std::true_type{});          // steady state
+    for (; t + 1 < nt; ++t) tile(std::false_type{}, std::true_type{});         // drain: nothing left to stage
+    tile(std::false_type{}, std::false_type{});                                // last tile
+  }
+  if (grp == 0) barrier();                                 // the first half waits for the second: every wave is done with the ring
+
+  if constexpr (DBG) {
+    if (p.dbg & 1) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) asm volatile("" ::"v"(acc[i][j]));
+      return;
+    }
+  }
+  // ---- epilogue: two passes of 128 rows through the shared scratch (wave (wm, wn) is quadrant (wm & 1, wn) of sub-block wm >> 1)
+  f4 csum[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) csum[i] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int sm = 0; sm < 2; ++sm) {
+    if ((wm >> 1) == sm) igemm_scratch_write<128, BN>(p, acc, csum, smem, (wm & 1) | (wn << 1), lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    barrier();
+    igemm_epilogue<128, BN>(p, smem, m0 + sm * 128, n0, split, wid & 3, wid >> 2, lane);
+    if (p.gn_part && m0 + sm * 128 < p.M) igemm_gn_stats<128, BN>(p, smem, m0 + sm * 128, n0, wid & 3, wid >> 2, lane);   // (block-uniform: the barrier inside is safe)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    barrier();
+  }
+}
+
 // split-K reduce + epilogue: y[m,n] = sum_z partial[z,m,n] + bias + bias_nc + residual   (N % 4 == 0 fast path)
 __global__ void __launch_bounds__(256) k_splitk_reduce(half_t* __restrict__ y, const float* __restrict__ partial, const half_t* __restrict__ bias,
                                                        const half_t* __restrict__ bias_nc, const half_t* __restrict__ residual, int M, int N,
@@ -1958,6 +2316,52 @@ static int launch8(const GemmP& p, hipStream_t st) {
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
+// k_igemm_pp (variant 4): 256 x BN tiles, every channel count on the 64 grid, no LayerNorm fold, no input GroupNorm, fp16 only
+static bool gemm_generic(const GemmP& p);
+static bool pp_ok(const GemmP& p, int bn) {
+  if (bn != 128 && bn != 160 && bn != 256) return false;
+  if (p.fp8 || p.bf16 || p.gi_part || p.ln_colsum || gemm_generic(p)) return false;
+  return p.act != 1 || bn % 64 == 0;                     // GEGLU pairs 16-row value | gate blocks inside a wave tile
+}
+template <int BN, int NP, bool FASTA>
+static int launch_pp2(const GemmP& p, hipStream_t st) {
+  constexpr int STAGE = (256 + BN) * 128, NS = (163840 / STAGE) >= 3 ? 3 : 2;
+  constexpr int ring = NS * STAGE, scratch = 4 * 64 * (BN / 2 + 4) * 4, tail = 128 * 8 + 4 * BN * 8;
+  constexpr int smem = ring > scratch + tail ? ring : scratch + tail;
+  static_assert(smem <= 163840, "LDS budget");
+  if (p.dbg) {                                             // ablation build (tools/pp_dbg.py)
+    static bool attr_dbg = false;
+    if (!attr_dbg) {
+      TF_HIP(hipFuncSetAttribute((const void*)k_igemm_pp<BN, NP, FASTA, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+      attr_dbg = true;
+    }
+    hipLaunchKernelGGL((k_igemm_pp<BN, NP, FASTA, true>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    TF_HIP(hipFuncSetAttribute((const void*)k_igemm_pp<BN, NP, FASTA>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_igemm_pp<BN, NP, FASTA>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+static int g_pp_np = 0;                                    // test / tuning hook: 0 = default phases per K tile, 1 / 2 = forced where admissible
+template <int BN>
+static int launch_pp(const GemmP& p, hipStream_t st) {
+  // lean addressing where the gather is a fixed pixel shift per tap: stride 1, no up-sampling, at most 31 taps
+  const bool fast = p.stride == 1 && !p.ups && p.S * p.S <= 31;
+  constexpr bool CAN1 = (163840 / ((256 + BN) * 128)) >= 3;
+  const bool np1 = CAN1 && g_pp_np != 2;
+  if constexpr (CAN1) {
+    if (np1) return fast ? launch_pp2<BN, 1, true>(p, st) : launch_pp2<BN, 1, false>(p, st);
+  }
+  return fast ? launch_pp2<BN, 2, true>(p, st) : launch_pp2<BN, 2, false>(p, st);
+}
+// rows of a tile as the GroupNorm-statistics code sees them: the ping-pong kernel's epilogue works in 128-row sub-blocks
+static int stats_bm(int bm, int variant) { return variant == 4 ? 128 : bm; }
 // (a 256x128 tile spills: the compiler keeps two copies of the accumulator set to issue the two k halves independently)
 static const int kTiles8[][2] = {{128, 128}, {64, 128}, {128, 64}, {256, 64}, {64, 64}};
 static const int kNumTiles8 = 5;
@@ -2024,7 +2428,7 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
   if (gn_part) {
     // chunk geometry of the statistics partials: in-kernel (2 pieces per m-tile) or in the split-K reduce (row stripes)
     if (p.splitk > 1) { p.gn_chunks = gn_reduce_chunks(p.HoWo); p.gn_part = nullptr; }
-    else p.gn_chunks = gn_pieces(p, c.bn) * (p.HoWo / c.bm);
+    else p.gn_chunks = gn_pieces(p, c.bn) * (p.HoWo / stats_bm(c.bm, variant));
   }
   if (p.bf16) {
     const bool g = gemm_generic(p);
@@ -2039,6 +2443,10 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
     else if (c.bm == 256 && c.bn == 64) rc = launch8<256, 64>(p, st);
     else if (c.bm == 64 && c.bn == 64) rc = launch8<64, 64>(p, st);
     else { tf_set_error("run_gemm: no fp8 kernel for tile %dx%d", c.bm, c.bn); return TF_E_UNSUPPORTED; }
+  }
+  else if (variant == 4) {
+    if (c.bm != 256 || !pp_ok(p, c.bn)) { tf_set_error("run_gemm: the ping-pong kernel cannot run tile %dx%d of this launch", c.bm, c.bn); return TF_E_UNSUPPORTED; }
+    rc = c.bn == 128 ? launch_pp<128>(p, st) : c.bn == 160 ? launch_pp<160>(p, st) : launch_pp<256>(p, st);
   }
   else if (variant == 2 && patch_setup(p, c.bm, c.bn)) {
     if (c.bm == 128 && c.bn == 160) rc = launch_patch<128, 160>(p, st);
@@ -2170,6 +2578,37 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
       }
     }
   }
+  // the ping-pong kernel (variant 4): 256 x {128, 160, 256} tiles for launches that still give most CUs a tile with them
+  static const int ppbn[3] = {160, 128, 256};
+  for (int ci = 0; ci < 3; ++ci) {
+    const int bn = ppbn[ci];
+    if (!pp_ok(p, bn) || p.M <= 256) continue;
+    for (int sk = 1; sk <= 8; sk *= 2) {
+      if (sk > 1 && (p.act == 1 || p.out32 || p.ktiles / sk < 4 || !workspace || (size_t)sk * p.M * p.N * 4 > workspace_bytes)) break;
+      long long blocks = (long long)((p.M + 255) / 256) * ((p.N + bn - 1) / bn) * sk;
+      if (blocks < 128) continue;
+      if (sk > 1 && blocks > 1024) break;
+      TileCfg c = {256, bn, sk};
+      for (int order = 0; order < 2; ++order) {
+        GemmP q = p;
+        if (q.gn_part && sk == 1 && !gn_tile_ok(q, 128, bn)) q.gn_part = nullptr;
+        int rc = launch_one(q, c, 4, order, workspace, st);   // warm-up
+        if (rc) return rc;
+        float tv[5];
+        for (int r = 0; r < 5; ++r) {
+          TF_HIP(hipMemsetAsync(g_flush, r, TF_FLUSH_BYTES, st));
+          TF_HIP(hipEventRecord(a, st));
+          rc = launch_one(q, c, 4, order, workspace, st);
+          if (rc) return rc;
+          TF_HIP(hipEventRecord(b, st));
+          TF_HIP(hipEventSynchronize(b));
+          TF_HIP(hipEventElapsedTime(&tv[r], a, b));
+        }
+        for (int i = 0; i < 5; ++i) for (int j = i + 1; j < 5; ++j) if (tv[j] < tv[i]) { float t = tv[i]; tv[i] = tv[j]; tv[j] = t; }
+        if (tv[2] < best) { best = tv[2]; bc = {c, 4, order}; }
+      }
+    }
+  }
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
   *out = bc;
   return TF_OK;
@@ -2230,6 +2669,11 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     wide = (blocks > 256 && p.ktiles / t.c.splitk <= 24) ? 1 : 0;
   }
   if (g_force_wide >= 0 && !(p.gi_part && p.S == 3)) wide = g_force_wide;
+  if (wide == 4 && (t.c.bm != 256 || !pp_ok(p, t.c.bn))) {   // a table configuration this launch cannot take falls back; an explicit request fails
+    if (g_force_wide == 4) { tf_set_error("run_gemm: the ping-pong kernel cannot run this launch (tile %dx%d)", t.c.bm, t.c.bn); return TF_E_UNSUPPORTED; }
+    wide = 0;
+    if (t.c.bm == 256) t.c = choose_tiles(p.M, p.N, p.K, p.act, workspace != nullptr);
+  }
   ProfRec rec;
   if (g_prof) {
     TF_HIP(hipEventCreate(&rec.a)); TF_HIP(hipEventCreate(&rec.b));
@@ -2242,8 +2686,10 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     // statistics ride along only when the chosen tiling maps m-tiles onto whole images; otherwise the caller is told
     // (chunks = 0) and runs the stand-alone statistics pass
     int kps = (p.ktiles + t.c.splitk - 1) / t.c.splitk, eff = (p.ktiles + kps - 1) / kps;
-    if (eff == 1 && !gn_tile_ok(p, t.c.bm, t.c.bn)) p.gn_part = nullptr;
-    if (gn_chunks) *gn_chunks = p.gn_part ? gn_chunks_for(p, t.c, eff) : 0;
+    TileCfg sc = t.c;
+    sc.bm = stats_bm(t.c.bm, wide);
+    if (eff == 1 && !gn_tile_ok(p, sc.bm, sc.bn)) p.gn_part = nullptr;
+    if (gn_chunks) *gn_chunks = p.gn_part ? gn_chunks_for(p, sc, eff) : 0;
     int a_, b_, c_; size_t d_;
     if (gn_chunks && p.gn_part && eff > 1 && p.on_z && rga_geometry(p.HoWo, p.N, p.gn_G, &a_, &b_, &c_, &d_)) *gn_chunks = 1;   // the fused reduce leaves whole-image sums
   }
@@ -2270,8 +2716,9 @@ static int g_force_bm = 0, g_force_bn = 0, g_force_split = 0;
 extern "C" {
 
 int tf_gemm_debug(int flags) {
-  g_dbg = flags & 7;
-  g_force_wide = (flags & 256) ? 3 : (flags & 128) ? 2 : (flags & 16) ? 1 : (flags & 8) ? 0 : -1;   // 128 / 256: the PATCH / ALL8 variants where eligible
+  g_dbg = (flags & 7) | ((flags & 4096) ? 8 : 0);         // 4096: no fragment reads (k_igemm_pp ablation build only)
+  g_pp_np = (flags & 8192) ? 2 : 0;                       // 8192: k_igemm_pp with one phase per k-step even where the 3-slot ring allows one per K tile
+  g_force_wide = (flags & 512) ? 4 : (flags & 256) ? 3 : (flags & 128) ? 2 : (flags & 16) ? 1 : (flags & 8) ? 0 : -1;   // 128 / 256 / 512: the PATCH / ALL8 / ping-pong variants where eligible
   g_force_order = (flags & 64) ? 1 : (flags & 32) ? 0 : -1;
   return TF_OK;
 }
@@ -2301,13 +2748,14 @@ int tf_gemm_tune_load(const char* path) {
     const bool f8 = (k[9] & 64) != 0;
     bool ok = (bm == 64 || bm == 128 || (f8 && bm == 256 && bn == 64) || (!f8 && bm == 256 && bn == 128)) && (bn == 64 || bn == 128 || (!f8 && bn == 160)) &&
               sk >= 1 && sk <= 32;
-    if ((f8 || bm == 256) && wide != 0) ok = false;
+    if ((f8 || (bm == 256 && wide != 4)) && wide != 0) ok = false;
+    if (wide == 4) ok = !f8 && bm == 256 && (bn == 128 || bn == 160 || bn == 256) && sk >= 1 && sk <= 32;
     // rows the tuner itself never emits: GEGLU (act = 1) pairs 16-row value|gate blocks inside a wave tile (bn % 64 == 0), and
     // neither GEGLU nor the LayerNorm fold (flag bit 8) can be split along K
     const int act = k[8], ln = k[9] & 8;
     if (act == 1 && (bn % 64) != 0) ok = false;
     if ((act == 1 || ln || (k[9] & 256)) && sk > 1) ok = false;
-    if (ok) g_tuned[k] = {{bm, bn, sk}, wide < 0 || wide > 3 ? 0 : wide, order != 0 ? 1 : 0};
+    if (ok) g_tuned[k] = {{bm, bn, sk}, wide < 0 || wide > 4 ? 0 : wide, order != 0 ? 1 : 0};
   }
   fclose(f);
   return TF_OK;

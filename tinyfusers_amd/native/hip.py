@@ -49,7 +49,10 @@ def _load():
             f"{LIB_PATH} is missing: build it with `python -m tinyfusers_amd.build` (hipcc --offload-arch=gfx950). "
             "tinyfusers_amd has no CPU fallback.")
     dll = ctypes.CDLL(LIB_PATH)
+    old_build = bool(os.environ.get("TF_LIB_PATH")) and os.environ.get("TF_LIB_ALLOW_MISSING") == "1"   # A/B against an earlier round's library
     for ret, name, argt in _parse_header():
+        if old_build and not hasattr(dll, name):
+            continue
         fn = getattr(dll, name)          # AttributeError here = header/library mismatch: fail loudly
         fn.restype = _CT[ret]
         fn.argtypes = [_CT[t] for t in argt]
