@@ -840,6 +840,7 @@ RGA_CASES = [  # n, cin, hw, cout, k, forced (bm, bn, splitk), silu, expect z
     (2, 320, 32, 640, 3, (64, 128, 2), False, True), (2, 640, 32, 320, 3, (64, 160, 4), True, True), (1, 128, 16, 128, 3, (64, 64, 2), True, True),
     (3, 640, 16, 1280, 1, (64, 160, 2), False, True),
     (2, 640, 64, 320, 3, (128, 160, 2), True, False),      # 4096 rows of 20-channel slabs do not fit a block's registers: reduce + apply launches
+    (5, 128, 24, 320, 3, (64, 160, 2), True, True),        # 5 images x 576 rows
     (2, 320, 16, 320, 3, (64, 160, 1), True, False),       # unsplit: the statistics come from the GEMM epilogue, the apply stays a launch
 ]
 

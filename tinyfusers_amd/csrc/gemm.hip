@@ -261,31 +261,51 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
   float* sc = reinterpret_cast<float*>(smem) + (size_t)w4 * (TM * RS) + (size_t)half * ROWS * RS;
   const int mb = m0 + wave_m * TM + half * ROWS;
   const int nb = n0 + wave_n * TN;                       // first (packed) column
+  // Both hot paths below run in two passes over a wave's items (a fixed, small count: fully unrolled): pass 1 issues EVERY global load
+  // (bias, time embedding, residual) of the wave, pass 2 consumes them.  Written as one loop, each iteration's loads sat behind the
+  // previous iteration's store (they may alias as far as the compiler knows), i.e. up to five dependent L2 / HBM round trips per wave:
+  // 7 us of a 256 x 160 tile's epilogue, 1-2 us of every short launch.
   if (p.act == 1) {
     // GEGLU: packed columns come in 16-wide blocks value|gate; out column = (n>>5)*16 + (n&15)
     constexpr int CPR = TN / 16;                          // 8-wide output chunks per row
+    constexpr int ITEMS = ROWS * CPR, ITER = (ITEMS + 63) / 64, KB = ITER < 4 ? ITER : 4;   // (batches of at most 4: 48 VGPRs of loads in flight)
     const int No = p.N >> 1;
-    for (int idx = lane; idx < ROWS * CPR; idx += 64) {
-      int row = idx / CPR, c8 = idx - row * CPR;
-      int m = mb + row;
-      int pc = 32 * (c8 >> 1) + 8 * (c8 & 1);            // packed column of the value chunk inside the wave tile
-      int n = nb + pc;
-      if (m >= p.M || n >= p.N) continue;
-      int no = (n >> 5) * 16 + (n & 15);
+#pragma unroll
+    for (int k0 = 0; k0 < ITER; k0 += KB) {
+    E8 ba[KB], bg[KB], rv[KB];
+    bool ok[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int idx = lane + 64 * (k0 + k);
+      const int row = idx / CPR, c8 = idx - row * CPR;
+      const int m = mb + row, n = nb + 32 * (c8 >> 1) + 8 * (c8 & 1);
+      ok[k] = k0 + k < ITER && idx < ITEMS && m < p.M && n < p.N;
+      if (ok[k]) {
+        ba[k] = *reinterpret_cast<const E8*>(e_bias + n); bg[k] = *reinterpret_cast<const E8*>(e_bias + n + 16);
+        if (p.residual) rv[k] = *reinterpret_cast<const E8*>(e_res + (long long)m * No + ((n >> 5) * 16 + (n & 15)));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      if (!ok[k]) continue;
+      const int idx = lane + 64 * (k0 + k);
+      const int row = idx / CPR, c8 = idx - row * CPR;
+      const int m = mb + row;
+      const int pc = 32 * (c8 >> 1) + 8 * (c8 & 1);      // packed column of the value chunk inside the wave tile
+      const int n = nb + pc;
+      const int no = (n >> 5) * 16 + (n & 15);
       const float* r = sc + row * RS + pc;
       f4 a0 = *reinterpret_cast<const f4*>(r), a1 = *reinterpret_cast<const f4*>(r + 4);
       f4 g0 = *reinterpret_cast<const f4*>(r + 16), g1 = *reinterpret_cast<const f4*>(r + 20);
-      E8 ba = *reinterpret_cast<const E8*>(e_bias + n), bg = *reinterpret_cast<const E8*>(e_bias + n + 16);
       E8 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        o[e] = (E)((a0[e] + (float)ba[e]) * gelu_f(g0[e] + (float)bg[e]));
-        o[4 + e] = (E)((a1[e] + (float)ba[4 + e]) * gelu_f(g1[e] + (float)bg[4 + e]));
+        o[e] = (E)((a0[e] + (float)ba[k][e]) * gelu_f(g0[e] + (float)bg[k][e]));
+        o[4 + e] = (E)((a1[e] + (float)ba[k][4 + e]) * gelu_f(g1[e] + (float)bg[k][4 + e]));
       }
       if (p.residual) {
-        E8 rv = *reinterpret_cast<const E8*>(e_res + (long long)m * No + no);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (E)((float)o[e] + (float)rv[e]);
+        for (int e = 0; e < 8; ++e) o[e] = (E)((float)o[e] + (float)rv[k][e]);
       }
       if constexpr (OUT8) {
         f4 q0, q1;
@@ -294,6 +314,52 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
       } else {
         *reinterpret_cast<E8*>(e_y + (long long)m * No + no) = o;
       }
+    }
+    }
+    return;
+  }
+  if ((p.N & 7) == 0 && p.splitk <= 1 && !p.out32) {
+    // the common case: 16-byte rows segments of an fp16 (or e4m3) output with bias + time embedding + residual
+    constexpr int CPR = TN / 8;
+    constexpr int ITEMS = ROWS * CPR, ITER = (ITEMS + 63) / 64, KB = ITER < 4 ? ITER : 4;
+#pragma unroll
+    for (int k0 = 0; k0 < ITER; k0 += KB) {
+    E8 bv[KB], cv[KB], rv[KB];
+    bool ok[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int idx = lane + 64 * (k0 + k);
+      const int row = idx / CPR, c8 = idx - row * CPR;
+      const int m = mb + row, n = nb + c8 * 8;
+      ok[k] = k0 + k < ITER && idx < ITEMS && m < p.M && n < p.N;
+      if (ok[k]) {
+        const long long o = (long long)m * p.N + n;
+        if (p.bias) bv[k] = *reinterpret_cast<const E8*>(e_bias + n);
+        if (p.bias_nc) cv[k] = *reinterpret_cast<const E8*>(e_bias_nc + (long long)(m / p.HoWo) * p.bias_nc_stride + n);
+        if (p.residual) rv[k] = *reinterpret_cast<const E8*>(e_res + o);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      if (!ok[k]) continue;
+      const int idx = lane + 64 * (k0 + k);
+      const int row = idx / CPR, c8 = idx - row * CPR;
+      const int m = mb + row, n = nb + c8 * 8;
+      float* r = sc + row * RS + c8 * 8;
+      f4 v0 = *reinterpret_cast<const f4*>(r), v1 = *reinterpret_cast<const f4*>(r + 4);
+      const long long o = (long long)m * p.N + n;
+      if (p.bias) { for (int e = 0; e < 4; ++e) { v0[e] += (float)bv[k][e]; v1[e] += (float)bv[k][4 + e]; } }
+      if (p.bias_nc) { for (int e = 0; e < 4; ++e) { v0[e] += (float)cv[k][e]; v1[e] += (float)cv[k][4 + e]; } }
+      if (p.residual) { for (int e = 0; e < 4; ++e) { v0[e] += (float)rv[k][e]; v1[e] += (float)rv[k][4 + e]; } }
+      E8 out;
+      for (int e = 0; e < 4; ++e) { out[e] = (E)v0[e]; out[4 + e] = (E)v1[e]; }
+      if constexpr (OUT8) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.y) + o) = pack8_fp8(v0, v1);
+      else *reinterpret_cast<E8*>(e_y + o) = out;
+      if (p.gn_part) {   // the statistics pass sums what the consumer will read: the fp16-rounded outputs
+        for (int e = 0; e < 4; ++e) { v0[e] = (float)out[e]; v1[e] = (float)out[4 + e]; }
+        *reinterpret_cast<f4*>(r) = v0; *reinterpret_cast<f4*>(r + 4) = v1;
+      }
+    }
     }
     return;
   }
@@ -2472,6 +2538,7 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
   int rg_gpb = 0, rg_cv = 0, rg_rps = 0;
   size_t rg_lds = 0;
   if (p.splitk > 1 && p.on_z && p.gn_part && rga_geometry(p.HoWo, p.N, p.gn_G, &rg_gpb, &rg_cv, &rg_rps, &rg_lds)) {
+
     static bool attr_set = false;
     if (!attr_set) { TF_HIP(hipFuncSetAttribute((const void*)k_splitk_reduce_gn_apply, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
     const int nimg = p.M / p.HoWo;
