@@ -39,8 +39,8 @@ sys.path.insert(0, ROOT)
 FLOP_PER_STEP = 1.6088e12          # algorithmic FLOPs of one step (conv 887.89 G + linear 466.49 G + SDPA 252.10 G + 2.28 G)
 PEAK_MFMA_TFLOPS = {"fp16": 2500.0, "fp8": 5000.0}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_PROFILE = os.path.join("profiles", "r02_pmc_traffic.json")
-FAMILY_PROFILE = os.path.join("profiles", "r02_kernel_family.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r03_pmc_traffic.json")
+FAMILY_PROFILE = os.path.join("profiles", "r03_kernel_family.json")
 
 
 def parse(argv=None):
@@ -52,6 +52,8 @@ def parse(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the config-3 end-to-end leg (CLIP x2 -> 50 steps -> VAE decode)")
     ap.add_argument("--e2e-images", type=int, default=3)
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg (4 images per GPU, 96x96 latents, fp16 and fp8 conv/linear, 3 timed steps each)")
+    ap.add_argument("--config5-steps", type=int, default=3)
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of the HIP-graph replay")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--tune-cache", default="", help="file to load/save the GEMM autotuner's per-shape choices (optional)")
@@ -137,7 +139,7 @@ def dry_run(args):
     assert np.array_equal(got, pack_tensor(synth_tensor(5, k, shapes[k])).reshape(-1)), "arena differs after the broadcast"
     lo, hi = shard_range(world * args.images, rank, world)
     assert hi - lo == args.images
-    lat = synth_normal(1234 + rank, "sd.latent", (args.images, 4, 8, 8))
+    lat = synth_normal(1234 + rank, "sd.latent", (args.images, 4, args.latent, args.latent))     # this rank's images: its own seed
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -159,7 +161,8 @@ def dry_run(args):
                           "ms_per_step": round(wall * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "none", "data": "synthetic", "dry_run": True,
                           "config": {"workload": "dry run: arena broadcast + image shard + max-over-ranks on CPU (gloo), no kernels",
-                                     "global_batch": world * args.images, "parallelism": f"dp{world}"},
+                                     "global_batch": world * args.images, "images_per_rank": args.images, "latent": [4, args.latent, args.latent],
+                                     "requested_dtype": args.dtype, "parallelism": f"dp{world}"},
                           "weights": {"bytes": total, "synth_s": round(t_gen, 3), "bcast_s": round(t_bcast, 4)}}), flush=True)
     if world > 1:
         dist.barrier()
@@ -202,7 +205,7 @@ def build_weight_arena(unet, rank, world, device_index):
         t_bcast = time.time() - t1
     state = {k: DeviceArray(base + offs[k], shapes[k], np.float16, None, base=arena) for k in shapes}
     update_state(unet, state, "")
-    return arena, off, t_gen, t_bcast
+    return arena, off, t_gen, t_bcast, state
 
 
 def host_cores():
@@ -309,6 +312,118 @@ def e2e_leg(sd, n_images, seed):
             "workload": "CLIP text encoder x2 -> 50 DDIM steps (CFG, one HIP-graph replay each) -> VAE decode to 512x512x3 uint8, batch 1, fp16"}
 
 
+def roofline_leg(sd, run, n_inst, peak, default_workload):
+    """The dominant kernel family = the implicit-GEMM conv2d + linear launches (84 % of the step's FLOPs): `n_inst` instrumented eager
+    steps with HIP events on the launch stream around every launch of the family.  `achieved` counts a GEMM together with the split-K
+    reduce launch that finishes it (a split conv is not done before its reduce has run); the bracket that ends behind the k_igemm* kernel
+    itself -- the figure rocprofv3 lists under that name -- is the sub-key `gemm_kernel_only`."""
+    import ctypes
+    from tinyfusers_amd.native import hip, lib
+    lib.tf_prof_enable(1)
+    run(n_inst, True)
+    sd.synchronize()
+    gfull, gms, gfl, gl = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+    hip.tf_prof_read_full(ctypes.byref(gfull), ctypes.byref(gms), ctypes.byref(gfl), ctypes.byref(gl))
+    lib.tf_prof_enable(0)
+    ach = gfl.value / (gfull.value * 1e-3) / 1e12 if gfull.value > 0 else 0.0
+    ach_k = gfl.value / (gms.value * 1e-3) / 1e12 if gms.value > 0 else 0.0
+    # HBM bytes per launch of this kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction +
+    # WRITE_SIZE, separate runs of this same command; tools/pmc_summary.py): they cannot be sampled live, so the profile is stamped with
+    # the hash of the kernel sources it was taken on and is reported only while that still matches
+    traffic, tnote = None, f"no {TRAFFIC_PROFILE}"
+    try:
+        pj = json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))
+        if pj.get("csrc_sha16") == csrc_hash() and default_workload:
+            traffic = round(pj["k_igemm"]["hbm_bytes_per_launch"])
+            tnote = f"HBM bytes per launch ({TRAFFIC_PROFILE}, kernel sources {pj['csrc_sha16']})"
+        else:
+            tnote = f"{TRAFFIC_PROFILE} was taken on other kernel sources or another workload ({pj.get('csrc_sha16')} vs {csrc_hash()}): not reported"
+    except Exception:
+        pass
+    # the same family in the committed rocprofv3 --kernel-trace --stats run (tools/prof_summary.py), quoted while the sources match
+    rocprof = None
+    try:
+        fj = json.load(open(os.path.join(ROOT, FAMILY_PROFILE)))
+        if fj.get("csrc_sha16") == csrc_hash() and default_workload:
+            k, kr = fj["k_igemm"], fj.get("k_igemm_plus_reduce", fj["k_igemm"])
+            per_step = gfl.value / n_inst
+            rocprof = {"gemm_plus_reduce_ms_per_step": round(kr["ms_per_step"], 4),
+                       "frac": round(per_step / (kr["ms_per_step"] * 1e-3) / 1e12 / peak, 4) if kr["ms_per_step"] > 0 else None,
+                       "gemm_kernel_only_ms_per_step": round(k["ms_per_step"], 4), "gemm_kernel_only_avg_launch_us": round(k["avg_launch_us"], 2),
+                       "gemm_kernel_only_frac": round(per_step / (k["ms_per_step"] * 1e-3) / 1e12 / peak, 4) if k["ms_per_step"] > 0 else None,
+                       "file": FAMILY_PROFILE}
+    except Exception:
+        pass
+    return {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": traffic, "traffic_unit": tnote,
+            "kernel": "k_igemm* (implicit-GEMM conv2d + linear) together with the split-K reduce launches that finish them",
+            "launches_per_step": gl.value / n_inst, "avg_launch_us": round(gfull.value * 1e3 / max(1, gl.value), 2),
+            "gemm_ms_per_step": round(gfull.value / n_inst, 4), "gemm_flop_per_step": gfl.value / n_inst,
+            "gemm_kernel_only": {"achieved": round(ach_k, 1), "frac": round(ach_k / peak, 4), "ms_per_step": round(gms.value / n_inst, 4),
+                                 "avg_launch_us": round(gms.value * 1e3 / max(1, gl.value), 2)},
+            "rocprof": rocprof}
+
+
+def config5_leg(wstate, steps, seed):
+    """BASELINE config 5's per-GPU workload (4 images per GPU = UNet batch 8, 96 x 96 latents), fp16 and fp8 conv / linear, on the
+    weights already resident: `steps` graph-replayed steps each after 2 warm-up steps, plus one instrumented eager step for the GEMM
+    family.  Rank 0 at N = 1 only; the 8-GPU form of the config is the same per-GPU workload on every rank."""
+    import contextlib
+    import ctypes
+    import io
+    import tinyfusers_amd.storage.tensor as T
+    from tinyfusers_amd import config
+    from tinyfusers_amd.native import hip
+    from tinyfusers_amd.storage.state import update_state
+    from tinyfusers_amd.storage.synth import synth_normal
+    from tinyfusers_amd.variants.sd import StableDiffusion
+    B, S = 4, 96
+    out = {"workload": f"{B} images per GPU, {S}x{S}x4 latents (768x768 images), UNet batch {2 * B}, one DDIM step; {steps} timed graph replays per dtype",
+           "flop_per_image_step": 4.30e12}
+    timesteps = list(range(1, 1000, 20))
+    for dtype in ("fp16", "fp8"):
+        config.set_dtype(dtype)
+        try:
+            sd = StableDiffusion(init=False)
+            with contextlib.redirect_stdout(io.StringIO()):
+                update_state(sd.model.diffusion_model, wstate, "")
+            alphas = sd.alphas_cumprod[timesteps]
+            alphas_prev = np.concatenate((np.array([1.0]), alphas[:-1])).astype(np.float32)
+            lat = sd.latent_from_numpy(synth_normal(seed, "sd.latent", (B, 4, S, S)))
+            ctx = T.DeviceArray.from_numpy(synth_normal(seed, "sd.context", (B, 77, 768)))
+            unc = T.DeviceArray.from_numpy(synth_normal(seed, "sd.uncond", (B, 77, 768)))
+            sd.compile(unc, ctx, lat)
+
+            def run(n, eager):
+                for s_ in range(n):
+                    i = 49 - (s_ % 50)
+                    sd.step(timesteps[i], alphas[i], alphas_prev[i], 7.5, eager=eager)
+            run(2, False)
+            sd.synchronize()
+            ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()
+            hip.tf_event_create(ctypes.byref(ev0)); hip.tf_event_create(ctypes.byref(ev1))
+            hip.tf_event_record(ev0, sd._stream.handle)
+            run(steps, False)
+            hip.tf_event_record(ev1, sd._stream.handle)
+            sd.synchronize()
+            ms = ctypes.c_float()
+            hip.tf_event_elapsed_ms(ctypes.byref(ms), ev0, ev1)
+            assert np.isfinite(lat.numpy()).all(), f"config5 {dtype}: non-finite latent"
+            peak = PEAK_MFMA_TFLOPS[dtype]
+            rl = roofline_leg(sd, run, 1, peak, False)
+            per = ms.value / steps
+            out[dtype] = {"image_steps_per_s": round(B * 1e3 / per, 2), "ms_per_step": round(per, 3),
+                          "step_tflops": round(4.30e12 * B / (per * 1e-3) / 1e12, 1),
+                          "gemm_family_tflops": rl["achieved"], "gemm_ms_per_step": rl["gemm_ms_per_step"], "gemm_launches_per_step": rl["launches_per_step"],
+                          "frac_of_2500_tflops_f16_peak": round(rl["achieved"] / 2500.0, 4), "frac_of_5000_tflops_f8_peak": round(rl["achieved"] / 5000.0, 4)}
+            del sd
+        finally:
+            config.set_dtype("fp16")
+    if "fp16" in out and "fp8" in out:
+        out["fp8_over_fp16"] = round(out["fp16"]["ms_per_step"] / out["fp8"]["ms_per_step"], 3)
+    return out
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
@@ -343,7 +458,7 @@ def main(argv=None):
     config.set_dtype(args.dtype)
 
     sd = StableDiffusion()
-    arena, arena_bytes, t_gen, t_bcast = build_weight_arena(sd.model.diffusion_model, rank, world, local_rank)
+    arena, arena_bytes, t_gen, t_bcast, wstate = build_weight_arena(sd.model.diffusion_model, rank, world, local_rank)
     seed = 1234 + rank
     B, S = args.images, args.latent
     lat = sd.latent_from_numpy(synth_normal(seed, "sd.latent", (B, 4, S, S)))
@@ -398,45 +513,7 @@ def main(argv=None):
     peak = PEAK_MFMA_TFLOPS[args.dtype]
     roofline = None
     if not args.no_roofline and rank == 0:
-        # dominant kernel family = k_igemm (conv2d + linear, 84 % of the step's FLOPs): per-launch HIP events
-        n_inst = max(1, min(args.steps, 5))
-        lib.tf_prof_enable(1)
-        run(n_inst, True)
-        sd.synchronize()
-        gms, gfl, gl = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
-        hip.tf_prof_read(ctypes.byref(gms), ctypes.byref(gfl), ctypes.byref(gl))
-        lib.tf_prof_enable(0)
-        ach = gfl.value / (gms.value * 1e-3) / 1e12 if gms.value > 0 else 0.0
-        # HBM bytes per launch of this kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950
-        # correction + WRITE_SIZE, separate runs of this same command; tools/pmc_summary.py): they cannot be sampled live, so the
-        # profile is stamped with the hash of the kernel sources it was taken on and is reported only while that still matches
-        traffic, tnote = None, f"no {TRAFFIC_PROFILE}"
-        try:
-            pj = json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))
-            if pj.get("csrc_sha16") == csrc_hash() and (B, S, args.dtype) == (1, 64, "fp16"):
-                traffic = round(pj["k_igemm"]["hbm_bytes_per_launch"])
-                tnote = f"HBM bytes per launch ({TRAFFIC_PROFILE}, kernel sources {pj['csrc_sha16']})"
-            else:
-                tnote = f"{TRAFFIC_PROFILE} was taken on other kernel sources or another workload ({pj.get('csrc_sha16')} vs {csrc_hash()}): not reported"
-        except Exception:
-            pass
-        # the same family in the committed rocprofv3 --kernel-trace --stats run (tools/prof_summary.py), quoted while the sources match: the
-        # profiler's per-dispatch duration reads ~2 us longer than an event bracket around the same launch
-        rocprof = None
-        try:
-            fj = json.load(open(os.path.join(ROOT, FAMILY_PROFILE)))
-            if fj.get("csrc_sha16") == csrc_hash() and (B, S, args.dtype) == (1, 64, "fp16"):
-                k = fj["k_igemm"]
-                rocprof = {"avg_launch_us": round(k["avg_launch_us"], 2), "gemm_ms_per_step": round(k["ms_per_step"], 4),
-                           "frac": round(gfl.value / n_inst / (k["ms_per_step"] * 1e-3) / 1e12 / peak, 4) if k["ms_per_step"] > 0 else None,
-                           "file": FAMILY_PROFILE}
-        except Exception:
-            pass
-        roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "traffic_unit": tnote,
-                    "kernel": "k_igemm<BM,BN> (implicit-GEMM conv2d + linear)",
-                    "launches_per_step": gl.value / n_inst, "avg_launch_us": round(gms.value * 1e3 / max(1, gl.value), 2),
-                    "gemm_ms_per_step": round(gms.value / n_inst, 4), "gemm_flop_per_step": gfl.value / n_inst, "rocprof": rocprof}
+        roofline = roofline_leg(sd, run, max(1, min(args.steps, 5)), peak, (B, S, args.dtype) == (1, 64, "fp16"))
 
     if rank == 0:
         steps_per_s = world * B * args.steps / wall      # image-steps per second (one unit = one denoising step of one image)
@@ -461,6 +538,8 @@ def main(argv=None):
         }
         if world == 1 and (B, S, args.dtype) == (1, 64, "fp16") and not args.no_e2e:
             out["e2e"] = e2e_leg(sd, args.e2e_images, seed)
+        if world == 1 and (B, S, args.dtype) == (1, 64, "fp16") and not args.no_config5:
+            out["config5"] = config5_leg(wstate, args.config5_steps, seed)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
         print(json.dumps(out), flush=True)

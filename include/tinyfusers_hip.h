@@ -121,8 +121,12 @@ int tf_comm_destroy(tfComm_t comm);
  * (bench.py roofline leg): enable, run eagerly, then read back accumulated ms / flops / launches. */
 int tf_prof_enable(int on);
 int tf_prof_read(double* gemm_ms, double* gemm_flops, long long* gemm_launches);
+/* the same accumulators with both brackets: `ms_with_reduce` spans every GEMM launch together with the split-K reduce launch that
+ * finishes it (the time the conv / linear family really takes in a step), `ms_gemm_kernel_only` ends behind the k_igemm* kernel itself
+ * (what tf_prof_read reports, the figure rocprofv3 lists under that kernel name) */
+int tf_prof_read_full(double* ms_with_reduce, double* ms_gemm_kernel_only, double* gemm_flops, long long* gemm_launches);
 int tf_prof_dump(const char* csv_path);   /* per-shape table: M,N,K,taps,tile,split-K,launches,ms,TFLOP/s */
-/* test / tuning hook: force the GEMM tile (bm x bn in {128,64} x {160,128,64}) and split-K; 0,0,0 = heuristic */
+/* test / tuning hook: force the GEMM tile (bm x bn in {256,128,64} x {256,160,128,64}) and split-K; 0,0,0 = heuristic */
 int tf_gemm_force_config(int bm, int bn, int splitk);
 /* per-shape autotuning of (tile, split-K, ring variant) on the first eager call of a shape (default on) */
 int tf_gemm_autotune(int on);
@@ -130,7 +134,9 @@ int tf_gemm_tune_save(const char* path);
 int tf_gemm_tune_load(const char* path);
 /* diagnostic builds of tools/: bit 0 no stores, 1 no MFMA, 2 no staging, 3/4 force deep/wide ring, 5/6 force n-fastest/m-fastest order,
  * 7 (128) the patch variant of the 3x3 convolutions (k_igemm_patch), 8 (256) the variant whose consumer waves issue part of the
- * weight loads, each where the shape is eligible */
+ * weight loads, each where the shape is eligible; 9 (512) the 256-row ping-pong kernel k_igemm_pp (with tf_gemm_force_config(256, BN, split),
+ * BN in {128, 160, 256}: fails where it cannot take the launch), 12 (4096) its ablation build without fragment reads, 13 (8192) its
+ * one-phase-per-k-step form on the three-slot ring */
 int tf_gemm_debug(int flags);
 
 /* ---- layout / dtype converters (the API edge: the reference's arrays are fp32 NCHW) ----------- */

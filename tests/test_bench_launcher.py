@@ -31,6 +31,20 @@ def test_bench_gpus2_launches_two_ranks_dry_run():
     assert out["weights"]["bytes"] > 0 and "bcast_s" in out["weights"]
 
 
+def test_bench_config5_geometry_on_eight_ranks_dry_run():
+    """BASELINE config 5 as the driver would start it -- 8 ranks, 4 images per rank (global batch 32), 96 x 96 latents, fp8 -- through
+    the launcher and the whole N > 1 plumbing on CPU: one arena broadcast, every rank its own image shard and seeds, max over ranks."""
+    r = _run(["--gpus", "8", "--images", "4", "--latent", "96", "--dtype", "fp8", "--steps", "2", "--warmup", "0", "--dry-run"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["dry_run"] is True and out["scaling"] == "weak"
+    c = out["config"]
+    assert c["global_batch"] == 32 and c["images_per_rank"] == 4 and c["latent"] == [4, 96, 96] and c["requested_dtype"] == "fp8" and c["parallelism"] == "dp8"
+    assert out["ms_per_step"] * 2 >= 79.0                  # the slowest rank (rank 7 sleeps 80 ms) sets the time
+
+
 def test_bench_dry_run_single_rank():
     r = _run(["--gpus", "1", "--steps", "2", "--warmup", "0", "--dry-run"])
     assert r.returncode == 0, r.stderr[-2000:]

@@ -2238,9 +2238,9 @@ __global__ void __launch_bounds__(256) k_ln_fold(half_t* __restrict__ wo, half_t
 // ------------------------------------------------------------------------------------------------
 // per-launch event profiling of this kernel family (bench.py roofline leg)
 static bool g_prof = false;
-static double g_prof_ms = 0.0, g_prof_flops = 0.0;
+static double g_prof_ms = 0.0, g_prof_ms_full = 0.0, g_prof_flops = 0.0;
 static long long g_prof_launches = 0;
-struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, taps, bm, bn, splitk, variant; };
+struct ProfRec { hipEvent_t a, b, c; double flops; int M, N, K, taps, bm, bn, splitk, variant; };   // a .. b: the GEMM kernel alone; a .. c: with the split-K reduce that finishes it
 #include <map>
 #include <array>
 static std::map<std::array<int, 8>, std::pair<long long, double>> g_prof_shapes;
@@ -2743,7 +2743,7 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
   }
   ProfRec rec;
   if (g_prof) {
-    TF_HIP(hipEventCreate(&rec.a)); TF_HIP(hipEventCreate(&rec.b));
+    TF_HIP(hipEventCreate(&rec.a)); TF_HIP(hipEventCreate(&rec.b)); TF_HIP(hipEventCreate(&rec.c));
     rec.flops = 2.0 * p.M * (double)p.N * p.K;
     rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.taps = p.Kc / p.C; rec.bm = t.c.bm; rec.bn = t.c.bn; rec.splitk = t.c.splitk; rec.variant = wide;
     TF_HIP(hipEventRecord(rec.a, st));
@@ -2764,7 +2764,7 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
   int rc = launch_one(p, t.c, wide, t.order, workspace, st);
   g_prof_end = nullptr;
   if (rc) return rc;
-  if (g_prof) g_prof_pending.push_back(rec);
+  if (g_prof) { TF_HIP(hipEventRecord(rec.c, st)); g_prof_pending.push_back(rec); }
   return TF_OK;
 }
 
@@ -2833,7 +2833,7 @@ static float g_prof_overhead_ms = 0.f;   // what an empty [record a][record b] i
 int tf_prof_enable(int on) {
   g_prof = on != 0;
   if (on) {
-    g_prof_ms = 0.0; g_prof_flops = 0.0; g_prof_launches = 0; g_prof_pending.clear(); g_prof_shapes.clear();
+    g_prof_ms = 0.0; g_prof_ms_full = 0.0; g_prof_flops = 0.0; g_prof_launches = 0; g_prof_pending.clear(); g_prof_shapes.clear();
     // calibrate the event pair itself (median of 16 empty intervals on the NULL stream) and subtract it per launch
     hipEvent_t a, b;
     TF_HIP(hipEventCreate(&a)); TF_HIP(hipEventCreate(&b));
@@ -2848,20 +2848,36 @@ int tf_prof_enable(int on) {
   }
   return TF_OK;
 }
-int tf_prof_read(double* ms, double* flops, long long* launches) {
+static int prof_collect() {
   for (auto& r : g_prof_pending) {
-    float t = 0.f;
-    TF_HIP(hipEventSynchronize(r.b));
+    float t = 0.f, tf = 0.f;
+    TF_HIP(hipEventSynchronize(r.c));
     TF_HIP(hipEventElapsedTime(&t, r.a, r.b));
-    t -= g_prof_overhead_ms;
+    TF_HIP(hipEventElapsedTime(&tf, r.a, r.c));
+    t -= g_prof_overhead_ms; tf -= g_prof_overhead_ms;
     if (t < 0.f) t = 0.f;
-    g_prof_ms += t; g_prof_flops += r.flops; g_prof_launches += 1;
+    if (tf < t) tf = t;
+    g_prof_ms += t; g_prof_ms_full += tf; g_prof_flops += r.flops; g_prof_launches += 1;
     auto& e = g_prof_shapes[{r.M, r.N, r.K, r.taps, r.bm, r.bn, r.splitk, r.variant}];
-    e.first += 1; e.second += t;
-    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    e.first += 1; e.second += tf;
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); (void)hipEventDestroy(r.c);
   }
   g_prof_pending.clear();
+  return TF_OK;
+}
+int tf_prof_read(double* ms, double* flops, long long* launches) {
+  int rc = prof_collect();
+  if (rc) return rc;
   if (ms) *ms = g_prof_ms;
+  if (flops) *flops = g_prof_flops;
+  if (launches) *launches = g_prof_launches;
+  return TF_OK;
+}
+int tf_prof_read_full(double* ms_with_reduce, double* ms_gemm_kernel_only, double* flops, long long* launches) {
+  int rc = prof_collect();
+  if (rc) return rc;
+  if (ms_with_reduce) *ms_with_reduce = g_prof_ms_full;
+  if (ms_gemm_kernel_only) *ms_gemm_kernel_only = g_prof_ms;
   if (flops) *flops = g_prof_flops;
   if (launches) *launches = g_prof_launches;
   return TF_OK;
@@ -2873,7 +2889,7 @@ int tf_prof_dump(const char* path) {
   if (rc) return rc;
   FILE* f = fopen(path, "w");
   TF_REQUIRE(f, "tf_prof_dump: cannot open %s", path);
-  fprintf(f, "M,N,K,taps,bm,bn,splitk,variant,launches,total_ms,avg_us,tflops\n");   // variant: 0 deep ring, 1 wide, 2 patch, 3 all8
+  fprintf(f, "M,N,K,taps,bm,bn,splitk,variant,launches,total_ms,avg_us,tflops\n");   // variant: 0 deep ring, 1 wide, 2 patch, 3 all8, 4 ping-pong; times include the split-K reduce
   for (auto& kv : g_prof_shapes) {
     const auto& k = kv.first;
     double ms = kv.second.second; long long n = kv.second.first;

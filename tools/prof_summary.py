@@ -20,8 +20,14 @@ if len(sys.argv) > 3:
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from bench import csrc_hash
     fam = [r for r in rows if "k_igemm" in r["Name"]]
+    red = [r for r in rows if "k_splitk_reduce" in r["Name"]]
     calls = sum(int(r["Calls"]) for r in fam)
     ns = sum(float(r["TotalDurationNs"]) for r in fam)
-    json.dump({"csrc_sha16": csrc_hash(), "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e",
-               "k_igemm": {"launches_per_step": calls / steps, "ms_per_step": ns / 1e6 / steps, "avg_launch_us": ns / 1e3 / max(1, calls)}},
+    rcalls = sum(int(r["Calls"]) for r in red)
+    rns = sum(float(r["TotalDurationNs"]) for r in red)
+    json.dump({"csrc_sha16": csrc_hash(), "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --no-config5",
+               "k_igemm": {"launches_per_step": calls / steps, "ms_per_step": ns / 1e6 / steps, "avg_launch_us": ns / 1e3 / max(1, calls)},
+               "k_splitk_reduce": {"launches_per_step": rcalls / steps, "ms_per_step": rns / 1e6 / steps, "avg_launch_us": rns / 1e3 / max(1, rcalls)},
+               "k_igemm_plus_reduce": {"launches_per_step": (calls + rcalls) / steps, "ms_per_step": (ns + rns) / 1e6 / steps,
+                                       "avg_launch_us": (ns + rns) / 1e3 / max(1, calls)}},
               open(sys.argv[3], "w"), indent=1)
