@@ -55,6 +55,17 @@ CONV8 = [  # n, c1, c2, hw, cout, stride, upsample, forced (bm, bn, splitk) or N
     (2, 64, 0, 8, 64, 1, False, (64, 64, 1)), (2, 128, 0, 16, 128, 1, False, (128, 128, 1)), (2, 320, 0, 32, 320, 1, False, (256, 64, 1)),
     (2, 320, 0, 32, 640, 1, False, (64, 128, 1)), (2, 640, 320, 16, 640, 1, False, (128, 64, 2)), (1, 1280, 1280, 8, 1280, 1, False, (64, 128, 8)),
     (2, 320, 0, 32, 320, 2, False, None), (2, 640, 0, 16, 640, 1, True, None), (8, 320, 0, 96, 320, 1, False, None), (1, 64, 0, 9, 72, 1, False, (64, 64, 1)),
+    # k_igemm_pp on e4m3 (a 4th entry = tf_gemm_debug flags; 512 = the ping-pong kernel): 128-element K tiles on the block-scaled MFMA
+    (2, 128, 0, 16, 128, 1, False, (256, 128, 1, 512)),    # channel counts on the 128 grid: one load per piece; K = 1152 = 9 tiles
+    (2, 320, 0, 32, 320, 1, False, (256, 160, 1, 512)),    # 320 channels = 2.5 tiles: half-masked loads, taps change inside a tile; K = 2880 = 22.5 tiles
+    (2, 640, 320, 16, 640, 1, False, (256, 160, 2, 512)),  # concat 640 + 320: the halves of a tile come from different tensors; split-K
+    (2, 320, 320, 32, 320, 1, False, (256, 128, 1, 512)),
+    (2, 320, 0, 32, 320, 2, False, (256, 160, 1, 512)),    # stride 2: the general gather
+    (2, 256, 0, 16, 256, 1, True, (256, 128, 1, 512)),     # nearest-2x upsample folded into the gather
+    (3, 64, 0, 24, 128, 1, False, (256, 128, 1, 512)),     # K = 576 = 4.5 tiles, ragged last m-tile
+    (8, 320, 0, 96, 320, 1, False, (256, 160, 1, 512)),    # config 5's most frequent conv
+    (8, 320, 0, 96, 320, 1, False, (192, 160, 1, 512)),    # ... on the 192-row tile: 768 tiles = three full rounds on 256 CUs
+    (2, 640, 320, 24, 640, 1, False, (192, 128, 2, 512)), (2, 128, 0, 24, 128, 1, False, (192, 128, 1, 512)),
 ]
 
 
@@ -73,13 +84,13 @@ def test_conv2d_fp8_against_the_same_e4m3_operands(tf, n, c1, c2, hw, cout, stri
     ho = (hw * (2 if ups else 1) + 2 - 3) // stride + 1
     r = rnd("c8.r", (n, cout, ho, ho))
     if force:
-        lib.tf_gemm_force_config(*force)
+        lib.tf_gemm_force_config(*force[:3]); lib.tf_gemm_debug(force[3] if len(force) > 3 else 0)
     try:
         y = fp8.conv2d_fp8(tuple(x8) if c2 else x8[0], w8, sc, tf.DeviceArray.from_numpy(b, np.float16, "row"), wt.shape, [1, 1], [stride, stride],
                            bias_nc=tf.DeviceArray.from_numpy(e, np.float16, "row"), residual=tf.DeviceArray.from_numpy(r, np.float16, "nhwc"),
                            upsample=ups, gn=32 if cout % 128 == 0 else 0)
     finally:
-        lib.tf_gemm_force_config(0, 0, 0)
+        lib.tf_gemm_force_config(0, 0, 0); lib.tf_gemm_debug(0)
     # the operands the device actually multiplied: decoded bytes (NHWC / KRSC storage order -> logical NCHW / KCRS)
     xq = np.concatenate([raw(a).reshape(n, hw, hw, -1).transpose(0, 3, 1, 2) for a in x8], 1)
     wq = (raw(w8).reshape(cout, 3, 3, C) * sc.numpy()[:, None, None, None]).transpose(0, 3, 1, 2)
@@ -95,7 +106,8 @@ def test_conv2d_fp8_against_the_same_e4m3_operands(tf, n, c1, c2, hw, cout, stri
         np.testing.assert_allclose(g(y, silu=True).numpy(), O.silu(O.group_norm(torch.from_numpy(got), 32, 1e-5)).numpy(), **TOL)
 
 
-@pytest.mark.parametrize("m,c,force", [(128, 320, None), (2 * 1024, 640, (128, 128, 1)), (2 * 256, 1280, (64, 128, 1)), (77, 64, (64, 64, 1)), (8 * 9216, 320, None)])
+@pytest.mark.parametrize("m,c,force", [(128, 320, None), (2 * 1024, 640, (128, 128, 1)), (2 * 256, 1280, (64, 128, 1)), (77, 64, (64, 64, 1)), (8 * 9216, 320, None),
+                                       (2 * 1024, 640, (256, 128, 1, 512)), (1000, 320, (256, 128, 1, 512)), (8 * 9216, 320, (256, 128, 1, 512))])
 def test_feed_forward_fp8_against_the_same_e4m3_operands(tf, m, c, force):
     """LayerNorm -> e4m3, GEGLU projection (e4m3 in, e4m3 out), second Linear + residual: ff/nn.py:14-23 on fp8 operands.  Every stage
     is checked against the oracle fed with the e4m3 bytes the device produced for the stage before (a value on a code boundary may
@@ -123,7 +135,7 @@ def test_feed_forward_fp8_against_the_same_e4m3_operands(tf, m, c, force):
     wp, bp = pack_geglu(ff.net[0].proj.weight, ff.net[0].proj.bias)
     w8, sc = fp8.pack_weight(wp, {})
     if force:
-        lib.tf_gemm_force_config(*force)
+        lib.tf_gemm_force_config(*force[:3]); lib.tf_gemm_debug(force[3] if len(force) > 3 else 0)
     try:
         hid8 = fp8.linear_fp8(h8, w8, sc, bp, act=1, out_features=4 * c, out_fp8=True)
         hidq = raw(hid8).reshape(1, m, 4 * c)
@@ -143,7 +155,7 @@ def test_feed_forward_fp8_against_the_same_e4m3_operands(tf, m, c, force):
         got = ff(xd, residual=xd, ln=ln).numpy()
         np.testing.assert_array_equal(got, y)
     finally:
-        lib.tf_gemm_force_config(0, 0, 0)
+        lib.tf_gemm_force_config(0, 0, 0); lib.tf_gemm_debug(0)
         config.set_dtype("fp16")
 
 

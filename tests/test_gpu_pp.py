@@ -39,8 +39,8 @@ def dev(tf, x, layout=None, dtype=np.float16):
 class forced:
     """with forced(bn, sk): every GEMM launch inside runs k_igemm_pp<bn> with split-K sk (or raises)."""
 
-    def __init__(self, bn, sk=1, flags=512):
-        self.cfg, self.flags = (256, bn, sk), flags
+    def __init__(self, bn, sk=1, flags=512, bm=256):
+        self.cfg, self.flags = (bm, bn, sk), flags
 
     def __enter__(self):
         from tinyfusers_amd.native import lib
@@ -51,7 +51,7 @@ class forced:
         lib.tf_gemm_force_config(0, 0, 0); lib.tf_gemm_debug(0)
 
 
-@pytest.mark.parametrize("bn,flags", [(128, 512), (160, 512), (256, 512), (128, 512 | 8192), (160, 512 | 8192)])     # 8192: one phase per k-step on the 3-slot ring too
+@pytest.mark.parametrize("bn,flags", [(128, 512), (160, 512), (256, 512), (128, 512 | 8192), (160, 512 | 8192), (-128, 512), (-160, 512)])     # 8192: one phase per k-step on the 3-slot ring too; negative: the 192-row tile
 @pytest.mark.parametrize("m,n,k,sk", [(1000, 400, 64, 1), (1000, 400, 256, 1), (1000, 400, 1600, 1), (257, 160, 128, 1), (2048, 328, 704, 2), (777, 1280, 1088, 3),
                                       (256, 256, 192, 1), (5000, 320, 320, 1)])
 def test_pp_linear_exact_integers(tf, bn, flags, m, n, k, sk):
@@ -64,7 +64,7 @@ def test_pp_linear_exact_integers(tf, bn, flags, m, n, k, sk):
     y = tf.DeviceArray.empty((m, n))
     ws = tf.DeviceArray.empty((sk * m * n * 4 + 16,), np.uint8, "row")
     xd, wd, bd, rd = dev(tf, x), dev(tf, w), dev(tf, b), dev(tf, r)     # (kept alive: the pool would hand a freed block to the next upload)
-    with forced(bn, sk, flags):
+    with forced(abs(bn), sk, flags, 192 if bn < 0 else 256):
         hip.tf_linear_f16(y.ptr, xd.ptr, wd.ptr, bd.ptr, rd.ptr, m, n, k, 0, ws.ptr, ws.nbytes, None)
     np.testing.assert_array_equal(y.numpy(), (x @ w.T + b + r).astype(np.float16).astype(np.float32))
 
@@ -93,6 +93,11 @@ def test_pp_geglu(tf, bn, m, c):
     close(got, O.geglu(x, w, b).numpy())
 
 
+PP_CONV192 = [  # the 192-row tile (wave tiles of 48 rows; statistics in 96-row sub-blocks: image sizes that are multiples of 96 pixels)
+    (2, 128, 64, 24, 320, 3, 1, 0, 0, 160, 1, 32), (2, 128, 64, 24, 320, 3, 1, 0, 0, 160, 2, 32), (4, 320, 0, 48, 320, 3, 1, 0, 0, 160, 1, 32),
+    (3, 64, 0, 24, 128, 3, 1, 0, 0, 128, 1, 0), (2, 128, 0, 48, 128, 3, 2, 0, 0, 128, 1, 32), (2, 64, 0, 12, 64, 3, 1, 1, 0, 128, 1, 0),
+    (2, 128, 0, 24, 256, 3, 1, 0, 192, 128, 1, 32), (2, 320, 0, 24, 320, 1, 1, 0, 0, 160, 1, 0),
+]
 PP_CONV = [  # n, c1, c2 (concat), hw, cout, k, stride, upsample, c3 (folded 1x1 skip source), bn, sk, gn
     (2, 64, 0, 32, 160, 3, 1, 0, 0, 160, 1, 32),
     (2, 128, 64, 32, 320, 3, 1, 0, 0, 160, 1, 32),     # concat input, two n-tiles, statistics (two 128-row sub-blocks per tile)
@@ -110,8 +115,13 @@ PP_CONV = [  # n, c1, c2 (concat), hw, cout, k, stride, upsample, c3 (folded 1x1
 ]
 
 
+@pytest.mark.parametrize("n,c1,c2,hw,cout,k,stride,ups,c3,bn,sk,gn", PP_CONV192)
+def test_pp_conv2d_192_row_tile(tf, n, c1, c2, hw, cout, k, stride, ups, c3, bn, sk, gn):
+    test_pp_conv2d(tf, n, c1, c2, hw, cout, k, stride, ups, c3, bn, sk, gn, bm=192)
+
+
 @pytest.mark.parametrize("n,c1,c2,hw,cout,k,stride,ups,c3,bn,sk,gn", PP_CONV)
-def test_pp_conv2d(tf, n, c1, c2, hw, cout, k, stride, ups, c3, bn, sk, gn):
+def test_pp_conv2d(tf, n, c1, c2, hw, cout, k, stride, ups, c3, bn, sk, gn, bm=256):
     from oracle import ops as O
     from tinyfusers_amd.ff.group_norm import GroupNorm
     from tinyfusers_amd.vision.conv2d import Conv2d
@@ -135,7 +145,7 @@ def test_pp_conv2d(tf, n, c1, c2, hw, cout, k, stride, ups, c3, bn, sk, gn):
         e = rnd("ppc.e", (n, cout), 0.5); r = rnd("ppc.r", (n, cout, ho, ho))
         kw["bias_nc"] = dev(tf, e); kw["residual"] = dev(tf, r)
         want = want + torch.from_numpy(e)[:, :, None, None] + torch.from_numpy(r)
-    with forced(abs(bn), sk, 512 | (8192 if bn < 0 else 0)):
+    with forced(abs(bn), sk, 512 | (8192 if bn < 0 else 0), bm):
         y = m(x, gn=gn, upsample=bool(ups), **kw)
         got = y.numpy()
     close(got, want.numpy())

@@ -57,14 +57,14 @@ def bench_conv(n, hw, cin, cout, k, label, base_cfgs, pp_cfgs):
     name = {8: "deep", 16: "wide", 128: "patch", 256: "all8", 512: "PP"}
     base = min(r for r in res if r[4] != 512)
     pp = min(r for r in res if r[4] == 512)
-    print(f"{label:26s} M={M:6d} N={cout:5d} K={K:6d} | best other {base[0]:8.1f} us {flops/base[0]/1e6:6.0f} TF {base[1]}x{base[2]}/{base[3]} {name[base[4]]:5s} | best PP {pp[0]:8.1f} us {flops/pp[0]/1e6:6.0f} TF 256x{pp[2]}/{pp[3]} | " +
+    print(f"{label:26s} M={M:6d} N={cout:5d} K={K:6d} | best other {base[0]:8.1f} us {flops/base[0]/1e6:6.0f} TF {base[1]}x{base[2]}/{base[3]} {name[base[4]]:5s} | best PP {pp[0]:8.1f} us {flops/pp[0]/1e6:6.0f} TF {pp[1]}x{pp[2]}/{pp[3]} | " +
           " ".join(f"{name[f]}{bm}x{bn}/{sk}:{us:.0f}" for us, bm, bn, sk, f in sorted(res)), flush=True)
 
 
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "quick"
     B3 = [(128, 128, 1, 256), (128, 160, 1, 8), (128, 160, 1, 128), (256, 128, 1, 8), (128, 128, 1, 16)]
-    P = lambda *bns: [(256, bn, sk, 512) for bn in bns for sk in (1, 2)]
+    P = lambda *bns: [(bm, bn, sk, 512) for bm in (256, 192) for bn in bns if not (bm == 192 and bn == 256) for sk in (1, 2)]
     bench_conv(8, 96, 320, 320, 3, "conv3x3 320@96", B3, P(160))
     bench_conv(8, 48, 640, 640, 3, "conv3x3 640@48", B3, P(160, 128))
     bench_conv(8, 24, 1280, 1280, 3, "conv3x3 1280@24", B3 + [(128, 64, 1, 16)], P(160, 128, 256))

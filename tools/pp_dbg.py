@@ -40,6 +40,11 @@ def run(n, hw, cin, cout, k, bn, sk, label, extra=0):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "short":
+        run(8, 96, 320, 2560, 1, 128, 1, "lin 320->2560 @73728")
+        run(8, 96, 320, 320, 1, 160, 1, "conv1x1 320@96")
+        run(8, 48, 640, 640, 1, 128, 1, "conv1x1 640@48")
+        sys.exit(0)
     run(8, 96, 320, 320, 3, 160, 1, "conv3x3 320@96")
     run(8, 96, 320, 320, 3, 160, 1, "conv3x3 320@96", 8192)
     run(8, 48, 640, 640, 3, 128, 1, "conv3x3 640@48")
