@@ -4,7 +4,7 @@ R=$1; shift
 mkdir -p gpurun_out
 for i in $(seq 1 $R); do
   for v in "$@"; do
-    ( export $v; exec python bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-roofline > gpurun_out/ab.json 2> gpurun_out/ab.err )
+    ( export $v; exec python bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-roofline --no-e2e --no-config5 > gpurun_out/ab.json 2> gpurun_out/ab.err )
     python - <<PY
 import json
 try:

@@ -9,7 +9,7 @@ i=0
 for v in "$@"; do
   i=$((i+1))
   rm -rf $O/prof_ab
-  ( export $v; rocprofv3 --kernel-trace --stats -d $O/prof_ab --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-roofline > $O/prof_ab.log 2>&1 )
+  ( export $v; rocprofv3 --kernel-trace --stats -d $O/prof_ab --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-roofline --no-config5 > $O/prof_ab.log 2>&1 )
   echo "== $v" > $O/prof_ab_$i.txt
   python3 $R/tools/prof_summary.py $O/prof_ab 14 >> $O/prof_ab_$i.txt 2>&1
   rm -rf $O/prof_ab

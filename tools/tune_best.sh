@@ -4,7 +4,7 @@ export TF_GEMM_TUNE_TABLE=
 best=0
 for i in 1 2 3 4; do
   rm -f gpurun_out/tune_$i.txt
-  v=$(python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-roofline --tune-cache gpurun_out/tune_$i.txt 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['value'])")
+  v=$(python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-roofline --no-e2e --no-config5 --tune-cache gpurun_out/tune_$i.txt 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['value'])")
   echo "run $i: $v steps/s"
   if python -c "import sys; sys.exit(0 if float('$v') > float('$best') else 1)"; then best=$v; cp gpurun_out/tune_$i.txt gpurun_out/tune_best.txt; fi
 done
