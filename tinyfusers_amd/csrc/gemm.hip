@@ -247,8 +247,10 @@ __device__ __forceinline__ void igemm_scratch_write(const GemmP& p, f4 (&acc)[BN
 }
 
 // all 8 waves: wave (w4, half) stores rows [half*TM/2, (half+1)*TM/2) of consumer w4's tile
-template <int BM, int BN, bool OUT8 = false, bool BF = false, int KBMAX = 4>     // OUT8: the output is stored as e4m3 (fp8 kernels only; a template parameter keeps it out of the fp16 kernels); BF: bias / residual / output are bfloat16; KBMAX: items whose loads are in flight together
-__device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m0, int n0, int split, int w4, int half, int lane) {
+// LB: bias and the time embedding (bias_nc) come from an fp32 LDS table `lb` the kernel filled for its tile ([0][BN]: bias, [1 + i][BN]:
+//   bias_nc of image lb_img0 + i, i < 2) instead of per-item global loads -- the only loads left in the epilogue are the residual's.
+template <int BM, int BN, bool OUT8 = false, bool BF = false, int KBMAX = 4, bool LB = false>     // OUT8: the output is stored as e4m3 (fp8 kernels only; a template parameter keeps it out of the fp16 kernels); BF: bias / residual / output are bfloat16; KBMAX: items whose loads are in flight together
+__device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m0, int n0, int split, int w4, int half, int lane, const float* lb = nullptr, int lb_n0 = 0, int lb_m1 = 0) {
   typedef typename std::conditional<BF, bf16_t, half_t>::type E;
   typedef E E8 __attribute__((ext_vector_type(8)));
   const E* const e_bias = reinterpret_cast<const E*>(p.bias);
@@ -281,7 +283,7 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
       const int m = mb + row, n = nb + 32 * (c8 >> 1) + 8 * (c8 & 1);
       ok[k] = k0 + k < ITER && idx < ITEMS && m < p.M && n < p.N;
       if (ok[k]) {
-        ba[k] = *reinterpret_cast<const E8*>(e_bias + n); bg[k] = *reinterpret_cast<const E8*>(e_bias + n + 16);
+        if constexpr (!LB) { ba[k] = *reinterpret_cast<const E8*>(e_bias + n); bg[k] = *reinterpret_cast<const E8*>(e_bias + n + 16); }
         if (p.residual) rv[k] = *reinterpret_cast<const E8*>(e_res + (long long)m * No + ((n >> 5) * 16 + (n & 15)));
       }
     }
@@ -298,10 +300,20 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
       f4 a0 = *reinterpret_cast<const f4*>(r), a1 = *reinterpret_cast<const f4*>(r + 4);
       f4 g0 = *reinterpret_cast<const f4*>(r + 16), g1 = *reinterpret_cast<const f4*>(r + 20);
       E8 o;
+      if constexpr (LB) {
+        const float* t = lb + (n - lb_n0);
+        f4 b0 = *reinterpret_cast<const f4*>(t), b1 = *reinterpret_cast<const f4*>(t + 4), c0 = *reinterpret_cast<const f4*>(t + 16), c1 = *reinterpret_cast<const f4*>(t + 20);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (E)((a0[e] + b0[e]) * gelu_f(g0[e] + c0[e]));
+          o[4 + e] = (E)((a1[e] + b1[e]) * gelu_f(g1[e] + c1[e]));
+        }
+      } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         o[e] = (E)((a0[e] + (float)ba[k][e]) * gelu_f(g0[e] + (float)bg[k][e]));
         o[4 + e] = (E)((a1[e] + (float)ba[k][4 + e]) * gelu_f(g1[e] + (float)bg[k][4 + e]));
+      }
       }
       if (p.residual) {
 #pragma unroll
@@ -334,8 +346,10 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
       ok[k] = k0 + k < ITER && idx < ITEMS && m < p.M && n < p.N;
       if (ok[k]) {
         const long long o = (long long)m * p.N + n;
-        if (p.bias) bv[k] = *reinterpret_cast<const E8*>(e_bias + n);
-        if (p.bias_nc) cv[k] = *reinterpret_cast<const E8*>(e_bias_nc + (long long)(m / p.HoWo) * p.bias_nc_stride + n);
+        if constexpr (!LB) {
+          if (p.bias) bv[k] = *reinterpret_cast<const E8*>(e_bias + n);
+          if (p.bias_nc) cv[k] = *reinterpret_cast<const E8*>(e_bias_nc + (long long)(m / p.HoWo) * p.bias_nc_stride + n);
+        }
         if (p.residual) rv[k] = *reinterpret_cast<const E8*>(e_res + o);
       }
     }
@@ -348,8 +362,14 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
       float* r = sc + row * RS + c8 * 8;
       f4 v0 = *reinterpret_cast<const f4*>(r), v1 = *reinterpret_cast<const f4*>(r + 4);
       const long long o = (long long)m * p.N + n;
+      if constexpr (LB) {
+        const float* t = lb + (n - lb_n0);
+        if (p.bias) { v0 += *reinterpret_cast<const f4*>(t); v1 += *reinterpret_cast<const f4*>(t + 4); }
+        if (p.bias_nc) { const float* u = t + (m >= lb_m1 ? 2 * BN : BN); v0 += *reinterpret_cast<const f4*>(u); v1 += *reinterpret_cast<const f4*>(u + 4); }
+      } else {
       if (p.bias) { for (int e = 0; e < 4; ++e) { v0[e] += (float)bv[k][e]; v1[e] += (float)bv[k][4 + e]; } }
       if (p.bias_nc) { for (int e = 0; e < 4; ++e) { v0[e] += (float)cv[k][e]; v1[e] += (float)cv[k][4 + e]; } }
+      }
       if (p.residual) { for (int e = 0; e < 4; ++e) { v0[e] += (float)rv[k][e]; v1[e] += (float)rv[k][4 + e]; } }
       E8 out;
       for (int e = 0; e < 4; ++e) { out[e] = (E)v0[e]; out[4 + e] = (E)v1[e]; }
@@ -1892,6 +1912,17 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
     asm volatile("" ::: "memory");
   };
 
+  // bias and time-embedding values of this tile's columns, fetched now (latency under the K loop) and handed to the epilogue through an
+  // LDS table: thread t < BN holds column n0 + t; a tile spans at most two images (the host admits the kernel only where HoWo >= BM)
+  const int lb_img0 = m0 / p.HoWo;
+  float lb_b = 0.f, lb_c0 = 0.f, lb_c1 = 0.f;
+  if (tid < BN && n0 + tid < p.N && p.splitk <= 1) {
+    if (p.bias) lb_b = (float)p.bias[n0 + tid];
+    if (p.bias_nc) {
+      lb_c0 = (float)p.bias_nc[(long long)lb_img0 * p.bias_nc_stride + n0 + tid];
+      if ((lb_img0 + 1) * p.HoWo < p.M) lb_c1 = (float)p.bias_nc[(long long)(lb_img0 + 1) * p.bias_nc_stride + n0 + tid];
+    }
+  }
   // ---- prologue: the first D tiles, whole
 #pragma unroll
   for (int s_ = 0; s_ < D; ++s_)
@@ -1975,14 +2006,17 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
 #pragma unroll
   for (int i = 0; i < NI; ++i) csum[i] = (f4){0.f, 0.f, 0.f, 0.f};
   constexpr int BS = BM / 2;                              // rows of an epilogue pass
+  float* const lbt = reinterpret_cast<float*>(smem + 4 * (BS / 2) * (TN + 4) * 4 + BS * 8 + 4 * BN * 8);    // behind the scratch, the LayerNorm table and the statistics table
+  if (tid < BN) { lbt[tid] = lb_b; lbt[BN + tid] = lb_c0; lbt[2 * BN + tid] = lb_c1; }                     // (visible behind the first pass's barrier)
+  const int lb_m1 = (lb_img0 + 1) * p.HoWo;
 #pragma unroll
   for (int sm = 0; sm < 2; ++sm) {
     if ((wm >> 1) == sm) igemm_scratch_write<BS, BN>(p, acc, csum, smem, (wm & 1) | (wn << 1), lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     barrier();
     // (two items' loads in flight at a time: half of the accumulators is still live during the first pass)
-    if (F8 && p.out8) igemm_epilogue<BS, BN, true, false, 2>(p, smem, m0 + sm * BS, n0, split, wid & 3, wid >> 2, lane);
-    else igemm_epilogue<BS, BN, false, false, 2>(p, smem, m0 + sm * BS, n0, split, wid & 3, wid >> 2, lane);
+    if (F8 && p.out8) igemm_epilogue<BS, BN, true, false, 2, true>(p, smem, m0 + sm * BS, n0, split, wid & 3, wid >> 2, lane, lbt, n0, lb_m1);
+    else igemm_epilogue<BS, BN, false, false, 2, true>(p, smem, m0 + sm * BS, n0, split, wid & 3, wid >> 2, lane, lbt, n0, lb_m1);
     if (p.gn_part && m0 + sm * BS < p.M) igemm_gn_stats<BS, BN>(p, smem, m0 + sm * BS, n0, wid & 3, wid >> 2, lane);   // (block-uniform: the barrier inside is safe)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     barrier();
@@ -2462,12 +2496,13 @@ static bool pp_ok(const GemmP& p, int bn, int bm = 256) {
   if (bm != 256 && !(bm == 192 && bn != 256)) return false;
   if (p.bf16 || p.gi_part || p.ln_colsum || gemm_generic(p)) return false;
   if (p.fp8 && bn == 256) return false;                  // the e4m3 form holds a whole K tile's fragments: needs the three-slot ring
+  if (p.bias_nc && p.HoWo < bm) return false;            // the epilogue's time-embedding table holds two images per tile
   return p.act != 1 || bn % 64 == 0;                     // GEGLU pairs 16-row value | gate blocks inside a wave tile
 }
 template <int BN, int NP, bool FASTA, bool F8 = false, bool H2 = false, int BM = 256>
 static int launch_pp2(const GemmP& p, hipStream_t st) {
   constexpr int STAGE = (BM + BN) * 128, NS = (163840 / STAGE) >= 3 ? 3 : 2;
-  constexpr int ring = NS * STAGE, scratch = 4 * (BM / 4) * (BN / 2 + 4) * 4, tail = (BM / 2) * 8 + 4 * BN * 8;
+  constexpr int ring = NS * STAGE, scratch = 4 * (BM / 4) * (BN / 2 + 4) * 4, tail = (BM / 2) * 8 + 4 * BN * 8 + 3 * BN * 4;   // (+ the bias / time-embedding table)
   constexpr int smem = ring > scratch + tail ? ring : scratch + tail;
   static_assert(smem <= 163840, "LDS budget");
   if constexpr (!F8 && FASTA && BM == 256) {               // ablation build (tools/pp_dbg.py): the lean-addressing fp16 instances only
