@@ -176,3 +176,31 @@ def test_pp_agrees_with_the_deep_ring_kernel_at_config5_size(tf):
     assert np.isfinite(y_pp).all()
     np.testing.assert_allclose(y_pp, y_ref, atol=4e-3, rtol=4e-3)
     np.testing.assert_allclose(y_pp2, 2.0 * y_pp, rtol=0, atol=1.2e-7)      # exact up to the fp16 subnormal spacing (2^-24) of outputs below 2^-14
+
+
+@pytest.mark.parametrize("m,n,k,act,bm,bn", [(4608, 960, 320, 0, 256, 160), (4608, 960, 320, 0, 192, 160), (2000, 640, 640, 0, 256, 128), (1100, 1280, 1280, 0, 192, 128),
+                                             (4608, 1280, 320, 1, 256, 128), (4608, 1280, 320, 1, 256, 256), (1000, 2560, 640, 1, 192, 128), (300, 128, 64, 0, 256, 128)])
+def test_pp_linear_with_folded_layer_norm(tf, m, n, k, act, bm, bn):
+    """Linear(LayerNorm(x)) as one GEMM on the raw x (tf_linear_ln_f16; ff/layer_norm.py:34-49 followed by ff/linear.py:112-121 / ff/nn.py:5-12)
+    on the ping-pong kernel: the row statistics come from the fragments the waves multiply (8 v_dot2 per fragment), the fold
+    rstd (acc - mean colsum) happens in the shared epilogue.  Non-zero row means exercise the cancellation."""
+    from oracle import ops as O
+    from tinyfusers_amd.ff.layer_norm import LayerNorm
+    from tinyfusers_amd.ff.linear import fold_layer_norm, linear_ln_f16
+    from tinyfusers_amd.ff.nn import GEGLU
+    x = rnd("pln.x", (m, k), 1.5) + 0.7
+    g, b = 1 + rnd("pln.g", (k,), 0.1), rnd("pln.b", (k,), 0.1)
+    ln = LayerNorm(k); ln.weight = dev(tf, g); ln.bias = dev(tf, b)
+    xn = O.layer_norm(x, g, b)
+    with forced(bn, 1, 512, bm):
+        if act == 0:
+            w, bias = rnd("pln.w", (n, k), k ** -0.5), rnd("pln.bias", (n,), 0.1)
+            r = rnd("pln.r", (m, n))
+            got = linear_ln_f16(dev(tf, x), fold_layer_norm(dev(tf, w), dev(tf, bias), ln), ln.eps, residual=dev(tf, r)).numpy()
+            want = (O.linear(xn, w, bias) + torch.from_numpy(r)).numpy()
+        else:
+            w, bias = rnd("pln.w", (2 * n, k), k ** -0.5), rnd("pln.bias", (2 * n,), 0.1)
+            ge = GEGLU(k, n, init=False); ge.proj.weight = dev(tf, w); ge.proj.bias = dev(tf, bias)
+            got = ge(dev(tf, x), ln=ln).numpy()
+            want = O.geglu(xn, w, bias).numpy()
+    close(got, want)

@@ -1631,8 +1631,13 @@ __device__ __forceinline__ void dma16(i4v rsrc, unsigned voffset_bytes, unsigned
 //   multiple of 128) one load.  Per-output-channel weight scales multiply the accumulators in front of the shared epilogue.
 // BM = 256 or 192 rows: 192 (wave tiles of 48 rows) exists for the tile COUNT -- 96 x 96 latents give M = 9216 * images rows, and
 //   e.g. 73728 x 320 is 576 tiles of 256 x 160 = 2.25 rounds on 256 CUs but 768 tiles of 192 x 160 = 3 rounds exactly.
-template <int BN, int NP, bool FASTA, bool DBG = false, bool F8 = false, bool H2 = false, int BM = 256>
+// LNF = the LayerNorm fold (tf_linear_ln_f16: Linear(LN(x)) = rstd[m] (x . w'^T - mean[m] colsum[n]) + bias'[n]): the row statistics come from
+//   the activation FRAGMENTS the wave multiplies anyway -- lane (lr, lg) holds the 8 k-values k = 8 lg .. of row lr of every fragment, so
+//   8 v_dot2_f32_f16 per fragment (in the MFMA block's spare issue slots) keep (sum, sum of squares) of that row's share, two lane
+//   shuffles at the end complete the row -- and they end up in exactly the lanes whose accumulators belong to that row.
+template <int BN, int NP, bool FASTA, bool DBG = false, bool F8 = false, bool H2 = false, int BM = 256, bool LNF = false>
 __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
+  static_assert(!LNF || !F8, "the LayerNorm fold is an fp16 path");
   constexpr int TN = BN / 2, MJ = BM / 64, NI = TN / 16;
   constexpr int APW = BM / 64;                            // activation pieces (8 rows x 128 B) per wave and stage: BM / 8 pieces in front of the weight pieces
   constexpr int ES = F8 ? 1 : 2;                          // bytes per element
@@ -1864,8 +1869,25 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) wf[f][i] = *reinterpret_cast<const h8*>(sb + ((wo_ + i * 2048) ^ (k2 * 64)));
   };
+  float ls[MJ], lq[MJ];                                    // LNF: this lane's share of (sum x, sum x^2) of row lr of every pixel tile
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) { ls[j] = 0.f; lq[j] = 0.f; }
   auto mma = [&]() {                                       // the MFMAs of every k-step held in registers
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (LNF) {
+      typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+      const hh2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+      for (int f = 0; f < KF; ++f)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            hh2 v = {xf[f][j][2 * e], xf[f][j][2 * e + 1]};
+            ls[j] = __builtin_amdgcn_fdot2(v, one2, ls[j], false);
+            lq[j] = __builtin_amdgcn_fdot2(v, v, lq[j], false);
+          }
+    }
     if constexpr (DBG) {
       if (p.dbg & 2) {
 #pragma unroll
@@ -2005,13 +2027,42 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
   f4 csum[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) csum[i] = (f4){0.f, 0.f, 0.f, 0.f};
+  f2 lstat[MJ];
+  if constexpr (LNF) {
+    const float invK = 1.0f / (float)p.K;
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+      float s_ = ls[j], q_ = lq[j];
+      s_ += __shfl_xor(s_, 16, 64); q_ += __shfl_xor(q_, 16, 64);
+      s_ += __shfl_xor(s_, 32, 64); q_ += __shfl_xor(q_, 32, 64);
+      const float mean = s_ * invK;
+      lstat[j] = (f2){mean, rsqrtf(fmaxf(q_ * invK - mean * mean, 0.f) + p.ln_eps)};
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int n = n0 + wn * TN + i * 16 + lg * 4;
+      if (n + 3 < p.N) csum[i] = *reinterpret_cast<const f4*>(p.ln_colsum + n);
+    }
+  }
   constexpr int BS = BM / 2;                              // rows of an epilogue pass
   float* const lbt = reinterpret_cast<float*>(smem + 4 * (BS / 2) * (TN + 4) * 4 + BS * 8 + 4 * BN * 8);    // behind the scratch, the LayerNorm table and the statistics table
   if (tid < BN) { lbt[tid] = lb_b; lbt[BN + tid] = lb_c0; lbt[2 * BN + tid] = lb_c1; }                     // (visible behind the first pass's barrier)
   const int lb_m1 = (lb_img0 + 1) * p.HoWo;
 #pragma unroll
   for (int sm = 0; sm < 2; ++sm) {
-    if ((wm >> 1) == sm) igemm_scratch_write<BS, BN>(p, acc, csum, smem, (wm & 1) | (wn << 1), lane);
+    if ((wm >> 1) == sm) {
+      if constexpr (LNF) {
+        // (mean, rstd) of this wave's rows into the table igemm_scratch_write reads them from; the wave with the other channel half
+        // writes the very same values to the very same slots, and every wave reads back only what it wrote itself
+        f2* stats = reinterpret_cast<f2*>(smem + 4 * (BS / 2) * (TN + 4) * 4);
+        if (lg == 0) {
+#pragma unroll
+          for (int j = 0; j < MJ; ++j) stats[(wm & 1) * (BS / 2) + j * 16 + lr] = lstat[j];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      igemm_scratch_write<BS, BN>(p, acc, csum, smem, (wm & 1) | (wn << 1), lane);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     barrier();
     // (two items' loads in flight at a time: half of the accumulators is still live during the first pass)
@@ -2494,18 +2545,19 @@ static bool gemm_generic(const GemmP& p);
 static bool pp_ok(const GemmP& p, int bn, int bm = 256) {
   if (bn != 128 && bn != 160 && bn != 256) return false;
   if (bm != 256 && !(bm == 192 && bn != 256)) return false;
-  if (p.bf16 || p.gi_part || p.ln_colsum || gemm_generic(p)) return false;
+  if (p.bf16 || p.gi_part || gemm_generic(p)) return false;
+  if (p.ln_colsum && (p.fp8 || p.S != 1 || p.stride != 1 || p.ups)) return false;   // the LayerNorm fold: linears, fp16
   if (p.fp8 && bn == 256) return false;                  // the e4m3 form holds a whole K tile's fragments: needs the three-slot ring
   if (p.bias_nc && p.HoWo < bm) return false;            // the epilogue's time-embedding table holds two images per tile
   return p.act != 1 || bn % 64 == 0;                     // GEGLU pairs 16-row value | gate blocks inside a wave tile
 }
-template <int BN, int NP, bool FASTA, bool F8 = false, bool H2 = false, int BM = 256>
+template <int BN, int NP, bool FASTA, bool F8 = false, bool H2 = false, int BM = 256, bool LNF = false>
 static int launch_pp2(const GemmP& p, hipStream_t st) {
   constexpr int STAGE = (BM + BN) * 128, NS = (163840 / STAGE) >= 3 ? 3 : 2;
   constexpr int ring = NS * STAGE, scratch = 4 * (BM / 4) * (BN / 2 + 4) * 4, tail = (BM / 2) * 8 + 4 * BN * 8 + 3 * BN * 4;   // (+ the bias / time-embedding table)
   constexpr int smem = ring > scratch + tail ? ring : scratch + tail;
   static_assert(smem <= 163840, "LDS budget");
-  if constexpr (!F8 && FASTA && BM == 256) {               // ablation build (tools/pp_dbg.py): the lean-addressing fp16 instances only
+  if constexpr (!F8 && FASTA && BM == 256 && !LNF) {       // ablation build (tools/pp_dbg.py): the lean-addressing fp16 instances only
     if (p.dbg) {
       static bool attr_dbg = false;
       if (!attr_dbg) {
@@ -2519,10 +2571,10 @@ static int launch_pp2(const GemmP& p, hipStream_t st) {
   }
   static bool attr_set = false;
   if (!attr_set) {
-    TF_HIP(hipFuncSetAttribute((const void*)k_igemm_pp<BN, NP, FASTA, false, F8, H2, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    TF_HIP(hipFuncSetAttribute((const void*)k_igemm_pp<BN, NP, FASTA, false, F8, H2, BM, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_igemm_pp<BN, NP, FASTA, false, F8, H2, BM>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
+  hipLaunchKernelGGL((k_igemm_pp<BN, NP, FASTA, false, F8, H2, BM, LNF>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
@@ -2539,10 +2591,14 @@ static int launch_pp(const GemmP& p, hipStream_t st) {
       if (fast) return h2 ? launch_pp2<BN, 1, true, true, true, BM>(p, st) : launch_pp2<BN, 1, true, true, false, BM>(p, st);
       return h2 ? launch_pp2<BN, 1, false, true, true, BM>(p, st) : launch_pp2<BN, 1, false, true, false, BM>(p, st);
     }
+    if (p.ln_colsum) return launch_pp2<BN, 1, true, false, false, BM, true>(p, st);    // (pp_ok admits linears only: the lean addressing)
     if (np1) return fast ? launch_pp2<BN, 1, true, false, false, BM>(p, st) : launch_pp2<BN, 1, false, false, false, BM>(p, st);
   }
   if (p.fp8) { tf_set_error("k_igemm_pp: no e4m3 instance for a %d-wide tile", BN); return TF_E_UNSUPPORTED; }
-  if constexpr (BM == 256) return fast ? launch_pp2<BN, 2, true>(p, st) : launch_pp2<BN, 2, false>(p, st);
+  if constexpr (BM == 256) {
+    if (p.ln_colsum) return launch_pp2<BN, 2, true, false, false, 256, true>(p, st);
+    return fast ? launch_pp2<BN, 2, true>(p, st) : launch_pp2<BN, 2, false>(p, st);
+  }
   else { tf_set_error("k_igemm_pp: the 192-row tile has the one-phase form only"); return TF_E_UNSUPPORTED; }
 }
 // rows of a tile as the GroupNorm-statistics code sees them: the ping-pong kernel's epilogue works in 128-row sub-blocks
@@ -2774,7 +2830,7 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
     const int bm = ppbm[bi], bn = ppbn[ci];
     if (!pp_ok(p, bn, bm) || p.M <= 256) continue;
     for (int sk = 1; sk <= 8; sk *= 2) {
-      if (sk > 1 && (p.act == 1 || p.out32 || p.ktiles / sk < 4 || !workspace || (size_t)sk * p.M * p.N * 4 > workspace_bytes)) break;
+      if (sk > 1 && (p.act == 1 || p.out32 || p.ln_colsum || p.ktiles / sk < 4 || !workspace || (size_t)sk * p.M * p.N * 4 > workspace_bytes)) break;
       long long blocks = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * sk;
       if (blocks < 128) continue;
       if (sk > 1 && blocks > 1024) break;
