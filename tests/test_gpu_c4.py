@@ -1,0 +1,117 @@
+"""GPU parity tests (pytest -m gpu) of k_gemm_c4 -- the persistent short-K kernel (two resident 4-wave blocks per CU walk the 128 x 128
+tile list, the next tile's first K tile is fetched during the epilogue, the epilogue stays in registers) -- forced through
+tf_gemm_force_config(128, 128, 1) + tf_gemm_debug(1024), which fails loudly where the kernel cannot take a launch.  Exact small-integer
+GEMMs first (any lane-map, ring, prefetch or tile-walk slip is an O(1) error), then the reference's ops that reach it (ff/linear.py:112-121,
+ff/nn.py:5-23, the 1x1 convolutions of vision/conv2d.py:9-58 incl. the concat input) against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_pp import close, dev, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tf():
+    import tinyfusers_amd.storage.tensor as T
+    T.ensure_init(0)
+    return T
+
+
+class forced:
+    def __init__(self, flags=1024):
+        self.flags = flags
+
+    def __enter__(self):
+        from tinyfusers_amd.native import lib
+        lib.tf_gemm_force_config(128, 128, 1); lib.tf_gemm_debug(self.flags)
+
+    def __exit__(self, *a):
+        from tinyfusers_amd.native import lib
+        lib.tf_gemm_force_config(0, 0, 0); lib.tf_gemm_debug(0)
+
+
+@pytest.mark.parametrize("flags", [1024, 1024 | 64])       # 64: m-fastest tile order
+@pytest.mark.parametrize("m,n,k", [(1000, 400, 64), (1000, 400, 256), (257, 160, 128), (5000, 320, 320), (8192, 2560, 320), (70000, 128, 64), (129, 8, 1280),
+                                   (66000, 136, 192)])
+def test_c4_linear_exact_integers(tf, flags, m, n, k):
+    """1 ... 20 K tiles, 1 ... 1280 tiles (fewer and more than the 512 resident blocks: the cross-tile prefetch and the tile walk),
+    ragged M / N edges, bias + residual."""
+    from tinyfusers_amd.native import hip
+    rs = np.random.RandomState(m + n + k)
+    x = rs.randint(-3, 4, (m, k)).astype(np.float32); w = rs.randint(-2, 3, (n, k)).astype(np.float32)
+    b = rs.randint(-4, 5, (n,)).astype(np.float32); r = rs.randint(-8, 9, (m, n)).astype(np.float32)
+    y = tf.DeviceArray.empty((m, n))
+    xd, wd, bd, rd = dev(tf, x), dev(tf, w), dev(tf, b), dev(tf, r)
+    with forced(flags):
+        hip.tf_linear_f16(y.ptr, xd.ptr, wd.ptr, bd.ptr, rd.ptr, m, n, k, 0, None, 0, None)
+    np.testing.assert_array_equal(y.numpy(), (x @ w.T + b + r).astype(np.float16).astype(np.float32))
+    y2 = tf.DeviceArray.empty((m, n))
+    with forced(flags):
+        hip.tf_linear_f16(y2.ptr, xd.ptr, wd.ptr, None, None, m, n, k, 0, None, 0, None)
+    np.testing.assert_array_equal(y2.numpy(), (x @ w.T).astype(np.float16).astype(np.float32))
+
+
+def test_c4_refuses_what_it_cannot_run(tf):
+    from tinyfusers_amd.native import hip
+    m, n, k = 512, 256, 200                                # K off the 64 grid
+    y = tf.DeviceArray.empty((m, n))
+    x, w = dev(tf, rnd("c4r.x", (m, k))), dev(tf, rnd("c4r.w", (n, k)))
+    with forced():
+        with pytest.raises(RuntimeError):
+            hip.tf_linear_f16(y.ptr, x.ptr, w.ptr, None, None, m, n, k, 0, None, 0, None)
+
+
+@pytest.mark.parametrize("m,c", [(1000, 64), (4608, 320), (9216, 320)])
+def test_c4_geglu(tf, m, c):
+    from oracle import ops as O
+    from tinyfusers_amd.ff.nn import GEGLU
+    x = rnd("c4g.x", (m, c)); w = rnd("c4g.w", (8 * c, c), c ** -0.5); b = rnd("c4g.b", (8 * c,), 0.1)
+    g = GEGLU(c, 4 * c, init=False); g.proj.weight = dev(tf, w); g.proj.bias = dev(tf, b)
+    with forced():
+        got = g(dev(tf, x)).numpy()
+    close(got, O.geglu(x, w, b).numpy())
+
+
+@pytest.mark.parametrize("m,n,k,act", [(4608, 960, 320, 0), (2000, 640, 640, 0), (1100, 1280, 1280, 0), (4608, 1280, 320, 1), (1000, 2560, 640, 1), (300, 128, 64, 0)])
+def test_c4_linear_with_folded_layer_norm(tf, m, n, k, act):
+    """Linear(LayerNorm(x)) as one GEMM on the raw x (tf_linear_ln_f16): the row statistics come from the fragments the waves multiply,
+    the fold rstd (acc - mean colsum) + bias' happens on the accumulators."""
+    from oracle import ops as O
+    from tinyfusers_amd.ff.layer_norm import LayerNorm
+    from tinyfusers_amd.ff.linear import fold_layer_norm, linear_ln_f16
+    from tinyfusers_amd.ff.nn import GEGLU
+    x = rnd("cln.x", (m, k), 1.5) + 0.7
+    g, b = 1 + rnd("cln.g", (k,), 0.1), rnd("cln.b", (k,), 0.1)
+    ln = LayerNorm(k); ln.weight = dev(tf, g); ln.bias = dev(tf, b)
+    xn = O.layer_norm(x, g, b)
+    with forced():
+        if act == 0:
+            w, bias = rnd("cln.w", (n, k), k ** -0.5), rnd("cln.bias", (n,), 0.1)
+            r = rnd("cln.r", (m, n))
+            got = linear_ln_f16(dev(tf, x), fold_layer_norm(dev(tf, w), dev(tf, bias), ln), ln.eps, residual=dev(tf, r)).numpy()
+            want = (O.linear(xn, w, bias) + torch.from_numpy(r)).numpy()
+        else:
+            w, bias = rnd("cln.w", (2 * n, k), k ** -0.5), rnd("cln.bias", (2 * n,), 0.1)
+            ge = GEGLU(k, n, init=False); ge.proj.weight = dev(tf, w); ge.proj.bias = dev(tf, bias)
+            got = ge(dev(tf, x), ln=ln).numpy()
+            want = O.geglu(xn, w, bias).numpy()
+    close(got, want)
+
+
+@pytest.mark.parametrize("n,c1,c2,hw,cout", [(2, 128, 64, 32, 320), (2, 320, 0, 32, 320), (3, 64, 0, 24, 128)])
+def test_c4_conv1x1(tf, n, c1, c2, hw, cout):
+    """A 1x1 / stride 1 convolution is the same GEMM; the concat input is a second K segment with its own row pitch."""
+    from oracle import ops as O
+    from tinyfusers_amd.vision.conv2d import Conv2d
+    xa = rnd("c4c.xa", (n, c1, hw, hw)); xb = rnd("c4c.xb", (n, c2, hw, hw)) if c2 else None
+    cin = c1 + c2
+    wt = rnd("c4c.w", (cout, cin, 1, 1), cin ** -0.5); b = rnd("c4c.b", (cout,), 0.1); r = rnd("c4c.r", (n, cout, hw, hw))
+    m = Conv2d(cin, cout, [1, 1], init=False); m.weight = dev(tf, wt); m.bias = dev(tf, b)
+    x = (dev(tf, xa), dev(tf, xb)) if c2 else dev(tf, xa)
+    xin = torch.from_numpy(np.concatenate((xa, xb), 1) if c2 else xa)
+    want = O.conv2d_bias(xin, wt, b, (0, 0)) + torch.from_numpy(r)
+    with forced():
+        got = m(x, residual=dev(tf, r)).numpy()
+    close(got, want.numpy())

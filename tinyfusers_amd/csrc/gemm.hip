@@ -2074,6 +2074,215 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
   }
 }
 
+// =====================================================================================================================
+// SHORT-K kernel (round 3): Linear / 1x1 convolution with K <= a few K tiles and many output tiles -- q|k|v, to_out, GEGLU projection
+// (ff/linear.py:112-121, ff/nn.py:5-12, attention/attention.py:35-41 of the reference).  For these shapes every part of a launch of the
+// kernels above is near a bound of its own -- block dispatch + prologue ~3.4 us per round of blocks, operand re-reads from L2, the MFMAs,
+// the output stores at the HBM write rate -- but the parts run one AFTER the other (tools/geglu_dbg.py: 8.5 + 10 + 9 + 5 ~ 31.6 us for
+// 8192 x 2560 x 320, where max() would be 10): a block is a serial chain and a CU holds two of them.  This kernel removes the seams:
+//   * PERSISTENT: 2 blocks of 4 waves per CU for the whole launch, each walking its own list of 128 x 128 tiles -- no dispatch or argument
+//     loads per tile, and the stores of tile i drain while tile i + 1 loads and multiplies (nothing ever waits for a store);
+//   * all four waves load and compute (2 x 2 wave tiles of 64 x 64); 2-slot LDS-DMA ring, one s_barrier per K tile; the first K tile of
+//     the NEXT output tile is issued before the epilogue of this one (cross-tile prefetch: the ring slot it lands in is not the one the
+//     epilogue borrows);
+//   * epilogue without a block barrier: LayerNorm fold / bias / GEGLU in registers on the accumulators (a lane owns 4 consecutive channels of
+//     a pixel), rounded to fp16, transposed through a PRIVATE per-wave LDS patch (half a wave tile at a time) into 16-byte row segments,
+//     residual added there, stored;
+//   * the two blocks of a CU are independent programs: one's epilogue and first-tile latency overlap the other's MFMAs.
+// S = 1 / stride 1 / no padding (rows are contiguous K vectors; the concat pair of the FF2 . proj_out fold is two sources), channel
+// counts on the 64 grid, fp16, no split-K / statistics / time embedding (those launches keep the kernels above).
+template <bool LNF>
+__global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
+  constexpr int BM = 128, BN = 128, MJ = 4, NI = 4;
+  constexpr int STAGE = (BM + BN) * 128;                  // 32 KiB
+  constexpr int PATCH = 32 * 144;                         // per-wave transpose patch: 32 rows x (128 + 16) bytes
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid & 1, wn = wid >> 1;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int sub = lane >> 3;
+  const int cs = (lane & 7) ^ ((4 * (wid & 1) + (sub >> 1)) & 7);       // source chunk: pieces of a wave are 4 apart, so 8 g's parity is the wave's
+  const unsigned lds0 = lds_off(smem);
+  const int ntm = p.ntm, ntn = p.ntn, ntiles = ntm * ntn;
+  const int nt = p.ktiles;
+  const int C1_ = p.C1, K_ = p.K, M_ = p.M, N_ = p.N;
+  const i4v rs_x1 = raw_rsrc(p.x, p.x_bytes), rs_x2 = raw_rsrc(p.x2 ? p.x2 : p.x, p.x2_bytes), rs_w = raw_rsrc(p.w, p.w_bytes);
+  const int C2_ = p.C2;
+  const int fo = lr * 128 + ((lg ^ ((lr >> 1) & 7)) << 4);
+  const int xo = wm * 64 * 128 + fo, wo_ = (BM + wn * 64) * 128 + fo;
+  char* const patch = smem + STAGE + wid * PATCH;         // inside ring slot 1 (the next tile's first K tile lands in slot 0)
+
+  // this wave's staging rows of a tile: activation pieces wid + 4 i (i < 4: rows 8 (wid + 4 i) + sub), weight pieces likewise
+  int am[4];
+  unsigned gw[4];
+  auto setup = [&](int tile, int& m0, int& n0) {
+    int tm, tn;
+    if (p.order == 0) { tm = tile / ntn; tn = tile - tm * ntn; } else { tn = tile / ntm; tm = tile - tn * ntm; }
+    m0 = tm * BM; n0 = tn * BN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + 8 * (wid + 4 * i) + sub;
+      am[i] = m < M_ ? m : -1;
+      const int n = n0 + 8 * (wid + 4 * i) + sub;
+      gw[i] = n < N_ ? (unsigned)(n * K_ + cs * 8) * 2u : TF_OOB;
+    }
+  };
+  auto stage = [&](int slot, int kt) {                    // K tile kt of the tile whose rows are in (am, gw)
+    const int c = kt * 64;
+    const bool second = c >= C1_;
+    const int ld = second ? C2_ : C1_;
+    const int cc = (second ? c - C1_ : c) + cs * 8;
+    const i4v rs = second ? rs_x2 : rs_x1;
+    const unsigned base = lds0 + (unsigned)slot * STAGE + (unsigned)wid * 1024u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16(rs, am[i] >= 0 ? (unsigned)(am[i] * ld + cc) * 2u : TF_OOB, base + (unsigned)i * 4096u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16(rs_w, gw[i] != TF_OOB ? gw[i] + (unsigned)kt * 128u : TF_OOB, base + 16384u + (unsigned)i * 4096u);
+  };
+  auto barrier = [&]() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  int m0, n0;
+  setup(tile, m0, n0);
+  stage(0, 0);
+  for (; tile < ntiles; tile += gridDim.x) {
+    f4 acc[NI][MJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+    float ls[MJ], lq[MJ];
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) { ls[j] = 0.f; lq[j] = 0.f; }
+    // bias (and LayerNorm column sums) of this lane's columns: requested now, consumed behind the K loop -- and BEFORE the next tile's
+    // prefetch is issued: the compiler counts only its own loads, so a wait for them placed behind the asm LDS-DMA would wait for the DMA too
+    const int nb = n0 + wn * 64;                           // first (packed) column of the wave tile
+    f4 bq[NI], cq[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      bq[i] = (f4){0.f, 0.f, 0.f, 0.f}; cq[i] = (f4){0.f, 0.f, 0.f, 0.f};
+      const int n = nb + i * 16 + lg * 4;
+      if (n + 3 < N_) {
+        if (p.bias) { h4 b = *reinterpret_cast<const h4*>(p.bias + n); for (int e = 0; e < 4; ++e) bq[i][e] = (float)b[e]; }
+        if constexpr (LNF) cq[i] = *reinterpret_cast<const f4*>(p.ln_colsum + n);
+      }
+    }
+    // ---- K loop: tile t in slot t & 1; the wait + barrier at the top make tile t visible and slot (t + 1) & 1 free
+    for (int t = 0; t < nt; ++t) {
+      wait_vm<0>();
+      barrier();
+      if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+      const char* sb = smem + (t & 1) * STAGE;
+      h8 wf[2][NI], xf[2][MJ];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) xf[f][j] = *reinterpret_cast<const h8*>(sb + ((xo + j * 2048) ^ (f * 64)));
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wf[f][i] = *reinterpret_cast<const h8*>(sb + ((wo_ + i * 2048) ^ (f * 64)));
+      }
+      wait_lds_reads();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (LNF) {
+        typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+        const hh2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int j = 0; j < MJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              hh2 v = {xf[f][j][2 * e], xf[f][j][2 * e + 1]};
+              ls[j] = __builtin_amdgcn_fdot2(v, one2, ls[j], false);
+              lq[j] = __builtin_amdgcn_fdot2(v, v, lq[j], false);
+            }
+      }
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[f][i], xf[f][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    barrier();                                             // every wave is done with the ring
+    // ---- LayerNorm fold and bias on the accumulators (registers)
+    if constexpr (LNF) {
+      const float invK = 1.0f / (float)K_;
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) {
+        float s_ = ls[j], q_ = lq[j];
+        s_ += __shfl_xor(s_, 16, 64); q_ += __shfl_xor(q_, 16, 64);
+        s_ += __shfl_xor(s_, 32, 64); q_ += __shfl_xor(q_, 32, 64);
+        const float mean = s_ * invK;
+        const float rstd = rsqrtf(fmaxf(q_ * invK - mean * mean, 0.f) + p.ln_eps);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i][j] = rstd * (acc[i][j] - mean * cq[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) acc[i][j] += bq[i];
+    asm volatile("" ::: "memory");
+    // ---- the next tile's rows and its first K tile (slot 0), in flight during the rest of this tile's epilogue
+    const int cm0 = m0, cn0 = n0;
+    const int next = tile + gridDim.x;
+    if (next < ntiles) { setup(next, m0, n0); stage(0, 0); }
+    const bool geglu = p.act == 1;
+    const int No = geglu ? N_ >> 1 : N_;
+    const unsigned pa = lds_off(patch);
+    // two halves of the wave tile (pixel tiles j = 2 h, 2 h + 1: 32 rows) through the private patch: rows of 64 (32 with GEGLU) fp16
+    const int ocols = geglu ? 32 : 64;                     // output columns of the wave tile
+    const int nbc = cn0 + wn * 64;
+    const int ocol0 = geglu ? (nbc >> 1) : nbc;            // packed column -> output column (n >> 5) * 16 + (n & 15) = n / 2 for n a multiple of 32
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * h + jj;
+        const unsigned rowa = pa + (unsigned)(jj * 16 + lr) * 144u;
+        if (geglu) {
+#pragma unroll
+          for (int i = 0; i < NI; i += 2) {
+            h4 o;
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)(acc[i][j][e] * gelu_f(acc[i + 1][j][e]));
+            asm volatile("ds_write_b64 %0, %1" ::"v"(rowa + (unsigned)((i >> 1) * 32 + lg * 8)), "v"(o) : "memory");
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            h4 o;
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)acc[i][j][e];
+            asm volatile("ds_write_b64 %0, %1" ::"v"(rowa + (unsigned)(i * 32 + lg * 8)), "v"(o) : "memory");
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // read back as rows: 32 rows x (ocols / 8) 16-byte chunks
+      const int cpr = ocols >> 3;                          // 8 or 4 chunks per row
+      for (int idx = lane; idx < 32 * cpr; idx += 64) {
+        const int row = idx / cpr, c8 = idx - row * cpr;
+        const int m = cm0 + wm * 64 + h * 32 + row, no = ocol0 + c8 * 8;
+        h8 v;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pa + (unsigned)row * 144u + (unsigned)c8 * 16u) : "memory");
+        if (m < M_ && no < No) {
+          const long long o = (long long)m * No + no;
+          if (p.residual) { h8 r = *reinterpret_cast<const h8*>(p.residual + o); for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)r[e]); }
+          *reinterpret_cast<h8*>(p.y + o) = v;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
 // split-K reduce + epilogue: y[m,n] = sum_z partial[z,m,n] + bias + bias_nc + residual   (N % 4 == 0 fast path)
 __global__ void __launch_bounds__(256) k_splitk_reduce(half_t* __restrict__ y, const float* __restrict__ partial, const half_t* __restrict__ bias,
                                                        const half_t* __restrict__ bias_nc, const half_t* __restrict__ residual, int M, int N,
@@ -2603,6 +2812,34 @@ static int launch_pp(const GemmP& p, hipStream_t st) {
 }
 // rows of a tile as the GroupNorm-statistics code sees them: the ping-pong kernel's epilogue works in 128-row sub-blocks
 static int stats_bm(int bm, int variant) { return variant == 4 ? bm / 2 : bm; }
+// k_gemm_c4 (variant 5): the persistent short-K kernel -- linears / 1x1 stride-1 convolutions of fp16 operands whose channel counts sit on
+// the 64 grid, one launch (no split-K), no statistics, no time-embedding bias; bias, residual, GEGLU and the LayerNorm fold ride along
+static bool c4_ok(const GemmP& p) {
+  if (p.fp8 || p.bf16 || p.gi_part || p.gn_part || p.bias_nc || p.out32 || p.out8 || p.on_z) return false;
+  if (p.S != 1 || p.stride != 1 || p.pad != 0 || p.ups || p.C3 || p.C4 || p.K != p.Kc) return false;
+  if ((p.C1 % 64) || (p.C2 % 64) || (p.N % 8) || p.M < 1) return false;
+  return p.act == 0 || (p.act == 1 && p.N % 64 == 0);
+}
+static int c4_num_cus() {
+  static int n = 0;
+  if (!n) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256; }
+  return n;
+}
+static int launch_c4(const GemmP& p, hipStream_t st) {
+  constexpr int smem = 2 * (128 + 128) * 128;             // the two-slot ring; the epilogue's patches live in slot 1
+  static bool attr_set = false;
+  if (!attr_set) {
+    TF_HIP(hipFuncSetAttribute((const void*)k_gemm_c4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    TF_HIP(hipFuncSetAttribute((const void*)k_gemm_c4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  const int tiles = p.ntm * p.ntn;
+  const int grid = tiles < 2 * c4_num_cus() ? tiles : 2 * c4_num_cus();   // two resident blocks per CU walk the tile list
+  if (p.ln_colsum) hipLaunchKernelGGL(k_gemm_c4<true>, dim3(grid), dim3(256), smem, st, p);
+  else hipLaunchKernelGGL(k_gemm_c4<false>, dim3(grid), dim3(256), smem, st, p);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
 // (a 256x128 tile spills: the compiler keeps two copies of the accumulator set to issue the two k halves independently)
 static const int kTiles8[][2] = {{128, 128}, {64, 128}, {128, 64}, {256, 64}, {64, 64}};
 static const int kNumTiles8 = 5;
@@ -2690,6 +2927,10 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
     if (!pp_ok(p, c.bn, c.bm)) { tf_set_error("run_gemm: the ping-pong kernel cannot run tile %dx%d of this launch", c.bm, c.bn); return TF_E_UNSUPPORTED; }
     if (c.bm == 192) rc = c.bn == 128 ? launch_pp<128, 192>(p, st) : launch_pp<160, 192>(p, st);
     else rc = c.bn == 128 ? launch_pp<128>(p, st) : c.bn == 160 ? launch_pp<160>(p, st) : launch_pp<256>(p, st);
+  }
+  else if (variant == 5) {
+    if (!c4_ok(p) || c.bm != 128 || c.bn != 128 || p.splitk != 1) { tf_set_error("run_gemm: the persistent short-K kernel cannot run this launch (tile %dx%d, split %d)", c.bm, c.bn, p.splitk); return TF_E_UNSUPPORTED; }
+    rc = launch_c4(p, st);
   }
   else if (variant == 2 && patch_setup(p, c.bm, c.bn)) {
     if (c.bm == 128 && c.bn == 160) rc = launch_patch<128, 160>(p, st);
@@ -2855,6 +3096,26 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
       }
     }
   }
+  // the persistent short-K kernel (variant 5): worth a try once the 128 x 128 tiles outnumber the CUs
+  if (c4_ok(p) && (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) > 256) {
+    TileCfg c = {128, 128, 1};
+    for (int order = 0; order < 2; ++order) {
+      int rc = launch_one(p, c, 5, order, workspace, st);   // warm-up
+      if (rc) return rc;
+      float tv[5];
+      for (int r = 0; r < 5; ++r) {
+        TF_HIP(hipMemsetAsync(g_flush, r, TF_FLUSH_BYTES, st));
+        TF_HIP(hipEventRecord(a, st));
+        rc = launch_one(p, c, 5, order, workspace, st);
+        if (rc) return rc;
+        TF_HIP(hipEventRecord(b, st));
+        TF_HIP(hipEventSynchronize(b));
+        TF_HIP(hipEventElapsedTime(&tv[r], a, b));
+      }
+      for (int i = 0; i < 5; ++i) for (int j = i + 1; j < 5; ++j) if (tv[j] < tv[i]) { float t = tv[i]; tv[i] = tv[j]; tv[j] = t; }
+      if (tv[2] < best) { best = tv[2]; bc = {c, 5, order}; }
+    }
+  }
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
   *out = bc;
   return TF_OK;
@@ -2920,6 +3181,13 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     wide = 0;
     if (t.c.bm >= 192) t.c = choose_tiles(p.M, p.N, p.K, p.act, workspace != nullptr);
   }
+  if (wide == 5) {
+    GemmP q = p;
+    if (!gn_chunks) q.gn_part = nullptr;                  // (statistics the caller did not ask to hear about are never requested)
+    if (c4_ok(q) && (!force_bm || (t.c.bm == 128 && t.c.bn == 128 && t.c.splitk == 1))) t.c = {128, 128, 1};
+    else if (g_force_wide == 5) { tf_set_error("run_gemm: the persistent short-K kernel cannot run this launch"); return TF_E_UNSUPPORTED; }
+    else wide = 0;
+  }
   ProfRec rec;
   if (g_prof) {
     TF_HIP(hipEventCreate(&rec.a)); TF_HIP(hipEventCreate(&rec.b)); TF_HIP(hipEventCreate(&rec.c));
@@ -2970,7 +3238,7 @@ extern "C" {
 int tf_gemm_debug(int flags) {
   g_dbg = (flags & 7) | ((flags & 4096) ? 8 : 0);         // 4096: no fragment reads (k_igemm_pp ablation build only)
   g_pp_np = (flags & 8192) ? 2 : 0;                       // 8192: k_igemm_pp with one phase per k-step even where the 3-slot ring allows one per K tile
-  g_force_wide = (flags & 512) ? 4 : (flags & 256) ? 3 : (flags & 128) ? 2 : (flags & 16) ? 1 : (flags & 8) ? 0 : -1;   // 128 / 256 / 512: the PATCH / ALL8 / ping-pong variants where eligible
+  g_force_wide = (flags & 1024) ? 5 : (flags & 512) ? 4 : (flags & 256) ? 3 : (flags & 128) ? 2 : (flags & 16) ? 1 : (flags & 8) ? 0 : -1;   // 128 / 256 / 512 / 1024: the PATCH / ALL8 / ping-pong / persistent short-K variants where eligible
   g_force_order = (flags & 64) ? 1 : (flags & 32) ? 0 : -1;
   return TF_OK;
 }
@@ -3007,7 +3275,8 @@ int tf_gemm_tune_load(const char* path) {
     const int act = k[8], ln = k[9] & 8;
     if (act == 1 && (bn % 64) != 0) ok = false;
     if ((act == 1 || ln || (k[9] & 256)) && sk > 1) ok = false;
-    if (ok) g_tuned[k] = {{bm, bn, sk}, wide < 0 || wide > 4 ? 0 : wide, order != 0 ? 1 : 0};
+    if (wide == 5) ok = bm == 128 && bn == 128 && sk == 1 && !f8;
+    if (ok) g_tuned[k] = {{bm, bn, sk}, wide < 0 || wide > 5 ? 0 : wide, order != 0 ? 1 : 0};
   }
   fclose(f);
   return TF_OK;
