@@ -2107,6 +2107,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
   const unsigned lds0 = lds_off(smem);
   const int ntm = p.ntm, ntn = p.ntn, ntiles = ntm * ntn;
   const int nt = p.ktiles;
+  const int gstep = gridDim.x;
   const int C1_ = p.C1, K_ = p.K, M_ = p.M, N_ = p.N;
   const i4v rs_x1 = raw_rsrc(p.x, p.x_bytes), rs_x2 = raw_rsrc(p.x2 ? p.x2 : p.x, p.x2_bytes), rs_w = raw_rsrc(p.w, p.w_bytes);
   const int C2_ = p.C2;
@@ -2151,7 +2152,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
   int m0, n0;
   setup(tile, m0, n0);
   stage(0, 0);
-  for (; tile < ntiles; tile += gridDim.x) {
+  int pend = 0;                                           // stores issued behind the prefetch of this tile's K tile 0 (0: unknown -> full wait)
+  for (; tile < ntiles; tile += gstep) {
     f4 acc[NI][MJ];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -2163,19 +2165,27 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
     // bias (and LayerNorm column sums) of this lane's columns: requested now, consumed behind the K loop -- and BEFORE the next tile's
     // prefetch is issued: the compiler counts only its own loads, so a wait for them placed behind the asm LDS-DMA would wait for the DMA too
     const int nb = n0 + wn * 64;                           // first (packed) column of the wave tile
-    f4 bq[NI], cq[NI];
+    h4 braw[NI];                                           // (kept as loaded: a conversion here would put the compiler's vmcnt(0) here)
+    f4 cq[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      bq[i] = (f4){0.f, 0.f, 0.f, 0.f}; cq[i] = (f4){0.f, 0.f, 0.f, 0.f};
-      const int n = nb + i * 16 + lg * 4;
-      if (n + 3 < N_) {
-        if (p.bias) { h4 b = *reinterpret_cast<const h4*>(p.bias + n); for (int e = 0; e < 4; ++e) bq[i][e] = (float)b[e]; }
-        if constexpr (LNF) cq[i] = *reinterpret_cast<const f4*>(p.ln_colsum + n);
-      }
+      braw[i] = (h4){(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f}; cq[i] = (f4){0.f, 0.f, 0.f, 0.f};
+      int n = nb + i * 16 + lg * 4;
+      n = n + 3 < N_ ? n : 0;                              // columns beyond N are never stored: any readable address will do (no masked load)
+      if (p.bias) braw[i] = *reinterpret_cast<const h4*>(p.bias + n);
+      if constexpr (LNF) cq[i] = *reinterpret_cast<const f4*>(p.ln_colsum + n);
     }
+    const int young = pend > 0 ? pend + (p.bias ? NI : 0) + (LNF ? NI : 0) : 0;
     // ---- K loop: tile t in slot t & 1; the wait + barrier at the top make tile t visible and slot (t + 1) & 1 free
     for (int t = 0; t < nt; ++t) {
-      wait_vm<0>();
+      // K tile t has landed.  For t = 0 it was issued in front of the previous tile's epilogue: where that epilogue's vector-memory
+      // instructions are known to be `pend` stores, followed by this tile's bias / column-sum loads and nothing else, those `young`
+      // ones stay in flight (the counter retires in issue order)
+      if (t == 0 && young == 4) wait_vm<4>();
+      else if (t == 0 && young == 8) wait_vm<8>();
+      else if (t == 0 && young == 12) wait_vm<12>();
+      else if (t == 0 && young == 16) wait_vm<16>();
+      else wait_vm<0>();
       barrier();
       if (t + 1 < nt) stage((t + 1) & 1, t + 1);
       const char* sb = smem + (t & 1) * STAGE;
@@ -2213,6 +2223,11 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
     }
     barrier();                                             // every wave is done with the ring
     // ---- LayerNorm fold and bias on the accumulators (registers)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      asm volatile("" : "+v"(braw[i]));                    // (the values are used from here on: nothing of this moves in front of the K loop)
+      if constexpr (LNF) asm volatile("" : "+v"(cq[i]));
+    }
     if constexpr (LNF) {
       const float invK = 1.0f / (float)K_;
 #pragma unroll
@@ -2229,14 +2244,16 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < MJ; ++j) acc[i][j] += bq[i];
+      for (int j = 0; j < MJ; ++j) acc[i][j] += (f4){(float)braw[i][0], (float)braw[i][1], (float)braw[i][2], (float)braw[i][3]};
     asm volatile("" ::: "memory");
     // ---- the next tile's rows and its first K tile (slot 0), in flight during the rest of this tile's epilogue
     const int cm0 = m0, cn0 = n0;
-    const int next = tile + gridDim.x;
+    const int next = tile + gstep;
     if (next < ntiles) { setup(next, m0, n0); stage(0, 0); }
     const bool geglu = p.act == 1;
     const int No = geglu ? N_ >> 1 : N_;
+    // an interior tile without a residual stores 2 halves x 32 rows x cpr chunks / 64 lanes = 8 (GEGLU: 4) times per wave, every lane active
+    pend = (cm0 + BM <= M_ && cn0 + BN <= N_ && !p.residual) ? (geglu ? 4 : 8) : 0;
     const unsigned pa = lds_off(patch);
     // two halves of the wave tile (pixel tiles j = 2 h, 2 h + 1: 32 rows) through the private patch: rows of 64 (32 with GEGLU) fp16
     const int ocols = geglu ? 32 : 64;                     // output columns of the wave tile
