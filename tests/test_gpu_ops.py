@@ -284,6 +284,7 @@ SDPA_CASES = [  # b, nh, tq, tk, hs
     (1, 2, 200, 200, 40), (1, 2, 130, 130, 80), (1, 1, 192, 192, 64), (1, 1, 256, 256, 128), (1, 1, 129, 65, 160), (1, 1, 1, 1, 40),
     (1, 2, 250, 250, 56), (1, 1, 64, 300, 48),
     (35, 12, 1024, 1024, 64),        # the dims of the reference's own tests/sdpa.py:13-20
+    (4, 8, 1000, 1000, 40), (2, 8, 2048, 200, 40), (2, 16, 1030, 64, 40),      # d = 40 with >= 256 query blocks (32-query waves), ragged Tq / Tk
 ]
 
 
@@ -330,6 +331,23 @@ def test_sdpa_first_tile_far_below_zero(tf, hs):
     ref = O.scaled_dot_product_attention(q, k, v).numpy()
     assert np.isfinite(got).all()
     close(got, ref)
+
+
+def test_sdpa_rescale_and_far_below_zero_at_256_query_blocks(tf):
+    """The two online-softmax corner cases above at a size that runs the 32-queries-per-wave kernel (d = 40, 256 query blocks): a score
+    spike late in the key sequence (rescale branch, the -m_run accumulator initialiser) and a first tile far below the later ones."""
+    from oracle import ops as O
+    from tinyfusers_amd.attention.sdpa import scaled_dot_product_attention
+    b, nh, t, hs = 8, 8, 512, 40
+    q, k, v = rnd("xr.q", (b, nh, t, hs), 0.7), rnd("xr.k", (b, nh, t, hs), 0.7), rnd("xr.v", (b, nh, t, hs))
+    k[0, 0, 300] = q[0, 0, 17] * 8.0           # query 17 . key 300 spikes in the 5th tile
+    k[3, 5, 70] = q[3, 5, 133] * 6.0
+    k[5, :, :64] -= 4.0 * np.sign(q[5].mean(axis=1, keepdims=True)) * np.abs(q[5]).mean()
+    q[5] = q[5] + 2.0 * np.sign(q[5].mean(axis=1, keepdims=True))
+    q, k = q.astype(np.float16).astype(np.float32), k.astype(np.float16).astype(np.float32)
+    got = scaled_dot_product_attention(dev(tf, q, "row"), dev(tf, k, "row"), dev(tf, v, "row")).numpy()
+    assert np.isfinite(got).all()
+    close(got, O.scaled_dot_product_attention(q, k, v).numpy())
 
 
 def test_softmax_rows_and_own_runtime_kernels(tf):

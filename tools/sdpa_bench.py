@@ -9,7 +9,8 @@ from tools.gemm_bench import time_call, st
 
 SHAPES = [("self 64^2 d40", 2, 8, 4096, 4096, 40), ("self 32^2 d80", 2, 8, 1024, 1024, 80), ("self 16^2 d160", 2, 8, 256, 256, 160),
           ("self 8^2 d160", 2, 8, 64, 64, 160), ("cross 64^2 d40", 2, 8, 4096, 77, 40), ("cross 32^2 d80", 2, 8, 1024, 77, 80),
-          ("cross 16^2 d160", 2, 8, 256, 77, 160), ("vae 64^2 d512", 1, 1, 4096, 4096, 512)]
+          ("cross 16^2 d160", 2, 8, 256, 77, 160), ("vae 64^2 d512", 1, 1, 4096, 4096, 512),
+          ("c5 self 96^2 d40", 8, 8, 9216, 9216, 40), ("c5 cross 96^2 d40", 8, 8, 9216, 77, 40), ("c5 self 48^2 d80", 8, 8, 2304, 2304, 80)]
 
 
 def main():
