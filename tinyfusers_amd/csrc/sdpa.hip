@@ -24,6 +24,7 @@ struct SdpaP {
   long long q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st;
   float scale_log2e;
   int causal;
+  int dbg;              // ablation build only (TF_SDPA_DBG, tools/sdpa_dbg.py): 1 no exp, 2 no P.V MFMAs, 4 no Q.K MFMAs, 8 no barrier, 16 no DMA in the loop, 32 no V reads, 64 no max
 };
 
 // max over the four 16-lane groups of the wave (lanes l, l^16, l^32, l^48), result in every lane: gfx950's v_permlane16_swap /
@@ -311,6 +312,9 @@ constexpr int sdpa_k_pitch(int ck) { return ck + (2 - ck % 4 + 4) % 4; }
 constexpr int sdpa_v_pitch(int ck) { return ck <= 6 ? 6 : ck <= 10 ? 10 : ck <= 18 ? 18 : ck <= 20 ? 20 : 22; }
 constexpr int sdpa_v_skew(int ck) { return ck <= 18 ? 8 : ck <= 20 ? 2 : 8; }
 
+// ring depth: SdpaDma<HS>::S (<= 4) for both block sizes.  Six stages for the 8-wave form (two blocks per CU leave 80 KiB each) were slower:
+// 64 x 64 d40 81.8 -> 86.9 us, 96 x 96 (B 8) 1116 -> 1162 us -- the tile fetch is not latency-starved at depth 4, and the prologue zero-fills the ring
+constexpr int sdpa_ring(int stage_b, int nw, int s4) { return s4; }
 template <int HS>
 struct SdpaDma {
   static constexpr int DQK = (HS + 31) / 32 * 32, NKS = DQK / 32, NDT = (HS + 15) / 16, CK = HS / 8;
@@ -327,12 +331,15 @@ struct SdpaDma {
   static_assert(S >= 2, "ring needs two stages");
 };
 
-template <int HS, int QT>
-__global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
-  constexpr int QW = 16 * QT, QB = 4 * QW;          // queries per wave / per block
+// NW = waves per block (4, or 8 for long sequences: twice the queries per fetched K/V tile -- the tile fetch, not the barrier, is what the
+// ablation prices at 19 % of the d = 40 loop at 9216 tokens -- and four waves per SIMD instead of three at two blocks per CU)
+template <int HS, int QT, int DBG = 0, int NW = 4>        // DBG: compile-time ablation mask (tools/sdpa_dbg.py; bits as SdpaP::dbg)
+__global__ void __launch_bounds__(NW * 64) k_sdpa_dma(const SdpaP p) {
+  constexpr int QW = 16 * QT, QB = NW * QW, NT = NW * 64;   // queries per wave / per block, threads
   using C = SdpaDma<HS>;
   constexpr int NKS = C::NKS, NDT = C::NDT, CK = C::CK, KPC = C::KPC, VPC = C::VPC, KP = C::KP, VP = C::VP, VSK = C::VSK, VGC = C::VGC;
-  constexpr int S = C::S, NI = C::NI, LPW = C::LPW, STAGE_B = C::STAGE_B;
+  constexpr int STAGE_B = C::STAGE_B, NI = C::NI, LPW = (C::NI + NW - 1) / NW;
+  constexpr int S = sdpa_ring(STAGE_B, NW, C::S);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -345,11 +352,11 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
   const half_t* vb = p.v + b * p.v_sb + h * p.v_sh;
 
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
-  for (int i = tid; i < S * STAGE_B / 16; i += 256) reinterpret_cast<u4*>(smem_raw)[i] = (u4){0, 0, 0, 0};
+  for (int i = tid; i < S * STAGE_B / 16; i += NT) reinterpret_cast<u4*>(smem_raw)[i] = (u4){0, 0, 0, 0};
   constexpr bool HAS_PAD = C::HAS_PAD;
   if constexpr (HAS_PAD) {
     __syncthreads();                     // ones column of V (column HS of every key row, every ring stage): written once
-    for (int i = tid; i < S * 64; i += 256) {
+    for (int i = tid; i < S * 64; i += NT) {
       int st_ = i >> 6, R = i & 63;
       reinterpret_cast<half_t*>(smem_raw + st_ * STAGE_B + C::K_BYTES)[(R >> 3) * VGC * 8 + (R & 7) * VP + HS] = (half_t)1.0f;
     }
@@ -383,7 +390,7 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
   const unsigned k_adv = 64u * (unsigned)p.k_st * 2u, v_adv = 64u * (unsigned)p.v_st * 2u;
 #pragma unroll
   for (int i = 0; i < LPW; ++i) {
-    int j = min(wid + 4 * i, NI - 1);
+    int j = min(wid + NW * i, NI - 1);
     if (j < KPC) {
       int x = 64 * j + lane, r = x / KPC, cc = x - r * KPC;
       int kt = r >> 4, rr = r & 15;
@@ -402,7 +409,7 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
     const unsigned base = lds0 + (unsigned)(tt % S) * STAGE_B;
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
-      int j = min(wid + 4 * i, NI - 1);
+      int j = min(wid + NW * i, NI - 1);
       if (j < KPC) sdpa_dma16(rs_k, voff[i] + (unsigned)tt * k_adv, base + j * 1024);
       else if (!HAS_PAD) sdpa_dma16(rs_v, voff[i] + (unsigned)tt * v_adv, base + j * 1024);
       else if (voff[i] != 0xFFFFFFFFu) sdpa_dma16(rs_v, voff[i] + (unsigned)tt * v_adv, base + j * 1024);   // (EXEC-masked: the skipped lanes write nothing)
@@ -427,12 +434,14 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
     // and tells that all of them are done reading tile t-1, whose slot the next issue refills
     {
       int younger = min(S - 2, ntiles - 1 - t);
-      if (younger >= 2 && S >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW > 63 ? 63 : 2 * LPW) : "memory");
+      if (younger >= 4 && S >= 6 && 4 * LPW <= 63) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPW > 63 ? 63 : 4 * LPW) : "memory");
+      else if (younger >= 3 && S >= 5 && 3 * LPW <= 63) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPW > 63 ? 63 : 3 * LPW) : "memory");
+      else if (younger >= 2 && S >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW > 63 ? 63 : 2 * LPW) : "memory");
       else if (younger >= 1 && S >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW > 63 ? 63 : LPW) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();
-    if (t + S - 1 < ntiles) issue(t + S - 1);
+    if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
+    if (t + S - 1 < ntiles && !(DBG & 16)) issue(t + S - 1);
 
     const half_t* ks_ = reinterpret_cast<const half_t*>(smem_raw + (t % S) * STAGE_B);
     const half_t* vs_ = ks_ + C::K_BYTES / 2;
@@ -447,7 +456,10 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
       for (int ks = 0; ks < NKS; ++ks) {
         h8 kf = *reinterpret_cast<const h8*>(ks_ + (16 * kt + lr) * KP + ks * 32 + lg * 8);
 #pragma unroll
-        for (int q_ = 0; q_ < QT; ++q_) st[kt][q_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[q_][ks], ks == 0 ? init4[q_] : st[kt][q_], 0, 0, 0);
+        for (int q_ = 0; q_ < QT; ++q_) {
+          if (DBG & 4) { if (ks == 0) st[kt][q_] = init4[q_] + (f4){(float)kf[0], (float)kf[1], (float)kf[2], (float)kf[3]}; }
+          else st[kt][q_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[q_][ks], ks == 0 ? init4[q_] : st[kt][q_], 0, 0, 0);
+        }
       }
     }
     const int kbase = t * 64 + 8 * lg;
@@ -468,6 +480,7 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
     float mx[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
+      if (DBG & 64) { mx[qt] = st[0][qt][0]; continue; }
       float m0_ = fmaxf(fmaxf(st[0][qt][0], st[0][qt][1]), fmaxf(st[0][qt][2], st[0][qt][3]));
 #pragma unroll
       for (int kt = 1; kt < 4; ++kt) {
@@ -503,7 +516,7 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pf[kt >> 1][qt][(kt & 1) * 4 + e] = (half_t)__builtin_amdgcn_exp2f(st[kt][qt][e]);
+        for (int e = 0; e < 4; ++e) pf[kt >> 1][qt][(kt & 1) * 4 + e] = (DBG & 1) ? (half_t)st[kt][qt][e] : (half_t)__builtin_amdgcn_exp2f(st[kt][qt][e]);
     if constexpr (!HAS_PAD) {
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc) {
@@ -516,11 +529,14 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc) {
         const half_t* va = vs_ + (32 * kc + 8 * lg + (lr >> 2)) * VP + (4 * kc + lg) * VSK + dt * 16 + 4 * (lr & 3);
-        s4v v0 = lds_tr16(va), v1 = lds_tr16(va + 4 * VP);
         union { struct { s4v a, b; } s; h8 h; } u;
-        u.s.a = v0; u.s.b = v1;
+        if (DBG & 32) u.h = pf[kc][0];
+        else { u.s.a = lds_tr16(va); u.s.b = lds_tr16(va + 4 * VP); }
 #pragma unroll
-        for (int q_ = 0; q_ < QT; ++q_) ot[dt][q_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.h, pf[kc][q_], ot[dt][q_], 0, 0, 0);
+        for (int q_ = 0; q_ < QT; ++q_) {
+          if (DBG & 2) ot[dt][q_] += (f4){(float)u.h[0] * (float)pf[kc][q_][0], (float)u.h[1], (float)u.h[2], (float)pf[kc][q_][7]};
+          else ot[dt][q_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.h, pf[kc][q_], ot[dt][q_], 0, 0, 0);
+        }
       }
     }
   }
@@ -548,16 +564,30 @@ __global__ void __launch_bounds__(256) k_sdpa_dma(const SdpaP p) {
   }
 }
 
-template <int HS, int QT>
+template <int HS, int QT, int NW = 4>
 static int launch_sdpa_dma(const SdpaP& p, hipStream_t st) {
-  constexpr int smem = SdpaDma<HS>::S * SdpaDma<HS>::STAGE_B;
-  constexpr int QB = 64 * QT;
+  constexpr int smem = sdpa_ring(SdpaDma<HS>::STAGE_B, NW, SdpaDma<HS>::S) * SdpaDma<HS>::STAGE_B;
+  constexpr int QB = 16 * NW * QT;
   static bool attr_set = false;
   if (!attr_set) {
-    TF_HIP(hipFuncSetAttribute((const void*)k_sdpa_dma<HS, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    TF_HIP(hipFuncSetAttribute((const void*)k_sdpa_dma<HS, QT, 0, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_sdpa_dma<HS, QT>), dim3((unsigned)((p.Tq + QB - 1) / QB * p.NH * p.B)), dim3(256), smem, st, p);
+  if constexpr (HS == 40 && QT == 2 && NW == 4) {                   // ablation builds (tools/sdpa_dbg.py): wrong results by design
+    if (p.dbg) {
+      const dim3 grid((unsigned)((p.Tq + QB - 1) / QB * p.NH * p.B));
+      switch (p.dbg) {
+#define TF_SDPA_DBG_CASE(M) case M: hipLaunchKernelGGL((k_sdpa_dma<HS, QT, M>), grid, dim3(256), smem, st, p); break;
+        TF_SDPA_DBG_CASE(1) TF_SDPA_DBG_CASE(64) TF_SDPA_DBG_CASE(65) TF_SDPA_DBG_CASE(2) TF_SDPA_DBG_CASE(4) TF_SDPA_DBG_CASE(6) TF_SDPA_DBG_CASE(32)
+        TF_SDPA_DBG_CASE(34) TF_SDPA_DBG_CASE(8) TF_SDPA_DBG_CASE(16) TF_SDPA_DBG_CASE(24) TF_SDPA_DBG_CASE(62) TF_SDPA_DBG_CASE(89) TF_SDPA_DBG_CASE(128)
+#undef TF_SDPA_DBG_CASE
+        default: tf_set_error("tf_sdpa_f16: no ablation build for TF_SDPA_DBG=%d", p.dbg); return TF_E_UNSUPPORTED;
+      }
+      TF_LAUNCH_CHECK();
+      return TF_OK;
+    }
+  }
+  hipLaunchKernelGGL((k_sdpa_dma<HS, QT, 0, NW>), dim3((unsigned)((p.Tq + QB - 1) / QB * p.NH * p.B)), dim3(NW * 64), smem, st, p);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
@@ -576,6 +606,8 @@ static int launch_sdpa(const SdpaP& p, hipStream_t st) {
 }
 
 static bool g_sdpa_generic = getenv("TF_SDPA_GENERIC") != nullptr;
+static int g_sdpa_dbg = getenv("TF_SDPA_DBG") ? atoi(getenv("TF_SDPA_DBG")) : 0;   // ablation of k_sdpa_dma<40, 2> (see SdpaP::dbg)
+static int g_sdpa_nw = getenv("TF_SDPA_NW") ? atoi(getenv("TF_SDPA_NW")) : 0;      // A/B: 4 / 8 waves per block where both exist (0 = per-shape choice)
 static int g_sdpa_qt = getenv("TF_SDPA_QT") ? atoi(getenv("TF_SDPA_QT")) : 0;   // debugging: force the register-staged kernel
 
 extern "C" int tf_sdpa_f16(void* o, const void* q, const void* k, const void* v, int B, int NH, int Tq, int Tk, int HS, long long q_sb,
@@ -596,6 +628,7 @@ extern "C" int tf_sdpa_f16(void* o, const void* q, const void* k, const void* v,
   p.v_sb = v_sb; p.v_sh = v_sh; p.v_st = v_st; p.o_sb = o_sb; p.o_sh = o_sh; p.o_st = o_st;
   p.scale_log2e = (1.0f / sqrtf((float)HS)) * 1.4426950408889634f;
   p.causal = causal;
+  p.dbg = g_sdpa_dbg;
   hipStream_t st = tf_hs(s);
   // K/V offsets inside a (batch, head) slice must fit the 32-bit buffer offsets of the DMA kernels
   const bool small = ((long long)Tk * k_st + HS) * 2 < (1ll << 31) && ((long long)Tk * v_st + HS) * 2 < (1ll << 31);
@@ -612,6 +645,12 @@ extern "C" int tf_sdpa_f16(void* o, const void* q, const void* k, const void* v,
       if (HS == 128) return launch_sdpa_dma<128, 1>(p, st);
       if (HS == 160) return launch_sdpa_dma<160, 1>(p, st);
     }
+    // eight waves per block (256 queries per K/V tile fetch) once that still gives every CU a block (measured: 64 x 64 d40, B 2: 86.9 -> 81.0 us
+    // with ONE eight-wave block per CU; 96 x 96, B 8: 1214 -> 1103 us)
+    const long long blocks8 = (long long)((Tq + 255) / 256) * NH * B;
+    const bool wide8 = g_sdpa_nw ? g_sdpa_nw == 8 : blocks8 >= 256;
+    if (HS == 40 && wide8) return launch_sdpa_dma<40, 2, 8>(p, st);
+    if (HS == 80 && wide8) return launch_sdpa_dma<80, 2, 8>(p, st);
     if (HS == 40) return launch_sdpa_dma<40, 2>(p, st);
     if (HS == 64) return launch_sdpa_dma<64, 2>(p, st);
     if (HS == 80) return launch_sdpa_dma<80, 2>(p, st);
