@@ -69,6 +69,7 @@ struct GemmP {
   // tf_linear_f32out_f16: the raw fp32 accumulators go to out32[m, n] (no bias / residual / activation, never split along K) -- the
   // q k^T scores of the unfused attention path, which must not be rounded to fp16 before the softmax; NULL = off
   float* out32;
+  int c4_chunk;         // k_gemm_c4: consecutive tiles a block takes before it strides on by gridDim chunks (launch_c4)
 };
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;   // 128-bit buffer resource
@@ -2114,6 +2115,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
   const int fo = lr * 128 + ((lg ^ ((lr >> 1) & 7)) << 4);
   const int xo = wm * 64 * 128 + fo, wo_ = (BM + wn * 64) * 128 + fo;
   char* const patch = smem + STAGE + wid * PATCH;         // inside ring slot 1 (the next tile's first K tile lands in slot 0)
+  f2* const stats = reinterpret_cast<f2*>(smem + 2 * STAGE);   // [4 waves][64 rows] halves of the LayerNorm row sums (behind the ring)
 
   // this wave's staging rows of a tile: activation pieces wid + 4 i (i < 4: rows 8 (wid + 4 i) + sub), weight pieces likewise
   int am[4];
@@ -2147,13 +2149,29 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
     asm volatile("" ::: "memory");
   };
 
-  int tile = blockIdx.x;
+  // this block's tiles: chunks of `chunk` consecutive tiles of the list, the chunks strided by the grid.  Consecutive tiles (n-fastest order)
+  // share their 128 rows -- L1 / L2 lines, and with the LayerNorm fold the row statistics, computed for the first tile of a run only --
+  // while the blocks running at the same time stay next to each other in the list (whole runs per block, each block on rows of its own, cost
+  // the wide-N shapes 5-15 %)
+  const int chunk = p.c4_chunk;
+  int cq_ = blockIdx.x, ce_ = 0;                          // chunk index, tile inside the chunk
+  int tile = cq_ * chunk;
   if (tile >= ntiles) return;
+  auto next_tile = [&](int& q, int& e) {                  // -> tile index or -1
+    if (e + 1 < chunk && q * chunk + e + 1 < ntiles) { ++e; return q * chunk + e; }
+    q += gstep; e = 0;
+    return q * chunk < ntiles ? q * chunk : -1;
+  };
   int m0, n0;
   setup(tile, m0, n0);
   stage(0, 0);
+  float ln_mean[MJ], ln_rstd[MJ];
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) { ln_mean[j] = 0.f; ln_rstd[j] = 0.f; }
+  int stat_m0 = -1;
   int pend = 0;                                           // stores issued behind the prefetch of this tile's K tile 0 (0: unknown -> full wait)
-  for (; tile < ntiles; tile += gstep) {
+  while (tile >= 0) {
+    const bool need_stats = LNF && m0 != stat_m0;
     f4 acc[NI][MJ];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -2199,19 +2217,21 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
       }
       wait_lds_reads();
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (LNF) {
+      if (LNF && need_stats) {
+        // row statistics from the fragments: the two waves that share these 64 rows (wn = 0, 1) take one 32-deep k-step each
         typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
         const hh2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
+        auto acc_stats = [&](const h8 (&x)[MJ]) {
 #pragma unroll
           for (int j = 0; j < MJ; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              hh2 v = {xf[f][j][2 * e], xf[f][j][2 * e + 1]};
+              hh2 v = {x[j][2 * e], x[j][2 * e + 1]};
               ls[j] = __builtin_amdgcn_fdot2(v, one2, ls[j], false);
               lq[j] = __builtin_amdgcn_fdot2(v, v, lq[j], false);
             }
+        };
+        if (wn == 0) acc_stats(xf[0]); else acc_stats(xf[1]);
       }
 #pragma unroll
       for (int f = 0; f < 2; ++f)
@@ -2221,6 +2241,17 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
           for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[f][i], xf[f][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (LNF && need_stats) {                               // this wave's half of the row sums -> LDS, the partner's half comes back behind the barrier
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) {
+        float s_ = ls[j], q_ = lq[j];
+        s_ += __shfl_xor(s_, 16, 64); q_ += __shfl_xor(q_, 16, 64);
+        s_ += __shfl_xor(s_, 32, 64); q_ += __shfl_xor(q_, 32, 64);
+        ls[j] = s_; lq[j] = q_;
+        if (lg == 0) stats[wid * 64 + j * 16 + lr] = (f2){s_, q_};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (a raw s_barrier does not wait for LDS stores)
+    }
     barrier();                                             // every wave is done with the ring
     // ---- LayerNorm fold and bias on the accumulators (registers)
 #pragma unroll
@@ -2229,17 +2260,21 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
       if constexpr (LNF) asm volatile("" : "+v"(cq[i]));
     }
     if constexpr (LNF) {
-      const float invK = 1.0f / (float)K_;
+      if (need_stats) {
+        const float invK = 1.0f / (float)K_;
 #pragma unroll
-      for (int j = 0; j < MJ; ++j) {
-        float s_ = ls[j], q_ = lq[j];
-        s_ += __shfl_xor(s_, 16, 64); q_ += __shfl_xor(q_, 16, 64);
-        s_ += __shfl_xor(s_, 32, 64); q_ += __shfl_xor(q_, 32, 64);
-        const float mean = s_ * invK;
-        const float rstd = rsqrtf(fmaxf(q_ * invK - mean * mean, 0.f) + p.ln_eps);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) acc[i][j] = rstd * (acc[i][j] - mean * cq[i]);
+        for (int j = 0; j < MJ; ++j) {
+          const f2 o_ = stats[(wid ^ 2) * 64 + j * 16 + lr];
+          const float s_ = ls[j] + o_[0], q_ = lq[j] + o_[1];
+          ln_mean[j] = s_ * invK;
+          ln_rstd[j] = rsqrtf(fmaxf(q_ * invK - ln_mean[j] * ln_mean[j], 0.f) + p.ln_eps);
+        }
+        stat_m0 = m0;
       }
+#pragma unroll
+      for (int j = 0; j < MJ; ++j)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i][j] = ln_rstd[j] * (acc[i][j] - ln_mean[j] * cq[i]);
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -2248,8 +2283,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
     asm volatile("" ::: "memory");
     // ---- the next tile's rows and its first K tile (slot 0), in flight during the rest of this tile's epilogue
     const int cm0 = m0, cn0 = n0;
-    const int next = tile + gstep;
-    if (next < ntiles) { setup(next, m0, n0); stage(0, 0); }
+    const int next = next_tile(cq_, ce_);
+    if (next >= 0) { setup(next, m0, n0); stage(0, 0); }
     const bool geglu = p.act == 1;
     const int No = geglu ? N_ >> 1 : N_;
     // an interior tile without a residual stores 2 halves x 32 rows x cpr chunks / 64 lanes = 8 (GEGLU: 4) times per wave, every lane active
@@ -2297,6 +2332,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    tile = next;
   }
 }
 
@@ -2842,8 +2878,9 @@ static int c4_num_cus() {
   if (!n) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256; }
   return n;
 }
+static int g_c4_chunk = getenv("TF_C4_CHUNK") ? atoi(getenv("TF_C4_CHUNK")) : 0;   // A/B: tiles per chunk of k_gemm_c4's walk (0 = per-shape choice)
 static int launch_c4(const GemmP& p, hipStream_t st) {
-  constexpr int smem = 2 * (128 + 128) * 128;             // the two-slot ring; the epilogue's patches live in slot 1
+  constexpr int smem = 2 * (128 + 128) * 128 + 4 * 64 * 8;   // the two-slot ring (the epilogue's patches live in slot 1) + the LayerNorm row-sum exchange
   static bool attr_set = false;
   if (!attr_set) {
     TF_HIP(hipFuncSetAttribute((const void*)k_gemm_c4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -2851,9 +2888,17 @@ static int launch_c4(const GemmP& p, hipStream_t st) {
     attr_set = true;
   }
   const int tiles = p.ntm * p.ntn;
-  const int grid = tiles < 2 * c4_num_cus() ? tiles : 2 * c4_num_cus();   // two resident blocks per CU walk the tile list
-  if (p.ln_colsum) hipLaunchKernelGGL(k_gemm_c4<true>, dim3(grid), dim3(256), smem, st, p);
-  else hipLaunchKernelGGL(k_gemm_c4<false>, dim3(grid), dim3(256), smem, st, p);
+  GemmP q = p;
+  // consecutive tiles per block.  Without the LayerNorm fold: one (chunks of 2-8 were 2-8 % faster on three narrow-N shapes and up to 6x slower
+  // wherever they left fewer chunks than blocks).  With it (n-fastest order): 4 or 2 while every block still gets >= 4 chunks -- the statistics
+  // of a row block are computed once per chunk
+  int chunk = 1;
+  if (p.ln_colsum && p.order == 0) chunk = tiles / 4 >= 8 * c4_num_cus() ? 4 : tiles / 2 >= 8 * c4_num_cus() ? 2 : 1;
+  q.c4_chunk = g_c4_chunk > 0 ? g_c4_chunk : chunk;
+  const int chunks = (tiles + q.c4_chunk - 1) / q.c4_chunk;
+  const int grid = chunks < 2 * c4_num_cus() ? chunks : 2 * c4_num_cus();   // two resident blocks per CU walk the tile list
+  if (p.ln_colsum) hipLaunchKernelGGL(k_gemm_c4<true>, dim3(grid), dim3(256), smem, st, q);
+  else hipLaunchKernelGGL(k_gemm_c4<false>, dim3(grid), dim3(256), smem, st, q);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
