@@ -3345,23 +3345,12 @@ int tf_gemm_tune_load(const char* path) {
 }
 int tf_gemm_force_config(int bm, int bn, int splitk) { g_force_bm = bm; g_force_bn = bn; g_force_split = splitk; return TF_OK; }
 
-static float g_prof_overhead_ms = 0.f;   // what an empty [record a][record b] interval reads on this stream
+// (Rounds 1-2 subtracted the reading of an empty [record a][record b] interval from every bracket.  That over-corrects: the brackets then read
+// ~2 us per launch SHORTER than the kernel durations rocprofv3 lists for the same launches (2.98 vs 3.31 ms per step); uncorrected they
+// agree with it to ~1 %, so the brackets are reported as they are.)
 int tf_prof_enable(int on) {
   g_prof = on != 0;
-  if (on) {
-    g_prof_ms = 0.0; g_prof_ms_full = 0.0; g_prof_flops = 0.0; g_prof_launches = 0; g_prof_pending.clear(); g_prof_shapes.clear();
-    // calibrate the event pair itself (median of 16 empty intervals on the NULL stream) and subtract it per launch
-    hipEvent_t a, b;
-    TF_HIP(hipEventCreate(&a)); TF_HIP(hipEventCreate(&b));
-    float v[16];
-    for (int i = 0; i < 16; ++i) {
-      TF_HIP(hipEventRecord(a, 0)); TF_HIP(hipEventRecord(b, 0)); TF_HIP(hipEventSynchronize(b));
-      TF_HIP(hipEventElapsedTime(&v[i], a, b));
-    }
-    for (int i = 0; i < 16; ++i) for (int j = i + 1; j < 16; ++j) if (v[j] < v[i]) { float t = v[i]; v[i] = v[j]; v[j] = t; }
-    g_prof_overhead_ms = v[8];
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-  }
+  if (on) { g_prof_ms = 0.0; g_prof_ms_full = 0.0; g_prof_flops = 0.0; g_prof_launches = 0; g_prof_pending.clear(); g_prof_shapes.clear(); }
   return TF_OK;
 }
 static int prof_collect() {
@@ -3369,14 +3358,11 @@ static int prof_collect() {
     float t = 0.f, tf = 0.f;
     TF_HIP(hipEventSynchronize(r.has_reduce ? r.c : r.b));
     TF_HIP(hipEventElapsedTime(&t, r.a, r.b));
-    t -= g_prof_overhead_ms;
-    if (t < 0.f) t = 0.f;
     tf = t;
     if (r.has_reduce) {                                    // GEMM bracket + the reduce's own bracket (b .. c): the event in between is not charged twice
       float tr = 0.f;
       TF_HIP(hipEventElapsedTime(&tr, r.b, r.c));
-      tr -= g_prof_overhead_ms;
-      if (tr > 0.f) tf += tr;
+      tf += tr;
     }
     g_prof_ms += t; g_prof_ms_full += tf; g_prof_flops += r.flops; g_prof_launches += 1;
     auto& e = g_prof_shapes[{r.M, r.N, r.K, r.taps, r.bm, r.bn, r.splitk, r.variant}];

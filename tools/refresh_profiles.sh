@@ -41,12 +41,18 @@ for i in 1 2; do
 done
 # BASELINE config 5's per-GPU shape (4 images, 96 x 96 latents), fp16 and fp8: bench line, per-shape GEMM table, rocprofv3 kernel statistics
 for dt in fp16 fp8; do
-  python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --images 4 --latent 96 --dtype $dt > $O/bench_images4_latent96_$dt.json 2>/dev/null
+  python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-e2e --no-config5 --images 4 --latent 96 --dtype $dt > $O/bench_images4_latent96_$dt.json 2>/dev/null
   python3 $R/tools/step_profile.py $O/gemm_shapes_images4_latent96_$dt.csv 4 96 $dt > $O/gemm_shapes_images4_latent96_$dt.txt 2>/dev/null
   rm -rf $O/prof_stats5
-  rocprofv3 --kernel-trace --stats -d $O/prof_stats5 --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --images 4 --latent 96 --dtype $dt > $O/prof_stats5.log 2>&1
-  echo "# csrc $(python3 -c "import sys; sys.path.insert(0, '$R'); from bench import csrc_hash; print(csrc_hash())")  rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --images 4 --latent 96 --dtype $dt   (9 steps executed: 2 in compile() + 2 warm-up + 5 timed)" > $O/kernel_stats_images4_latent96_$dt.txt
+  rocprofv3 --kernel-trace --stats -d $O/prof_stats5 --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-e2e --no-config5 --images 4 --latent 96 --dtype $dt > $O/prof_stats5.log 2>&1
+  echo "# csrc $(python3 -c "import sys; sys.path.insert(0, '$R'); from bench import csrc_hash; print(csrc_hash())")  rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-e2e --no-config5 --images 4 --latent 96 --dtype $dt   (9 steps executed: 2 in compile() + 2 warm-up + 5 timed)" > $O/kernel_stats_images4_latent96_$dt.txt
   python3 $R/tools/prof_summary.py $O/prof_stats5 9 >> $O/kernel_stats_images4_latent96_$dt.txt
   rm -rf $O/prof_stats5
+  # HBM traffic of the same shape: FETCH_SIZE and WRITE_SIZE in separate passes, 6 steps each (2 in compile() + 1 warm-up + 3 timed)
+  rm -rf $O/prof_fetch5 $O/prof_write5
+  rocprofv3 --pmc FETCH_SIZE -d $O/prof_fetch5 --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-e2e --no-config5 --images 4 --latent 96 --dtype $dt > $O/prof_fetch5.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE -d $O/prof_write5 --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-e2e --no-config5 --images 4 --latent 96 --dtype $dt > $O/prof_write5.log 2>&1
+  python3 $R/tools/pmc_summary.py $O/prof_fetch5 $O/prof_write5 $O/pmc_traffic_images4_latent96_$dt.json
+  rm -rf $O/prof_fetch5 $O/prof_write5
 done
 ls -la $O
