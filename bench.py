@@ -361,6 +361,7 @@ def roofline_leg(sd, run, n_inst, peak, default_workload):
             "gemm_ms_per_step": round(gfull.value / n_inst, 4), "gemm_flop_per_step": gfl.value / n_inst,
             "gemm_kernel_only": {"achieved": round(ach_k, 1), "frac": round(ach_k / peak, 4), "ms_per_step": round(gms.value / n_inst, 4),
                                  "avg_launch_us": round(gms.value * 1e3 / max(1, gl.value), 2)},
+            "event_bracket_overhead_us": round(float(lib.tf_prof_overhead_us()), 2),
             "rocprof": rocprof}
 
 

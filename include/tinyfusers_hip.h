@@ -125,6 +125,7 @@ int tf_prof_read(double* gemm_ms, double* gemm_flops, long long* gemm_launches);
  * finishes it (the time the conv / linear family really takes in a step), `ms_gemm_kernel_only` ends behind the k_igemm* kernel itself
  * (what tf_prof_read reports, the figure rocprofv3 lists under that kernel name) */
 int tf_prof_read_full(double* ms_with_reduce, double* ms_gemm_kernel_only, double* gemm_flops, long long* gemm_launches);
+float tf_prof_overhead_us(void);   /* the per-bracket event overhead tf_prof_enable(1) measured (spin-kernel pair, see csrc/gemm.hip) and subtracts */
 int tf_prof_dump(const char* csv_path);   /* per-shape table: M,N,K,taps,tile,split-K,launches,ms,TFLOP/s */
 /* test / tuning hook: force the GEMM tile (bm x bn in {256,128,64} x {256,160,128,64}) and split-K; 0,0,0 = heuristic */
 int tf_gemm_force_config(int bm, int bn, int splitk);
