@@ -10,12 +10,12 @@ tot = 0
 out = []
 for r in rows:
     n = r["Name"]
-    if "rocclr" in n: continue
+    if "rocclr" in n or "k_prof_spin" in n: continue      # (runtime helpers; the spin kernel is the instrumented pass's event-overhead calibration)
     ms = float(r["TotalDurationNs"]) / 1e6 / steps
     tot += ms
     out.append("%-64s calls/step %6.1f  ms/step %7.3f  avg_us %8.2f" % (n[:64], int(r["Calls"]) / steps, ms, float(r["AverageNs"]) / 1e3))
 print("\n".join(out))
-print("sum of kernel durations: %.3f ms/step over %d kernel launches/step" % (tot, sum(int(r["Calls"]) for r in rows if "rocclr" not in r["Name"]) / steps))
+print("sum of kernel durations: %.3f ms/step over %d kernel launches/step" % (tot, sum(int(r["Calls"]) for r in rows if "rocclr" not in r["Name"] and "k_prof_spin" not in r["Name"]) / steps))
 if len(sys.argv) > 3:
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from bench import csrc_hash
