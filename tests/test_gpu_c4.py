@@ -115,3 +115,28 @@ def test_c4_conv1x1(tf, n, c1, c2, hw, cout):
     with forced():
         got = m(x, residual=dev(tf, r)).numpy()
     close(got, want.numpy())
+
+
+def test_c4_agrees_with_the_deep_ring_kernel_at_config5_size(tf):
+    """The GEGLU projection of config 5's first level (73728 x 2560 x 320: 11520 tiles, 22-23 per resident block) is too large for the CPU
+    oracle inside a test: the persistent kernel against the round-1 two-blocks-per-CU kernel on the same inputs (same products, another
+    summation order inside a K tile only), plus the linearity property f(2 x) = 2 f(x) of the plain linear (exact in floating point)."""
+    from tinyfusers_amd.native import hip, lib
+    m, n, k = 73728, 2560, 320
+    x = rnd("c45.x", (m, k), 0.5); w = rnd("c45.w", (n, k), k ** -0.5); b = rnd("c45.b", (n,), 0.1)
+    xd, x2d, wd, bd = dev(tf, x), dev(tf, 2.0 * x), dev(tf, w), dev(tf, b)
+    y_c4, y_c42, y_ref = tf.DeviceArray.empty((m, n // 2)), tf.DeviceArray.empty((m, n)), tf.DeviceArray.empty((m, n // 2))
+    y_lin = tf.DeviceArray.empty((m, n))
+    with forced():
+        hip.tf_linear_f16(y_c4.ptr, xd.ptr, wd.ptr, bd.ptr, None, m, n // 2, k, 1, None, 0, None)          # GEGLU
+        hip.tf_linear_f16(y_lin.ptr, xd.ptr, wd.ptr, None, None, m, n, k, 0, None, 0, None)
+        hip.tf_linear_f16(y_c42.ptr, x2d.ptr, wd.ptr, None, None, m, n, k, 0, None, 0, None)
+    lib.tf_gemm_force_config(128, 128, 1); lib.tf_gemm_debug(16)
+    try:
+        hip.tf_linear_f16(y_ref.ptr, xd.ptr, wd.ptr, bd.ptr, None, m, n // 2, k, 1, None, 0, None)
+    finally:
+        lib.tf_gemm_force_config(0, 0, 0); lib.tf_gemm_debug(0)
+    a, r = y_c4.numpy(), y_ref.numpy()
+    assert np.isfinite(a).all()
+    np.testing.assert_allclose(a, r, atol=2e-3, rtol=2e-3)
+    np.testing.assert_allclose(y_c42.numpy(), 2.0 * y_lin.numpy(), rtol=0, atol=1.2e-7)
