@@ -36,7 +36,7 @@ def decode_e4m3(raw_u8):
 
 class policy:
     """``with oracle.fp8.policy():`` makes oracle.unet_forward evaluate the fp8 layer policy (the ResBlocks' 3x3 convs with
-    Cin, Cout >= 64 and the FeedForward linears on e4m3 operands).  Restores the fp32 functions on exit."""
+    Cin, Cout >= 64 and the FeedForward linears of width >= 640 on e4m3 operands).  Restores the fp32 functions on exit."""
 
     def __enter__(self):
         from . import unet as U
@@ -58,7 +58,11 @@ class policy:
                 inside[0] -= 1
         U.resblock = res
 
+        ff0 = U.feed_forward
+
         def ff(x, W, p):
+            if ops.as_t(x).shape[-1] < 640:                # the K = 320 FeedForward stays fp16 (tinyfusers_amd/ff/nn.py: faster there, and exact)
+                return ff0(x, W, p)
             h = geglu0(quant_act(x), quant_weight(W[p + ".net.0.proj.weight"])[0], W[p + ".net.0.proj.bias"])
             return lin0(quant_act(h), quant_weight(W[p + ".net.2.weight"])[0], W[p + ".net.2.bias"])
         ops.conv2d_bias, U.feed_forward = conv, ff

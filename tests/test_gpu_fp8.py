@@ -150,10 +150,16 @@ def test_feed_forward_fp8_against_the_same_e4m3_operands(tf, m, c, force):
         y = fp8.linear_fp8(hid8, w28, sc2, ff.net[2].bias, residual=xd).numpy()
         want = O.linear(torch.from_numpy(hidq), O8.quant_weight(w2)[0], b2) + torch.from_numpy(x)
         np.testing.assert_allclose(y, want.numpy(), **TOL)
-        # and the module-level call (config 5's FeedForward) is those three stages
+        # and the module-level call (config 5's FeedForward) is those three stages -- from width 640 on; the K = 320 FeedForward stays fp16
+        # under the fp8 policy (faster there: tinyfusers_amd/ff/nn.py)
         config.set_dtype("fp8")
         got = ff(xd, residual=xd, ln=ln).numpy()
-        np.testing.assert_array_equal(got, y)
+        if c >= 640:
+            np.testing.assert_array_equal(got, y)
+        else:
+            xn = O.layer_norm(x, ln.weight.numpy(), ln.bias.numpy())
+            want16 = O.linear(O.geglu(xn, w1, b1), w2, b2) + torch.from_numpy(x)
+            np.testing.assert_allclose(got, want16.numpy(), **TOL)
     finally:
         lib.tf_gemm_force_config(0, 0, 0); lib.tf_gemm_debug(0)
         config.set_dtype("fp16")

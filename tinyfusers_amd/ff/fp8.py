@@ -4,7 +4,7 @@ precision variant of vision/conv2d.py:9-58 and ff/linear.py:112-121, selected wi
 Which layers run in fp8 (measured on the CPU oracle with e4m3 emulation, BASELINE.md section 4 gate: UNet rel-L2 <= 0.1):
 every conv and linear in e4m3 gives 0.16; the 3x3 convolutions (Cin, Cout >= 64) + the FeedForward linears give 0.088 and hold
 86 % of the conv / linear FLOPs.  The policy is the part of that set whose activation operand is a NORMALISED tensor: the two 3x3
-convs of every ResBlock (they read GroupNorm + SiLU outputs; opt-in through ``Conv2d._fp8_ok``) and the FeedForward linears behind a
+convs of every ResBlock (they read GroupNorm + SiLU outputs; opt-in through ``Conv2d._fp8_ok``) and the FeedForward linears of width >= 640 behind a
 LayerNorm.  The 1x1 projections, the attention projections, conv_in / conv_out, the time-embedding GEMVs, the six up / down-sampling
 convs (their input is the raw residual stream: e4m3 at a fixed scale of 1 saturates at 448 and flushes everything below 2e-3) and
 every module outside the UNet (the VAE's convs) stay fp16.

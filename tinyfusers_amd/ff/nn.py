@@ -71,7 +71,9 @@ class FeedForward:
     def __call__(self, x, residual=None, ln=None):
         from . import fp8
         g, l2 = self.net[0], self.net[2]
-        if fp8.enabled() and ln is not None and x.shape[-1] % 64 == 0 and g.dim_out % 64 == 0 and g.proj.bias is not None:
+        # (dim >= 640 only: at K = 320 the fp16 pair -- LayerNorm folded into the persistent short-K kernel, then the ping-pong kernel -- is faster
+        # than the e4m3 pair, 305 vs 366 us at config 5's first level, and exact)
+        if fp8.enabled() and ln is not None and x.shape[-1] >= 640 and x.shape[-1] % 64 == 0 and g.dim_out % 64 == 0 and g.proj.bias is not None:
             # config 5: LayerNorm -> e4m3, GEGLU projection in fp8 with an e4m3 output, second Linear in fp8 (+ bias + residual, fp16 out);
             # only behind a LayerNorm (a raw input has no fixed scale)
             h8 = fp8.layer_norm_fp8(x, ln)
