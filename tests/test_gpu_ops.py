@@ -284,8 +284,8 @@ SDPA_CASES = [  # b, nh, tq, tk, hs
     (1, 2, 200, 200, 40), (1, 2, 130, 130, 80), (1, 1, 192, 192, 64), (1, 1, 256, 256, 128), (1, 1, 129, 65, 160), (1, 1, 1, 1, 40),
     (1, 2, 250, 250, 56), (1, 1, 64, 300, 48),
     (35, 12, 1024, 1024, 64),        # the dims of the reference's own tests/sdpa.py:13-20
-    (16, 8, 1024, 300, 40), (8, 16, 1000, 200, 40), (16, 8, 512, 512, 80), (8, 32, 300, 200, 80), (16, 16, 256, 256, 40), (32, 8, 200, 200, 80),      # (the last two also run the causal mask through it)
-         # d = 40 / 80 with >= 256 blocks of 256 queries: the eight-wave form of k_sdpa_dma
+    # d = 40 / 80 with >= 256 blocks of 256 queries: the eight-wave form of k_sdpa_dma (the last two also run the causal mask through it)
+    (16, 8, 1024, 300, 40), (8, 16, 1000, 200, 40), (16, 8, 512, 512, 80), (8, 32, 300, 200, 80), (16, 16, 256, 256, 40), (32, 8, 200, 200, 80),
     (4, 8, 1000, 1000, 40), (2, 8, 2048, 200, 40), (2, 16, 1030, 64, 40),      # d = 40 with >= 256 query blocks (32-query waves), ragged Tq / Tk
 ]
 
