@@ -107,7 +107,7 @@ def test_update_state_key_walk_matches_checkpoint_names():
     seen = set(rec.seen)
     assert len(seen) == len(rec.seen), "a leaf was visited twice"
     want = {"model.diffusion_model." + k for k in oracle.unet_param_shapes(oracle.SD15)}
-    want |= set(oracle.vae_decoder_param_shapes()) | set(oracle.clip_param_shapes())
+    want |= set(oracle.vae_decoder_param_shapes()) | set(oracle.vae_encoder_param_shapes()) | set(oracle.clip_param_shapes())
     assert len(oracle.clip_param_shapes()) == 2 + 12 * 16 + 2
     extra = {k for k in seen - want if not k.endswith((".to_q.bias", ".to_k.bias", ".to_v.bias"))}
     assert not extra, sorted(extra)[:5]
@@ -116,6 +116,7 @@ def test_update_state_key_walk_matches_checkpoint_names():
     from tinyfusers_amd.storage.state import param_shapes
     shapes = {"model.diffusion_model." + k: tuple(v) for k, v in oracle.unet_param_shapes(oracle.SD15).items()}
     shapes.update({k: tuple(v) for k, v in oracle.vae_decoder_param_shapes().items()})
+    shapes.update({k: tuple(v) for k, v in oracle.vae_encoder_param_shapes().items()})
     shapes.update({k: tuple(v) for k, v in oracle.clip_param_shapes().items()})
     assert param_shapes(StableDiffusion(init=False)) == shapes
 

@@ -197,6 +197,19 @@ def conv2d_bf16(x, w, bias, padding, stride, dilation, residual=None):
     return y
 
 
+def pad_image(x, left, right, top, bottom):
+    """Zero padding of an NHWC image tensor on the device: the asymmetric [0, 1, 0, 1] (left, right, top, bottom) of the VAE encoder's
+    stride-2 convolutions (vae/encoder.py:19 hands that list to the conv as its ``padding``; a symmetric conv cannot express it)."""
+    n, c, h, w = x.shape
+    assert x.layout == "nhwc" and x.dtype == np.float16
+    hp, wp = h + top + bottom, w + left + right
+    y = DeviceArray.empty((n, c, hp, wp), np.float16, "nhwc")
+    hip.tf_memset_async(y.ptr, 0, y.nbytes, _sh())
+    for i in range(n):
+        hip.tf_memcpy_2d_async(y.ptr + ((i * hp + top) * wp + left) * c * 2, wp * c * 2, x.ptr + i * h * w * c * 2, w * c * 2, w * c * 2, h, _sh())
+    return y
+
+
 class Conv2d:
     def __init__(self, in_channels, out_channels, kernel_size, stride=[1, 1], padding=[0, 0], dilation=[1, 1], groups=1, bias=True, init=True):
         assert groups == 1, "groups=1 only (all the UNet uses)"
@@ -235,6 +248,10 @@ class Conv2d:
         """gn = G: also emit the statistics of the output for the GroupNorm(G) that reads it next (y.gn).
         extra = (proj, x3): add ``proj(x3)`` (a Conv2d 1x1; x3 a tensor or a concat pair) inside this conv's GEMM.
         gn_in = (GroupNorm, silu): this conv reads GroupNorm(x) [-> SiLU] (x is the RAW tensor): one launch where possible."""
+        if len(self.padding) == 4:                         # [left, right, top, bottom]: pad explicitly, then an unpadded conv
+            assert extra is None and gn_in is None and not upsample and not isinstance(x, (tuple, list))
+            x = pad_image(x, *self.padding)
+            return _conv(x, self.weight, self.bias, [0, 0], self.stride, self.dilation, bias_nc, residual, False, gn, out_norm=out_norm)
         if extra is not None:
             proj, x3 = extra
             wp, bp = self.fold_1x1(proj)
