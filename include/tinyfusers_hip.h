@@ -28,6 +28,7 @@ typedef struct tfStream_st* tfStream_t;
 typedef struct tfEvent_st* tfEvent_t;
 typedef struct tfGraph_st* tfGraph_t;
 typedef struct tfComm_st* tfComm_t;
+typedef struct tfFunction_st* tfFunction_t;   /* a kernel compiled at run time (tf_rtc_load) */
 
 #define TF_OK 0
 #define TF_E_ARG 10001
@@ -49,6 +50,13 @@ int tf_device_count(int* count);
 int tf_device_attr(int* value, int attr, int device);
 /* gcn arch name ("gfx950:...") copied into buf */
 int tf_device_arch(char* buf, int buflen, int device);
+
+/* ---- run-time compilation: replaces nvrtcCreateProgram / nvrtcCompileProgram / nvrtcGetCUBIN (native/nvrtc/ops.py:3-45) + cuModuleLoadData /
+ * cuModuleGetFunction / cuLaunchKernel (native/cuda/ops.py:3-39) as storage/device.py:31-77 and its wrappers :79-233 use them.  hiprtc compiles
+ * HIP source for the current device's architecture; a failed compilation returns TF_E_ARG with the compiler's log in tf_last_error().
+ * params[i] points at the i-th kernel argument (cuLaunchKernel's kernelParams). */
+int tf_rtc_load(tfFunction_t* out_fn, const char* source, const char* func_name);
+int tf_rtc_launch(tfFunction_t fn, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by, unsigned bz, unsigned shared_bytes, tfStream_t s, void** params);
 const char* tf_last_error(void);
 int tf_version(void);
 

@@ -352,6 +352,49 @@ def test_sdpa_rescale_and_far_below_zero_at_256_query_blocks(tf):
     close(got, O.scaled_dot_product_attention(q, k, v).numpy())
 
 
+RTC_SRC = r"""
+// written for this test: the semantics of the reference's scale_tensor_func.cu:5-10 (in-place scalar multiply) and a row-sum that uses LDS
+extern "C" __global__ void scale_kernel(float* inp, float scale, int N) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) inp[i] *= scale;
+}
+extern "C" __global__ void row_sum(float* out, const float* inp, int C) {
+  extern __shared__ float part[];
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) s += inp[(size_t)blockIdx.x * C + c];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) out[blockIdx.x] = part[0];
+}
+"""
+
+
+def test_device_load_func_compiles_and_launches_at_run_time(tf):
+    """storage/device.py:31-77 + :104-127 (tests/device.py:8-22 of the reference): a kernel given as SOURCE is compiled for the device at run
+    time (hiprtc), cached per Device, and launched with the reference's geometry (block 8, grid ceil(N / 8)); a kernel with dynamic
+    shared memory; a compilation error is a RuntimeError that carries the compiler's message."""
+    import ctypes
+    from tinyfusers_amd.storage.device import Device
+    d = Device("hip")
+    x = rnd("rtc.x", (13, 87), 2.0)
+    t = tf.Tensor.from_np(x.copy()).eval()
+    fn = d.load_func(RTC_SRC, "scale_kernel")
+    assert d.load_func(RTC_SRC, "scale_kernel") is fn      # cached
+    n = x.size
+    d.launch_func(fn, ((n + 7) // 8,), (8,), [t, ctypes.c_float(2.5), ctypes.c_int(n)])
+    rs = d.load_func(RTC_SRC, "row_sum")
+    out = tf.Tensor.zeros((13,), np.float32).eval()
+    d.launch_func(rs, (13,), (64,), [out, t, 87], shared_mem=64 * 4)
+    close(out.to("cpu").data, (2.5 * x).sum(axis=1), rtol=1e-5, atol=1e-4)
+    close(t.to("cpu").data, 2.5 * x, atol=1e-6)           # (to("cpu") moves the tensor: its device memory is gone afterwards)
+    with pytest.raises(RuntimeError) as e:
+        d.load_func("extern \"C\" __global__ void broken(float* p) { p[0] = undeclared_symbol; }", "broken")
+    assert "undeclared_symbol" in str(e.value)
+    with pytest.raises(RuntimeError):
+        d.load_func(RTC_SRC, "no_such_kernel")
+
+
 def test_softmax_rows_and_own_runtime_kernels(tf):
     from oracle import ops as O
     from tinyfusers_amd.storage.device import Device

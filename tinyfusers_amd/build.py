@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtinyfusers_hip.so")
-SOURCES = ["runtime.hip", "elementwise.hip", "norm.hip", "gemm.hip", "sdpa.hip", "sgemm.hip", "comm.hip"]
+SOURCES = ["runtime.hip", "elementwise.hip", "norm.hip", "gemm.hip", "sdpa.hip", "sgemm.hip", "comm.hip", "rtc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-ffp-contract=fast"]
 # sdpa.hip: keep the MFMA accumulators in VGPRs (the softmax reads every score: no v_accvgpr_read traffic) and drop
 # the NaN-canonicalising v_max in front of every fmaxf on MFMA outputs (scores are never NaN; -inf masks still work)

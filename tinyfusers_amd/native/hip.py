@@ -16,6 +16,7 @@ _CT = {
     "tfComm_t*": ctypes.POINTER(ctypes.c_void_p),
     "tfStream_t*": ctypes.POINTER(ctypes.c_void_p), "tfEvent_t*": ctypes.POINTER(ctypes.c_void_p),
     "tfGraph_t*": ctypes.POINTER(ctypes.c_void_p), "void": None,
+    "unsigned": ctypes.c_uint, "tfFunction_t": ctypes.c_void_p, "tfFunction_t*": ctypes.POINTER(ctypes.c_void_p),
 }
 
 
