@@ -63,3 +63,26 @@ def test_product_never_imports_the_oracle():
     import subprocess, sys
     out = subprocess.run(["grep", "-rlE", r"^\s*(from|import)\s+oracle", os.path.join(ROOT, "tinyfusers_amd")], capture_output=True, text=True)
     assert out.stdout.strip() == "", out.stdout
+
+
+def test_shipped_library_holds_no_ablation_kernel(native):
+    """Kernels that skip work and return wrong results by design (the DBG template instances tools/*_dbg.py time) are compiled only under
+    -DTF_ABLATION into a second library; the shipped code objects hold none, no environment variable can select one, and the ablation
+    bits of tf_gemm_debug are refused (one code path per op, as attention/sdpa.py:53-77 of the reference has)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from tools.kernel_regs import LLVM, census
+    if not os.path.exists(os.path.join(LLVM, "clang-offload-bundler")):
+        pytest.skip("llvm tools not found")
+    ks = census(os.path.dirname(native.LIB_PATH))
+    assert 100 <= len(ks) <= 185, len(ks)
+    for k in ks:
+        m = re.match(r"void k_igemm_pp<(\d+), (\d+), (true|false), (true|false),", k["name"])
+        assert not (m and m.group(4) == "true"), k["name"]                    # k_igemm_pp<BN, NP, FASTA, DBG, ...>
+        m = re.match(r"void k_sdpa_dma<(\d+), (\d+), (\d+), (\d+)>", k["name"])
+        assert not (m and m.group(3) != "0"), k["name"]                       # k_sdpa_dma<HS, QT, DBG, NW>
+        assert k["vspill"] == 0 and k["scratch"] == 0, k                      # no kernel spills vector registers
+    assert native.lib.tf_gemm_debug(1) == 10001 and b"TF_ABLATION" in native.lib.tf_last_error()
+    assert native.lib.tf_gemm_debug(512) == 0 and native.lib.tf_gemm_debug(0) == 0   # (variant selection is a test hook, not an ablation)
+    src = open(os.path.join(ROOT, "tinyfusers_amd", "csrc", "sdpa.hip")).read()
+    assert re.search(r"#ifdef TF_ABLATION\s*\nstatic int g_sdpa_dbg = getenv", src)   # TF_SDPA_DBG is read by the ablation build only

@@ -1,4 +1,8 @@
-"""In-tree build of libtinyfusers_hip.so (hipcc, gfx950 only).  `python -m tinyfusers_amd.build [-f]`."""
+"""In-tree build of libtinyfusers_hip.so (hipcc, gfx950 only).  `python -m tinyfusers_amd.build [-f] [--ablation]`.
+
+`--ablation` builds a SECOND library, lib/libtinyfusers_hip_ablation.so, from the same sources with -DTF_ABLATION: it additionally holds the
+ablation instances (kernels that skip work and return wrong results by design) that tools/*_dbg.py time; those tools load it explicitly
+through TF_LIB_PATH.  The shipped library has none of them and ignores TF_SDPA_DBG / the ablation bits of tf_gemm_debug."""
 import concurrent.futures as cf
 import os
 import subprocess
@@ -8,7 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtinyfusers_hip.so")
-SOURCES = ["runtime.hip", "elementwise.hip", "norm.hip", "gemm.hip", "sdpa.hip", "sgemm.hip", "comm.hip", "rtc.hip"]
+LIB_ABLATION = os.path.join(LIBDIR, "libtinyfusers_hip_ablation.so")
+# the GEMM family is one translation unit per kernel family (gemm_k_*.hip) so that its instances compile in parallel; the largest first
+SOURCES = ["gemm_k_pp16.hip", "gemm_k_pp8.hip", "gemm_k_igemm_128.hip", "gemm_k_igemm_64.hip", "gemm_k_igemm_160.hip", "gemm_k_patch.hip", "sdpa.hip",
+           "gemm_k_igemm8.hip", "gemm_k_c4.hip", "gemm.hip", "norm.hip", "elementwise.hip", "runtime.hip", "sgemm.hip", "comm.hip", "rtc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-ffp-contract=fast"]
 # sdpa.hip: keep the MFMA accumulators in VGPRs (the softmax reads every score: no v_accvgpr_read traffic) and drop
 # the NaN-canonicalising v_max in front of every fmaxf on MFMA outputs (scores are never NaN; -inf masks still work)
@@ -29,17 +36,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    os.makedirs(LIBDIR, exist_ok=True)
+def build(force=False, verbose=False, ablation=False):
+    objdir = os.path.join(LIBDIR, "ablation") if ablation else LIBDIR
+    lib = LIB_ABLATION if ablation else LIB
+    os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "tinyfusers_hip.h")]
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))] + [os.path.join(os.path.dirname(HERE), "include", "tinyfusers_hip.h")]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([hipcc] + FLAGS + EXTRA.get(s, []) + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + (["-DTF_ABLATION"] if ablation else []) + EXTRA.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -47,12 +56,12 @@ def build(force=False, verbose=False):
             raise RuntimeError("build failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
-    with cf.ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(int(os.environ.get("TF_BUILD_JOBS", "8")), max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    if jobs or force or _stale(lib, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="-f" in sys.argv, verbose=True))
+    print(build(force="-f" in sys.argv, verbose=True, ablation="--ablation" in sys.argv))

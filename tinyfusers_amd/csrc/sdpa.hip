@@ -573,7 +573,8 @@ static int launch_sdpa_dma(const SdpaP& p, hipStream_t st) {
     TF_HIP(hipFuncSetAttribute((const void*)k_sdpa_dma<HS, QT, 0, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  if constexpr (HS == 40 && QT == 2 && NW == 4) {                   // ablation builds (tools/sdpa_dbg.py): wrong results by design
+#ifdef TF_ABLATION   // the ablation library only (python -m tinyfusers_amd.build --ablation; tools/sdpa_dbg.py): wrong results by design
+  if constexpr (HS == 40 && QT == 2 && NW == 4) {
     if (p.dbg) {
       const dim3 grid((unsigned)((p.Tq + QB - 1) / QB * p.NH * p.B));
       switch (p.dbg) {
@@ -587,6 +588,7 @@ static int launch_sdpa_dma(const SdpaP& p, hipStream_t st) {
       return TF_OK;
     }
   }
+#endif
   hipLaunchKernelGGL((k_sdpa_dma<HS, QT, 0, NW>), dim3((unsigned)((p.Tq + QB - 1) / QB * p.NH * p.B)), dim3(NW * 64), smem, st, p);
   TF_LAUNCH_CHECK();
   return TF_OK;
@@ -606,7 +608,11 @@ static int launch_sdpa(const SdpaP& p, hipStream_t st) {
 }
 
 static bool g_sdpa_generic = getenv("TF_SDPA_GENERIC") != nullptr;
+#ifdef TF_ABLATION
 static int g_sdpa_dbg = getenv("TF_SDPA_DBG") ? atoi(getenv("TF_SDPA_DBG")) : 0;   // ablation of k_sdpa_dma<40, 2> (see SdpaP::dbg)
+#else
+static const int g_sdpa_dbg = 0;   // the shipped library ignores TF_SDPA_DBG: it holds no kernel that returns wrong results
+#endif
 static int g_sdpa_nw = getenv("TF_SDPA_NW") ? atoi(getenv("TF_SDPA_NW")) : 0;      // A/B: 4 / 8 waves per block where both exist (0 = per-shape choice)
 static int g_sdpa_qt = getenv("TF_SDPA_QT") ? atoi(getenv("TF_SDPA_QT")) : 0;   // debugging: force the register-staged kernel
 

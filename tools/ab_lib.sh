@@ -1,0 +1,19 @@
+#!/bin/bash
+# tools/ab_lib.sh ROUNDS OLD_LIB [bench args...]: same-box A/B of the built library against an earlier one (e.g. _r03lib/libtinyfusers_hip.so),
+# alternating, one bench process per measurement (200 graph-replayed steps each); prints ms per step per round.
+R=$1; OLD=$2; shift 2
+mkdir -p gpurun_out
+one() {   # label, env assignment
+  ( export $2 TF_LIB_ALLOW_MISSING=1; exec python bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-roofline --no-e2e --no-config5 "${@:3}" > gpurun_out/ab.json 2> gpurun_out/ab.err )
+  python - "$1" <<'PY'
+import json, sys
+try:
+    print("%-10s %.4f ms/step" % (sys.argv[1], json.loads(open("gpurun_out/ab.json").read().strip().splitlines()[-1])["ms_per_step"]))
+except Exception as e:
+    print(sys.argv[1], "failed:", e, open("gpurun_out/ab.err").read()[-300:])
+PY
+}
+for i in $(seq 1 $R); do
+  one "old[$i]" "TF_LIB_PATH=$OLD" "$@"
+  one "new[$i]" "TF_AB_DUMMY=1" "$@"
+done

@@ -2,6 +2,7 @@
 """Ablation (tf_gemm_debug) of the short-K, many-tile GEMMs: WIDE vs deep, per tile size."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools import _ablation; _ablation.use()   # the ablation bits exist only in the -DTF_ABLATION library
 from tinyfusers_amd.native import lib
 from tools.gemm_dbg import run
 for wide in (16, 8):

@@ -4,6 +4,7 @@
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools import _ablation; _ablation.use()   # the ablation bits exist only in the -DTF_ABLATION library
 import tinyfusers_amd.storage.tensor as T
 from tinyfusers_amd.native import hip, lib
 from tools.pp_bench import time_call, st
