@@ -52,8 +52,8 @@ def parse(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the config-3 end-to-end leg (CLIP x2 -> 50 steps -> VAE decode)")
     ap.add_argument("--e2e-images", type=int, default=3)
-    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg (4 images per GPU, 96x96 latents, fp16 and fp8 conv/linear, 3 timed steps each)")
-    ap.add_argument("--config5-steps", type=int, default=3)
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg (4 images per GPU, 96x96 latents, fp16 and fp8 conv/linear, --config5-steps timed graph replays each)")
+    ap.add_argument("--config5-steps", type=int, default=12)
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of the HIP-graph replay")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--tune-cache", default="", help="file to load/save the GEMM autotuner's per-shape choices (optional)")
@@ -61,6 +61,8 @@ def parse(argv=None):
     ap.add_argument("--latent", type=int, default=64, help="latent height = width; default 64 (512x512 images); 96 = 768x768 (config 5)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp8"], help="conv/linear operand type (fp8 = config 5: OCP e4m3 weights + activations, fp32 accumulate, fp16 residual stream)")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank plumbing (gloo): no GPU, no kernels")
+    ap.add_argument("--comm", default="torch", choices=["torch", "tf"], help="who carries the one weight-arena broadcast: torch.distributed (nccl = RCCL), or the C-ABI's own "
+                    "tf_comm_unique_id / tf_comm_init_rank / tf_bcast (csrc/comm.hip; the id travels through a file, tinyfusers_amd.dist.TfComm)")
     return ap.parse_args(argv)
 
 
@@ -171,7 +173,7 @@ def dry_run(args):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def build_weight_arena(unet, rank, world, device_index):
+def build_weight_arena(unet, rank, world, device_index, comm="torch"):
     """Pack every UNet tensor into ONE fp16 device arena (torch owns the memory: plumbing), filled on rank 0 and
     broadcast once over RCCL; every module leaf becomes a view into it."""
     import torch
@@ -200,7 +202,14 @@ def build_weight_arena(unet, rank, world, device_index):
         torch.cuda.synchronize()
         dist.barrier()
         t1 = time.time()
-        broadcast_arena(arena, src=0)          # the ONLY collective of the path (RCCL over xGMI)
+        if comm == "tf":                       # the C-ABI's own RCCL wrappers (what a host without torch.distributed would call)
+            from tinyfusers_amd.dist import TfComm
+            c = TfComm(rank, world)
+            c.bcast(base, off, 0, None)
+            hip.tf_stream_sync(None)
+            c.destroy()
+        else:
+            broadcast_arena(arena, src=0)      # the ONLY collective of the path (RCCL over xGMI)
         torch.cuda.synchronize()
         t_bcast = time.time() - t1
     state = {k: DeviceArray(base + offs[k], shapes[k], np.float16, None, base=arena) for k in shapes}
@@ -242,19 +251,29 @@ def cpu_baseline(steps):
         x = oracle.sd_step(unc, ctx, x, np.array([ts[i]], np.float32), al[i:i + 1], ap[i:i + 1], np.array([7.5]), W)
         times.append(time.time() - t0)
     sec = float(np.median(times[1:]))
-    # config 1: the reference's own single-op tests on CPU.  tests/conv2d.py:13-33: X (1,2,10000,10000) fp32, W (1,2,2,2), pad 0,
-    # stride 1 (bounded here to 4000 x 4000: same arithmetic per output, 16 % of the pixels); tests/group_norm.py:22-41:
-    # (2048, C, 2, 2) with 2 groups, C = 1600 (the largest of its parametrisation).
-    xc = torch.from_numpy(synth_normal(7, "cfg1.conv.x", (1, 2, 4000, 4000))); wc = torch.from_numpy(synth_normal(7, "cfg1.conv.w", (1, 2, 2, 2)))
-    F.conv2d(xc, wc)
+    # config 1: the reference's own single-op tests on CPU.  tests/conv2d.py:13-33: X (1,2,10000,10000) fp32 (800 MB), W (1,2,2,2), pad 0,
+    # stride 1 -- at the test's own size when the host has the memory for it (input + output + torch's scratch: < 4 GB), else bounded to
+    # 4000 x 4000 (same arithmetic per output); tests/group_norm.py:22-41: (2048, C, 2, 2) with 2 groups, C = 1600 (the largest of its
+    # parametrisation).
+    side = 4000
+    try:
+        avail_kb = int(next(ln for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")).split()[1])
+        if avail_kb > 16 * 1024 * 1024:
+            side = 10000
+    except Exception:
+        pass
+    xc = torch.from_numpy(np.random.default_rng(7).standard_normal((1, 2, side, side), dtype=np.float32)); wc = torch.from_numpy(synth_normal(7, "cfg1.conv.w", (1, 2, 2, 2)))
+    F.conv2d(xc[:, :, :1000, :1000], wc)
     t0 = time.time(); yc = F.conv2d(xc, wc); t_conv = time.time() - t0
+    conv_shape = f"x(1,2,{side},{side}) w(1,2,2,2) pad 0 stride 1 fp32 (" + ("the reference test's own size" if side == 10000 else "16 % of the reference test's 10000^2 pixels: host memory") + ")"
+    n_out = yc.numel()
+    del xc, yc
     xg = torch.from_numpy(synth_normal(7, "cfg1.gn.x", (2048, 1600, 2, 2)))
     oracle.group_norm(xg, 2, 1e-5)
     t0 = time.time(); oracle.group_norm(xg, 2, 1e-5); t_gn = time.time() - t0
     return {"value": 1.0 / sec, "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"{steps} full SD1.5 denoising steps (CFG batch 2, 64x64 latent) after 1 warm-up, torch-CPU fp32 oracle, median {sec:.2f} s/step",
-            "single_ops": {"conv2d_tests_conv2d_py": {"shape": "x(1,2,4000,4000) w(1,2,2,2) pad 0 stride 1 fp32 (16 % of the reference test's 10000^2 pixels)",
-                                                      "ms": round(t_conv * 1e3, 2), "gpixel_per_s": round(yc.numel() / t_conv / 1e9, 3)},
+            "single_ops": {"conv2d_tests_conv2d_py": {"shape": conv_shape, "ms": round(t_conv * 1e3, 2), "gpixel_per_s": round(n_out / t_conv / 1e9, 3)},
                            "group_norm_tests_group_norm_py": {"shape": "x(2048,1600,2,2) 2 groups fp32", "ms": round(t_gn * 1e3, 2),
                                                               "gb_per_s": round(2 * xg.numel() * 4 / t_gn / 1e9, 2)}}}
 
@@ -288,12 +307,10 @@ def e2e_leg(sd, n_images, seed):
         T.hip.tf_stream_sync(None)
         t1 = time.perf_counter()
         if n == 0:
-            sd.compile(unconditional_context, context, latent)
+            sd.compile(unconditional_context, context, latent, timesteps=timesteps)
         t2 = time.perf_counter()
         if n > 0:
-            # same buffers as the captured graph: refresh the stacked context in place
-            T.hip.tf_memcpy_async(sd._ctx2.ptr, unconditional_context.ptr, context.nbytes, 3, sd._stream.handle)
-            T.hip.tf_memcpy_async(sd._ctx2.ptr + context.nbytes, context.ptr, context.nbytes, 3, sd._stream.handle)
+            sd.set_context(unconditional_context, context)     # same buffers as the captured graph: the stacked context and its K|V projection, in place
         sd.set_latent(synth_normal(seed + n, "sd.latent", (1, 4, 64, 64)))
         for index, timestep in list(enumerate(timesteps))[::-1]:
             sd.step(timestep, alphas[index], alphas_prev[index], 7.5)
@@ -393,7 +410,7 @@ def config5_leg(wstate, steps, seed):
             lat = sd.latent_from_numpy(synth_normal(seed, "sd.latent", (B, 4, S, S)))
             ctx = T.DeviceArray.from_numpy(synth_normal(seed, "sd.context", (B, 77, 768)))
             unc = T.DeviceArray.from_numpy(synth_normal(seed, "sd.uncond", (B, 77, 768)))
-            sd.compile(unc, ctx, lat)
+            sd.compile(unc, ctx, lat, timesteps=timesteps)
 
             def run(n, eager):
                 for s_ in range(n):
@@ -459,7 +476,7 @@ def main(argv=None):
     config.set_dtype(args.dtype)
 
     sd = StableDiffusion()
-    arena, arena_bytes, t_gen, t_bcast, wstate = build_weight_arena(sd.model.diffusion_model, rank, world, local_rank)
+    arena, arena_bytes, t_gen, t_bcast, wstate = build_weight_arena(sd.model.diffusion_model, rank, world, local_rank, args.comm)
     seed = 1234 + rank
     B, S = args.images, args.latent
     lat = sd.latent_from_numpy(synth_normal(seed, "sd.latent", (B, 4, S, S)))
@@ -471,7 +488,7 @@ def main(argv=None):
     alphas_prev = np.concatenate((np.array([1.0]), alphas[:-1])).astype(np.float32)
     if args.tune_cache:
         hip.tf_gemm_tune_load(args.tune_cache.encode())
-    sd.compile(unc, ctx, lat)
+    sd.compile(unc, ctx, lat, timesteps=timesteps)
     if args.tune_cache and rank == 0:
         hip.tf_gemm_tune_save(args.tune_cache.encode())
 
@@ -534,7 +551,7 @@ def main(argv=None):
             "device_ms_per_step": round(ms.value / args.steps, 4),
             "step_tflops": round(flop_unit * B * args.steps / (ms.value * 1e-3) / 1e12, 1) if flop_unit else None,
             "step_mfma_frac": round(flop_unit * B * args.steps / (ms.value * 1e-3) / 1e12 / peak, 4) if flop_unit else None,
-            "weights": {"bytes": arena_bytes, "synth_s": round(t_gen, 2), "bcast_s": round(t_bcast, 4)},
+            "weights": {"bytes": arena_bytes, "synth_s": round(t_gen, 2), "bcast_s": round(t_bcast, 4), "bcast_via": ("tf_bcast (C-ABI, librccl)" if args.comm == "tf" else "torch.distributed nccl") if use_dist else None},
             "roofline": roofline,
         }
         if world == 1 and (B, S, args.dtype) == (1, 64, "fp16") and not args.no_e2e:

@@ -137,15 +137,28 @@ float tf_prof_overhead_us(void);   /* the per-bracket event overhead tf_prof_ena
 int tf_prof_dump(const char* csv_path);   /* per-shape table: M,N,K,taps,tile,split-K,launches,ms,TFLOP/s */
 /* test / tuning hook: force the GEMM tile (bm x bn in {256,128,64} x {256,160,128,64}) and split-K; 0,0,0 = heuristic */
 int tf_gemm_force_config(int bm, int bn, int splitk);
-/* per-shape autotuning of (tile, split-K, ring variant) on the first eager call of a shape (default on) */
-int tf_gemm_autotune(int on);
+/* per-shape choice of (tile, split-K, ring variant).  mode 1 (default): a shape that is not in the table is timed on its first eager
+ * call and cached; mode 0: cost model only; mode 2: table only -- a shape without a row is an error naming the shape (what every rank
+ * of a multi-GPU run uses, so that all ranks run the same kernels: tinyfusers_amd.native sets it when WORLD_SIZE > 1) */
+int tf_gemm_autotune(int mode);
 int tf_gemm_tune_save(const char* path);
 int tf_gemm_tune_load(const char* path);
-/* diagnostic builds of tools/: bit 0 no stores, 1 no MFMA, 2 no staging, 3/4 force deep/wide ring, 5/6 force n-fastest/m-fastest order,
- * 7 (128) the patch variant of the 3x3 convolutions (k_igemm_patch), 8 (256) the variant whose consumer waves issue part of the
- * weight loads, each where the shape is eligible; 9 (512) the 256-row ping-pong kernel k_igemm_pp (with tf_gemm_force_config(256, BN, split),
- * BN in {128, 160, 256}: fails where it cannot take the launch), 12 (4096) its ablation build without fragment reads, 13 (8192) its
- * one-phase-per-k-step form on the three-slot ring */
+/* host-side view of the table (no device work).  key = {M, N, K, C1, C2, S, stride, upsample, act, flags} as tf_gemm_tune_save writes
+ * a row, cfg = {bm, bn, splitk, variant, order}; tf_gemm_tune_query returns TF_E_STATE (10004) for a shape without a row */
+int tf_gemm_tune_query(const int* key, int* cfg);
+int tf_gemm_tune_count(int* n);
+int tf_gemm_tune_entry(int index, int* key, int* cfg);
+/* tf_gemm_tune_trace(1) starts remembering every shape key a launch looks up, tf_gemm_tune_trace_dump writes them (ten key fields + 1 / 0:
+ * had a row), one per line -- which rows a workload needs (tools/gemm_keys.py) */
+int tf_gemm_tune_trace(int on);
+int tf_gemm_tune_trace_dump(const char* path);
+/* test / tuning hook, kernel SELECTION only (every setting computes the same result): bits 3/4 force the deep/wide ring, 5/6 the
+ * n-fastest/m-fastest block order, 7 (128) the patch variant of the 3x3 convolutions (k_igemm_patch), 8 (256) the variant whose consumer
+ * waves issue part of the weight loads, each where the shape is eligible; 9 (512) the 256-row ping-pong kernel k_igemm_pp (with
+ * tf_gemm_force_config(256, BN, split), BN in {128, 160, 256}: fails where it cannot take the launch), 10 (1024) the persistent short-K
+ * kernel k_gemm_c4, 13 (8192) the ping-pong kernel's one-phase-per-k-step form on the three-slot ring.  The ABLATION bits -- 0 no stores,
+ * 1 no MFMA, 2 no staging, 12 (4096) no fragment reads: wrong results by design -- exist only in the second library built with
+ * -DTF_ABLATION (python -m tinyfusers_amd.build --ablation, loaded by tools/*_dbg.py); the shipped library refuses them (10001) */
 int tf_gemm_debug(int flags);
 
 /* ---- layout / dtype converters (the API edge: the reference's arrays are fp32 NCHW) ----------- */
@@ -362,6 +375,10 @@ int tf_transpose_f32(void* out, const void* inp, int ndim, const int* shape, con
  * tf_set_step_params (values travel as kernel arguments, so there is no host buffer to race with) ahead of the
  * replay of the step's HIP graph, whose kernels read them from device memory. */
 int tf_set_step_params(void* step_params, float timestep, float a_t, float a_prev, float guidance, tfStream_t s);
+/* the same launch also copies nbytes (a multiple of 16, both pointers 16-byte aligned) src -> dst: the time-embedding chain of
+ * vision/unet.py:54-56 + the ResBlocks' Linear(SiLU(emb)) (vision/resnet.py:28) depends on the timestep alone, so a sampler computes the
+ * row of a timestep once, keeps it, and hands it to the captured step through this copy instead of four launches per step */
+int tf_set_step_params_copy(void* step_params, float timestep, float a_t, float a_prev, float guidance, void* dst, const void* src, long long nbytes, tfStream_t s);
 int tf_timestep_embedding_f16(void* out, const void* step_params, int dim, float max_period, tfStream_t s);
 /* latent (B,C,H,W) f32 NCHW  ->  unet input (2B,H,W,C) f16 NHWC = [latent ; latent]  (variants/sd.py:31) */
 int tf_cfg_duplicate_f16(void* x2b_nhwc, const void* latent_nchw_f32, int B, int C, int H, int W, tfStream_t s);

@@ -55,3 +55,65 @@ def test_weight_broadcast_and_sharding_world2():
     assert sh0 == (0, 4) and sh1 == (4, 8)                    # images sharded, no overlap
     assert l0 != l1                                           # distinct per-rank latent seeds
     assert t0 == t1 == 2.0                                    # timing = max over ranks
+
+
+# ---- the C-ABI's own collective: the unique-id hand-over (host code of tinyfusers_amd.dist.TfComm) and the kernel choices of the ranks ----
+def _id_worker(rank, world, path, q):
+    sys.path.insert(0, ROOT)
+    os.environ["WORLD_SIZE"] = str(world)                 # native sets tf_gemm_autotune(2) at import: table only
+    from tinyfusers_amd.dist import exchange_unique_id
+    uid = exchange_unique_id(rank, lambda: bytes(range(128)), path, timeout=60.0)
+    # every rank's view of the shipped tuning table through the C-ABI (host code, no device): digest of all rows + the choices of some shapes
+    import ctypes, hashlib
+    from tinyfusers_amd.native import hip, lib
+    n = ctypes.c_int()
+    hip.tf_gemm_tune_count(ctypes.byref(n))
+    h = hashlib.sha256()
+    keys = []
+    for i in range(n.value):
+        k, c = (ctypes.c_int * 10)(), (ctypes.c_int * 5)()
+        hip.tf_gemm_tune_entry(i, k, c)
+        c2 = (ctypes.c_int * 5)()
+        hip.tf_gemm_tune_query(k, c2)
+        assert list(c) == list(c2)
+        h.update(bytes(k)); h.update(bytes(c))
+        keys.append(tuple(k))
+    missing = (ctypes.c_int * 10)(7, 7, 64, 64, 0, 1, 1, 0, 0, 0)
+    rc = lib.tf_gemm_tune_query(missing, (ctypes.c_int * 5)())
+    q.put((rank, uid, n.value, h.hexdigest(), rc, sorted(keys)))
+
+
+def test_unique_id_handover_and_identical_kernel_choices_world2(tmp_path):
+    """bench.py --comm tf: rank 0 publishes the 128-byte RCCL id through a file, rank 1 picks it up; and with WORLD_SIZE > 1 both ranks
+    hold the same tuning table (tf_gemm_tune_* is host code) and will not tune at run time, so they launch the same kernels."""
+    path = str(tmp_path / "uid")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_id_worker, args=(r, 2, path, q)) for r in (1, 0)]      # the waiting rank starts first
+    for p in procs: p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, u0, n0, d0, rc0, k0), (r1, u1, n1, d1, rc1, k1) = res
+    assert u0 == u1 == bytes(range(128))
+    assert n0 == n1 >= 150 and d0 == d1 and k0 == k1          # the same rows, the same choices
+    assert rc0 == rc1 == 10004                                # a shape without a row: an error, not a tuning run
+    # the table covers BASELINE config 2 and config 5 (fp16 and fp8 policy): the shape keys a GPU run of each configuration consults
+    # (tests/golden/gemm_keys.json, written by tools/gemm_keys.py on the GPU box in table-only mode)
+    import json
+    fixture = os.path.join(ROOT, "tests", "golden", "gemm_keys.json")
+    want = json.load(open(fixture))
+    have = set(k0)
+    assert set(want) == {"config2_fp16", "config5_fp16", "config5_fp8"}
+    for cfg, keys in want.items():
+        miss = [k for k in keys if tuple(k) not in have]
+        assert not miss, f"{cfg}: {len(miss)} shapes without a row, e.g. {miss[:3]}"
+
+
+def test_table_only_mode_is_set_with_world_size(monkeypatch):
+    import subprocess
+    code = ("import ctypes, tinyfusers_amd.native as n; k=(ctypes.c_int*10)(7,7,64,64,0,1,1,0,0,0); "
+            "print(n.lib.tf_gemm_autotune(3), n.lib.tf_gemm_autotune(2))")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, WORLD_SIZE="2"))
+    assert r.returncode == 0 and r.stdout.split() == ["10001", "0"], r.stdout + r.stderr

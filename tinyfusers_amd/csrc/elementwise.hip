@@ -280,6 +280,12 @@ __global__ void __launch_bounds__(256) k_softmax_mask_rows_f16(half_t* __restric
 __global__ void k_set_params(float* p, float t, float a_t, float a_prev, float g) {
   if (threadIdx.x == 0) { p[0] = t; p[1] = a_t; p[2] = a_prev; p[3] = g; }
 }
+// the same, and in the same launch a copy of `n16` 16-byte units src -> dst: the cached time-embedding row of this timestep goes into the
+// buffer the captured step reads (vision/unet.py:54-56, resnet.py:28 of the reference compute it afresh every step; it depends on t only)
+__global__ void __launch_bounds__(256) k_set_params_copy(float* p, float t, float a_t, float a_prev, float g, uint4* __restrict__ dst, const uint4* __restrict__ src, long long n16) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) { p[0] = t; p[1] = a_t; p[2] = a_prev; p[3] = g; }
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
 // out (1, dim) f16 = [cos(t f_i), sin(t f_i)], f_i = exp(-ln(max_period) i / half)   (vision/unet.py:92-97)
 __global__ void k_timestep_embedding(half_t* out, const float* params, int dim, float max_period) {
   int half_dim = dim / 2;
@@ -584,6 +590,17 @@ int tf_softmax_mask_rows_f32in_f16(void* out, int ldo, const void* inp_f32, int 
 int tf_set_step_params(void* step_params, float timestep, float a_t, float a_prev, float guidance, tfStream_t s) {
   TF_REQUIRE(step_params, "tf_set_step_params: null pointer");
   hipLaunchKernelGGL(k_set_params, dim3(1), dim3(64), 0, tf_hs(s), (float*)step_params, timestep, a_t, a_prev, guidance);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_set_step_params_copy(void* step_params, float timestep, float a_t, float a_prev, float guidance, void* dst, const void* src, long long nbytes, tfStream_t s) {
+  TF_REQUIRE(step_params && dst && src && nbytes >= 0 && nbytes % 16 == 0, "tf_set_step_params_copy: null pointer or nbytes=%lld not a multiple of 16", nbytes);
+  TF_REQUIRE((((uintptr_t)dst | (uintptr_t)src) & 15) == 0, "tf_set_step_params_copy: dst and src must be 16-byte aligned");
+  const long long n16 = nbytes / 16;
+  int grid = (int)((n16 + 255) / 256);
+  if (grid < 1) grid = 1;
+  if (grid > 64) grid = 64;
+  hipLaunchKernelGGL(k_set_params_copy, dim3(grid), dim3(256), 0, tf_hs(s), (float*)step_params, timestep, a_t, a_prev, guidance, (uint4*)dst, (const uint4*)src, n16);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }

@@ -517,9 +517,11 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
 // (tile, split-K, ring variant) on the caller's own buffers with HIP events and caches the winner.  Never runs
 // inside a stream capture (a captured shape that was never seen eagerly falls back to the cost model).
 #define TF_SPLITK_WS_CAP ((size_t)64 << 20)
-static bool g_autotune = true;
+static int g_autotune = 1;     // 0: cost model only; 1: a shape missing from the table is tuned on its first eager use; 2: table only -- a missing shape is an error (every rank of a multi-GPU run must pick the same kernels)
 struct TunedCfg { TileCfg c; int variant; int order; };   // variant: see launch_one
 static std::map<std::array<int, 10>, TunedCfg> g_tuned;
+static bool g_trace_keys = false;                       // tf_gemm_tune_trace: remember every shape key a launch looks up (tools/gemm_keys.py)
+static std::map<std::array<int, 10>, bool> g_traced;
 
 // untuned default for a launch that carries the input GroupNorm: the first admissible (tile, variant), split-K of the cost model
 static TunedCfg gi_default(const GemmP& p) {
@@ -676,11 +678,18 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     std::array<int, 10> key = {p.M, p.N, p.K, p.C1, p.C2, p.S, p.stride, p.ups, p.act,
                                (p.bias ? 1 : 0) | (p.residual ? 2 : 0) | (p.bias_nc ? 4 : 0) | (p.ln_colsum ? 8 : 0) | (p.gi_part ? 16 : 0) | (p.fp8 ? 64 : 0) | (p.out8 ? 128 : 0) | (p.out32 ? 256 : 0)};   // (on_z shares the plain key: same tile, another reduce kernel)
     auto it = g_tuned.find(key);
+    if (g_trace_keys) g_traced[key] = it != g_tuned.end();
     if (it != g_tuned.end()) {
       t = it->second; tuned = true;
       // a table row (shipped, or loaded from a user's file) whose tile cannot carry this launch's input GroupNorm -- the key holds
       // only a gi flag, not HoWo / H / W -- falls back to the first admissible tile instead of failing the forward
       if (p.gi_part && !gi_tile_ok(p, t.c.bm, t.c.bn, t.variant)) t = gi_default(p);
+    }
+    else if (g_autotune == 2) {
+      tf_set_error("run_gemm: shape M=%d N=%d K=%d C1=%d C2=%d S=%d stride=%d ups=%d act=%d flags=%d is not in the tuning table and tuning is off "
+                   "(tf_gemm_autotune(2): with WORLD_SIZE > 1 every rank must run the same kernels); tune it on one GPU (tools/tune_best.sh) and ship the row",
+                   key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7], key[8], key[9]);
+      return TF_E_STATE;
     }
     else {
       hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -775,7 +784,46 @@ int tf_gemm_debug(int flags) {
   g_force_order = (flags & 64) ? 1 : (flags & 32) ? 0 : -1;
   return TF_OK;
 }
-int tf_gemm_autotune(int on) { g_autotune = on != 0; if (!on) g_tuned.clear(); return TF_OK; }
+int tf_gemm_autotune(int mode) {
+  TF_REQUIRE(mode >= 0 && mode <= 2, "tf_gemm_autotune: mode=%d (0 cost model only, 1 tune missing shapes on first use, 2 table only: a missing shape is an error)", mode);
+  g_autotune = mode;
+  if (!mode) g_tuned.clear();
+  return TF_OK;
+}
+// host-side view of the table (no device work): what the launch of a shape would pick.  key = {M, N, K, C1, C2, S, stride, upsample, act, flags}
+// as tf_gemm_tune_save writes them, cfg = {bm, bn, splitk, variant, order}; TF_E_STATE when the shape has no row
+int tf_gemm_tune_query(const int* key, int* cfg) {
+  TF_REQUIRE(key && cfg, "tf_gemm_tune_query: null argument");
+  std::array<int, 10> k;
+  for (int i = 0; i < 10; ++i) k[i] = key[i];
+  auto it = g_tuned.find(k);
+  if (it == g_tuned.end()) { tf_set_error("tf_gemm_tune_query: shape M=%d N=%d K=%d has no row", key[0], key[1], key[2]); return TF_E_STATE; }
+  cfg[0] = it->second.c.bm; cfg[1] = it->second.c.bn; cfg[2] = it->second.c.splitk; cfg[3] = it->second.variant; cfg[4] = it->second.order;
+  return TF_OK;
+}
+// which shapes does a workload consult?  tf_gemm_tune_trace(1) starts remembering every key a launch looks up (and whether it had a row),
+// tf_gemm_tune_trace_dump writes them, one per line: the ten key fields and 1 / 0 (tools/gemm_keys.py -> tests/golden/gemm_keys.json)
+int tf_gemm_tune_trace(int on) { g_trace_keys = on != 0; if (on) g_traced.clear(); return TF_OK; }
+int tf_gemm_tune_trace_dump(const char* path) {
+  TF_REQUIRE(path, "tf_gemm_tune_trace_dump: null path");
+  FILE* f = fopen(path, "w");
+  TF_REQUIRE(f, "tf_gemm_tune_trace_dump: cannot open %s", path);
+  for (auto& kv : g_traced) {
+    for (int i = 0; i < 10; ++i) fprintf(f, "%d ", kv.first[i]);
+    fprintf(f, "%d\n", kv.second ? 1 : 0);
+  }
+  fclose(f);
+  return TF_OK;
+}
+int tf_gemm_tune_count(int* n) { TF_REQUIRE(n, "tf_gemm_tune_count: null argument"); *n = (int)g_tuned.size(); return TF_OK; }
+int tf_gemm_tune_entry(int index, int* key, int* cfg) {
+  TF_REQUIRE(key && cfg && index >= 0 && index < (int)g_tuned.size(), "tf_gemm_tune_entry: index %d out of range", index);
+  auto it = g_tuned.begin();
+  std::advance(it, index);
+  for (int i = 0; i < 10; ++i) key[i] = it->first[i];
+  cfg[0] = it->second.c.bm; cfg[1] = it->second.c.bn; cfg[2] = it->second.c.splitk; cfg[3] = it->second.variant; cfg[4] = it->second.order;
+  return TF_OK;
+}
 // persist / restore the tuner's choices (one line per shape) so that profiled or repeated runs skip the tuning launches
 int tf_gemm_tune_save(const char* path) {
   TF_REQUIRE(path, "tf_gemm_tune_save: null path");

@@ -93,3 +93,9 @@ hip = _Hip()
 _TUNE = os.environ.get("TF_GEMM_TUNE_TABLE", os.path.join(os.path.dirname(_HERE), "gemm_tune_gfx950.txt"))
 if _TUNE and os.path.exists(_TUNE):
     lib.tf_gemm_tune_load(_TUNE.encode())
+# One process per GPU: with several ranks every rank must pick the same kernels (bit-identical results across ranks, the same kernels in
+# every rank's timed region), so nothing is tuned at run time -- a shape without a row in the table is an error naming the shape
+# (TF_GEMM_AUTOTUNE=0/1/2 overrides: see tf_gemm_autotune in include/tinyfusers_hip.h)
+_mode = os.environ.get("TF_GEMM_AUTOTUNE", "2" if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 else "")
+if _mode:
+    check(lib.tf_gemm_autotune(int(_mode)), "tf_gemm_autotune")

@@ -121,14 +121,30 @@ class StableDiffusion:
         return self._latent
 
     # -- whole-step HIP graph ------------------------------------------------------------------------
-    def compile(self, unconditional_context, context, latent, stream=None, warmup=2):
+    def compile(self, unconditional_context, context, latent, stream=None, warmup=2, timesteps=None):
         """Capture one denoising step for these (static) buffers into a HIP graph.  Afterwards
-        ``step(timestep, a_t, a_prev, guidance)`` updates ``latent`` in place with one graph launch."""
+        ``step(timestep, a_t, a_prev, guidance)`` updates ``latent`` in place with one graph launch.
+
+        Step-invariant work stays out of the captured step (config.hoist_step_invariants): the cross-attention K|V projection of the
+        context runs here and in ``set_context`` -- it depends on the context alone -- and the time-embedding row of a timestep (the MLP
+        of unet.py:54-56 + the 22 ResBlock projections of resnet.py:28) is computed once per distinct timestep, kept in a table, and
+        handed to the replay by the launch that sets the step scalars.  ``timesteps``: the schedule, to fill the table up front."""
         self._stream = stream or Stream()
         self._latent, self._unc, self._ctx = latent, unconditional_context, context
         sp = self._step_params()
+        unet = self.model.diffusion_model
         with use_stream(self._stream):
             self._ctx2 = self._stack_context(unconditional_context, context)
+            self._kv_all, self._emb_cur, self._emb_rows, self._emb_key = None, None, {}, None
+            if config.hoist_step_invariants and not config.cfg_parallel:
+                self._kv_all = unet.context_kv(self._ctx2)
+                _, row = unet.time_embedding_all(sp.set(981.0))
+                self._emb_cur = DeviceArray.empty(row.shape, np.float16, "row")      # what the captured step reads
+                assert self._emb_cur.nbytes % 16 == 0
+                hip.tf_memcpy_async(self._emb_cur.ptr, row.ptr, row.nbytes, 3, _sh())   # (the warm-up steps below run at t = 981)
+                self._keep_row = row
+                for t in (timesteps if timesteps is not None else ()):
+                    self._emb_row(float(t))
             saved = DeviceArray.empty(latent.shape, np.float32, "row")
             hip.tf_memcpy_async(saved.ptr, latent.ptr, latent.nbytes, 3, _sh())
             for _ in range(warmup):                 # warms the pool and builds the lazily packed weights
@@ -177,7 +193,10 @@ class StableDiffusion:
             hip.tf_cfg_ddim_step2_f32(self._latent.ptr, out_u.ptr, out_c.ptr, sp.dev.ptr, b, c, h, w, _sh())
             self._keep = (x2, out_u, out_c, emb, emb_all, kv_all)
             return
-        out = unet(x2, sp, self._ctx2)
+        if getattr(self, "_emb_cur", None) is not None:
+            out = unet(x2, sp, self._ctx2, shared=(None, self._emb_cur, self._kv_all))     # (step() has put this timestep's row into _emb_cur)
+        else:
+            out = unet(x2, sp, self._ctx2)
         hip.tf_cfg_ddim_step_f32(self._latent.ptr, out.ptr, sp.dev.ptr, b, c, h, w, _sh())
         self._keep = (x2, out)      # graph nodes reference these blocks: keep them out of the pool
 
@@ -187,11 +206,43 @@ class StableDiffusion:
         the stream itself.  Work on other streams that touches the latent goes through set_latent() / synchronize()."""
         sp = self._params
         with use_stream(self._stream, ordered=False):
-            sp.set(timestep, a_t, a_prev, guidance)
+            if getattr(self, "_emb_cur", None) is not None:
+                row = self._emb_row(float(timestep))          # (computed on this stream the first time a timestep is seen)
+                hip.tf_set_step_params_copy(sp.dev.ptr, float(timestep), float(a_t), float(a_prev), float(guidance), self._emb_cur.ptr, row.ptr, row.nbytes, _sh())
+            else:
+                sp.set(timestep, a_t, a_prev, guidance)
             if eager or self._graph is None:
                 self._eager_step(sp)
             else:
                 hip.tf_graph_launch(self._graph, self._stream.handle)
+
+    def _emb_row(self, t):
+        """The cached time-embedding row of timestep t (keyed by the weights it was computed from; at most 1024 rows are kept)."""
+        unet = self.model.diffusion_model
+        key = unet.weights_key()
+        if self._emb_key != key:
+            self._emb_rows, self._emb_key = {}, key
+        row = self._emb_rows.get(t)
+        if row is None:
+            if len(self._emb_rows) >= 1024:
+                self._emb_rows.clear()
+            tmp = StepParams().set(t)
+            row = self._emb_rows[t] = unet.time_embedding_all(tmp)[1]
+            row._base = (row._base, tmp)
+        return row
+
+    def set_context(self, unconditional_context, context):
+        """New prompts for the compiled step: refresh the stacked context in place (the captured graph reads these buffers) and the
+        cross-attention K|V projection that was hoisted out of the step.  Ordered on the sampler stream."""
+        nb = context.nbytes
+        with use_stream(self._stream):
+            hip.tf_memcpy_async(self._ctx2.ptr, unconditional_context.ptr, nb, 3, _sh())
+            hip.tf_memcpy_async(self._ctx2.ptr + nb, context.ptr, nb, 3, _sh())
+            if getattr(self, "_kv_all", None) is not None:
+                kv = self.model.diffusion_model.context_kv(self._ctx2)
+                hip.tf_memcpy_async(self._kv_all.ptr, kv.ptr, kv.nbytes, 3, _sh())
+                self._kv_tmp = kv                                  # (referenced until the copy has run)
+        self._unc, self._ctx = unconditional_context, context
 
     def synchronize(self):
         self._stream.synchronize()

@@ -156,23 +156,37 @@ class UNetModel:
         self._batched = dict(key=key, emb_w=emb_w, emb_b=emb_b, emb_off=emb_off, kv_w=kv_w, kv_off=kv_off, kv_n=off)
         return self._batched
 
+    def time_embedding_all(self, timesteps):
+        """(emb, emb_all): the time-embedding chain of unet.py:54-56 and every ResBlock's Linear(SiLU(emb)) (resnet.py:28) as one row.  Both
+        depend on the timestep alone -- not on the latent, the context or the batch -- so a sampler may compute the row of a timestep once
+        and keep it (variants/sd.py here: StableDiffusion.compile(timesteps=...))."""
+        bt = self._prepare()
+        t_emb = timestep_embedding(timesteps, self.cfg.model_channels)
+        emb = self.time_embed[2](self.time_embed[0](t_emb), silu_input=True)          # Linear -> SiLU -> Linear
+        return emb, gemv_f16(emb, bt["emb_w"], bt["emb_b"], silu_input=True)          # every ResBlock's Linear(SiLU(emb))
+
+    def context_kv(self, context):
+        """Every cross-attention's K|V projection of the (stacked) context as ONE GEMM (attention/attention.py:35-36 for all 16 blocks):
+        depends on the context alone, so a sampler computes it when the context changes, not once per step."""
+        bt = self._prepare()
+        return linear_f16(context, bt["kv_w"]) if bt["kv_w"] is not None else None
+
+    def weights_key(self):
+        """Identity of everything time_embedding_all / context_kv depend on: a cached row is stale once any of these weights is replaced."""
+        return self._prepare()["key"] + tuple(m.weight.wkey for m in (self.time_embed[0], self.time_embed[2])) + tuple(m.bias.wkey for m in (self.time_embed[0], self.time_embed[2]))
+
     def step_shared(self, timesteps, context):
         """What one denoising step computes ONCE for every sample: the time-embedding chain (the same timestep for the whole batch) and
         the cross-attention K|V projection of all contexts.  __call__ computes them itself unless handed the result (``shared``)."""
-        cfg = self.cfg
-        bt = self._prepare()
-        t_emb = timestep_embedding(timesteps, cfg.model_channels)
-        emb = self.time_embed[2](self.time_embed[0](t_emb), silu_input=True)          # Linear -> SiLU -> Linear
-        emb_all = gemv_f16(emb, bt["emb_w"], bt["emb_b"], silu_input=True)            # every ResBlock's Linear(SiLU(emb))
-        kv_all = linear_f16(context, bt["kv_w"]) if bt["kv_w"] is not None else None  # every attn2's K|V of the context
-        return emb, emb_all, kv_all
+        emb, emb_all = self.time_embedding_all(timesteps)
+        return emb, emb_all, self.context_kv(context)
 
     def __call__(self, x, timesteps=None, context=None, shared=None):
         cfg = self.cfg
         bt = self._prepare()
         br = None
         if shared is not None:
-            emb, emb_all, kv_all = shared          # kv_all: this call's rows (b, tk, kv_n) of the step-level projection
+            emb, emb_all, kv_all = shared          # kv_all: this call's rows (b, tk, kv_n) of the step-level projection; emb may be None (emb_all is what the ResBlocks read)
         else:
             if config.parallel_branches and bt["kv_w"] is not None:
                 br = Branch()                          # the context projection is independent of the time-embedding chain

@@ -4,7 +4,7 @@
 R=$1; OLD=$2; shift 2
 mkdir -p gpurun_out
 one() {   # label, env assignment
-  ( export $2 TF_LIB_ALLOW_MISSING=1; exec python bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-roofline --no-e2e --no-config5 "${@:3}" > gpurun_out/ab.json 2> gpurun_out/ab.err )
+  ( export $2 TF_LIB_ALLOW_MISSING=1 TF_GEMM_AUTOTUNE=1; exec python bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-roofline --no-e2e --no-config5 "${@:3}" > gpurun_out/ab.json 2> gpurun_out/ab.err )
   python - "$1" <<'PY'
 import json, sys
 try:
@@ -14,6 +14,6 @@ except Exception as e:
 PY
 }
 for i in $(seq 1 $R); do
-  one "old[$i]" "TF_LIB_PATH=$OLD" "$@"
+  one "old[$i]" "TF_LIB_PATH=$OLD TF_HOIST_STEP_INVARIANTS=0" "$@"     # (an earlier round's library has no tf_set_step_params_copy)
   one "new[$i]" "TF_AB_DUMMY=1" "$@"
 done
