@@ -20,6 +20,46 @@ def quant_act(t):
     return ops.as_t(t).clamp(-448.0, 448.0).to(F8).to(torch.float32)
 
 
+MX_BLOCK = 32          # elements that share one E8M0 scale (the block of v_mfma_scale_f32_16x16x128_f8f6f4: 32 consecutive K values of a lane)
+
+
+def mx_scale_exponent(amax):
+    """Power-of-two block scale 2^e with amax / 2^e <= 448 (the largest e4m3 value): e = ceil(log2(amax / 448)), exact on the fp32 bits
+    (frexp), clamped to the E8M0 range [-127, 127]; a block of zeros gets e = -127.  The E8M0 byte is e + 127."""
+    a = ops.as_t(amax)
+    m, ex = torch.frexp(a / 448.0)                          # a / 448 = m * 2^ex, m in [0.5, 1)
+    e = torch.where(m == 0.5, ex - 1, ex)                   # exact powers of two need no round-up
+    e = torch.where(a > 0, e, torch.full_like(e, -127))
+    return e.clamp(-127, 127)
+
+
+def quant_act_mx(t, channel_dim=-1):
+    """activation operand of the block-scaled e4m3 GEMMs as the HIP producers store it: along the channel axis, every MX_BLOCK consecutive
+    channels of one pixel / token share one power-of-two scale 2^e (mx_scale_exponent of the block's largest magnitude); elements are
+    e4m3(x / 2^e), round to nearest even -- no saturation can occur.  Returns the dequantised tensor (fp32)."""
+    t = ops.as_t(t)
+    x = t.movedim(channel_dim, -1)
+    sh = x.shape
+    assert sh[-1] % MX_BLOCK == 0, sh
+    xb = x.reshape(*sh[:-1], sh[-1] // MX_BLOCK, MX_BLOCK)
+    e = mx_scale_exponent(xb.abs().amax(-1, keepdim=True))
+    s = torch.ldexp(torch.ones_like(xb[..., :1]), e)
+    q = (xb / s).to(F8).to(torch.float32) * s
+    return q.reshape(sh).movedim(-1, channel_dim)
+
+
+def quant_act_mx_codes(t, channel_dim=-1):
+    """(e4m3 codes as uint8, E8M0 scale bytes as uint8) of quant_act_mx, channel axis last: what the device tensors hold."""
+    t = ops.as_t(t)
+    x = t.movedim(channel_dim, -1)
+    sh = x.shape
+    xb = x.reshape(*sh[:-1], sh[-1] // MX_BLOCK, MX_BLOCK)
+    e = mx_scale_exponent(xb.abs().amax(-1, keepdim=True))
+    s = torch.ldexp(torch.ones_like(xb[..., :1]), e)
+    codes = (xb / s).to(F8).view(torch.uint8).reshape(sh)
+    return codes.numpy(), (e.squeeze(-1) + 127).to(torch.uint8).numpy()
+
+
 def quant_weight(w):
     """(dequantised weight, scale per output channel): scale = max|w[n]| / 448, w8 = e4m3(w / scale)."""
     w = ops.as_t(w)
