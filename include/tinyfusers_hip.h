@@ -116,6 +116,27 @@ int tf_group_norm_apply_fp8(void* y8, const void* x, const void* x2, const void*
                             tfStream_t s);
 int tf_layer_norm_fp8(void* y8, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s);
 
+/* ---- block-scaled e4m3 activations (round 4; the same reference ops: vision/conv2d.py:9-28, ff/linear.py:112-121, ff/group_norm.py:13-21,
+ * ff/layer_norm.py:34-49, ff/nn.py:5-12).  An "mx8" tensor is ONE buffer: rows x C e4m3 codes (row = pixel / token, NHWC), then rows x C/32
+ * E8M0 bytes: every 32 consecutive channels of a row share the power-of-two scale 2^(byte - 127) with amax / 2^e <= 448, code = e4m3(x / 2^e)
+ * (round to nearest even, no saturation).  The GEMM feeds the bytes to the scale operand of v_mfma_scale_f32_16x16x128_f8f6f4; weights keep
+ * tf_pack_weight_fp8's one fp32 scale per output channel.  The kernel is the 192- / 256-row ping-pong kernel: tf_mx8_gemm_supported /
+ * tf_mx8_conv_supported say whether a shape fills the chip with its tiles (stride-1 convolutions without up-sampling, linears) -- a caller
+ * keeps fp16 operands otherwise; an unsupported launch returns 10002.  out_mx: the GEGLU output (act = 1) as an mx8 tensor of M x N. */
+size_t tf_mx8_bytes(long long rows, int C);
+int tf_quantize_mx8_f16(void* y_mx, const void* x, long long rows, int C, tfStream_t s);
+int tf_group_norm_apply_mx8(void* y_mx, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial, int chunks,
+                            int groups1, const void* partial2, int chunks2, int groups2, int N, int HW, int C1, int C2, int G, float eps, int silu,
+                            tfStream_t s);
+int tf_layer_norm_mx8(void* y_mx, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s);
+int tf_mx8_gemm_supported(int M, int N, int K, int act, int out_mx);
+int tf_mx8_conv_supported(int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample);
+int tf_conv2d_mx8(void* y, const void* x_mx, const void* x2_mx, const void* w8, const void* wscale, const void* bias, const void* bias_nc,
+                  long long bias_nc_stride, const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad,
+                  void* workspace, size_t workspace_bytes, void* gn_partial, size_t gn_partial_bytes, int gn_groups, int* gn_chunks, tfStream_t s);
+int tf_linear_mx8(void* y, const void* x_mx, const void* w8, const void* wscale, const void* bias, const void* residual, int M, int N, int K, int act,
+                  int out_mx, void* workspace, size_t workspace_bytes, tfStream_t s);
+
 /* ---- multi-GPU: one process per GPU, the path shards by image, and the only exchange is the one-off broadcast of
  * the packed weight arena.  The reference has no communication (device_id = 0, storage/device.py:23).  RCCL over xGMI, opened on
  * first use.  tf_comm_unique_id: rank 0 fills 128 bytes and hands them to the other ranks over any host channel; every rank then

@@ -196,8 +196,10 @@ def test_clip_text_transformer_vs_huggingface():
 @pytest.mark.slow
 def test_fp8_layer_policy_meets_the_config5_gate_on_the_oracle():
     """BASELINE config 5's precision gate (UNet rel-L2 <= 0.1 vs fp32) for the layer policy the HIP path implements: e4m3 operands for
-    the 3x3 convolutions (Cin, Cout >= 64) and the FeedForward linears, per-output-channel weight scales, activation scale 1 --
-    evaluated on the CPU oracle with e4m3 emulation (oracle/fp8.py)."""
+    the ResBlocks' 3x3 convolutions, the FeedForward pair and the attention projections (K >= 640), per-output-channel weight scales,
+    block-scaled activations -- evaluated on the CPU oracle with e4m3 emulation (oracle/fp8.py) at every shape of a batch-2 forward
+    (assume_supported: on the device the kernel takes these layers at config 5's row counts); with the shape rule of the device a batch-2
+    forward at 64 x 64 quantises only the first level's convolutions; the contexts restore the fp32 functions."""
     import oracle
     from oracle import fp8 as O8
     from tinyfusers_amd.storage.synth import synth_normal, synth_state_dict
@@ -205,9 +207,15 @@ def test_fp8_layer_policy_meets_the_config5_gate_on_the_oracle():
     x = torch.from_numpy(synth_normal(1234, "sd.latent", (1, 4, 64, 64))).repeat(2, 1, 1, 1)
     ctx = torch.from_numpy(np.concatenate([synth_normal(1234, "sd.uncond", (1, 77, 768)), synth_normal(1234, "sd.context", (1, 77, 768))]))
     ref = oracle.unet_forward(x, np.array([981.0], np.float32), ctx, W)
-    with O8.policy():
+    with O8.policy(assume_supported=True):
         got = oracle.unet_forward(x, np.array([981.0], np.float32), ctx, W)
+    with O8.policy():
+        part = oracle.unet_forward(x, np.array([981.0], np.float32), ctx, W)
     again = oracle.unet_forward(x, np.array([981.0], np.float32), ctx, W)
-    assert torch.equal(again, ref)                         # the policy context restored the fp32 functions
+    assert torch.equal(again, ref)                         # the policy contexts restored the fp32 functions
+    # with the device's shape rule fewer layers qualify at 8192 rows (the 320-channel convs do, on the 192 x 128 tile: 43 x 3 = 129 blocks)
+    assert 0.0 < float((part - ref).norm() / ref.norm()) < float((got - ref).norm() / ref.norm())
+    assert O8.mx_gemm_supported(8 * 9216, 320, 2880, howo=9216, c_parts=(320,)) and not O8.mx_gemm_supported(8 * 144, 1280, 11520, howo=144)
+    assert O8.mx_gemm_supported(8192, 320, 2880, howo=4096, c_parts=(320,)) and not O8.mx_gemm_supported(2048, 640, 5760, howo=1024)
     rl2 = float((got - ref).norm() / ref.norm())
     assert 0.01 < rl2 <= 0.1, rl2

@@ -103,15 +103,30 @@ class CrossAttention:
         b, t, _ = x.shape
         nh, hs = self.num_heads, self.head_size
         c = nh * hs
+        from ..ff import fp8
+        # config 5: the projections on block-scaled e4m3 operands where the kernel takes the shape (ff/fp8.py: K >= 640 levels) -- LayerNorm written
+        # as an mx8 tensor instead of folded, the attention output quantised in one pass in front of to_out
+        mx_in = ln is not None and fp8.linear_ok(b * t, 3 * c if (context is None and kv is None) else c, x.shape[-1])
+        if mx_in:
+            if getattr(self, "_cache8", None) is None:
+                self._cache8 = {"qkv": {}, "q": {}, "out": {}}
+            x8 = fp8.layer_norm_mx(x, ln)
         if context is None and kv is None:
-            if ln is not None:
+            if mx_in:
+                w8, wsc = fp8.pack_weight(self._fused_weights(True), self._cache8["qkv"])
+                qkv = fp8.linear_mx(x8, w8, wsc, None)
+            elif ln is not None:
                 qkv = linear_ln_f16(x, self._folded(ln, True), ln.eps)
             else:
                 qkv = linear_f16(x, self._fused_weights(True))        # (b, t, 3C): q | k | v
             q, k, v = qkv, qkv.view((b, t, 3 * c), "row", c), qkv.view((b, t, 3 * c), "row", 2 * c)
             tk, qs, ks = t, (t * 3 * c, hs, 3 * c), (t * 3 * c, hs, 3 * c)
         else:
-            q = linear_ln_f16(x, self._folded(ln, False), ln.eps) if ln is not None else linear_f16(x, self.to_q.weight)
+            if mx_in:
+                w8, wsc = fp8.pack_weight(self.to_q.weight, self._cache8["q"])
+                q = fp8.linear_mx(x8, w8, wsc, None)
+            else:
+                q = linear_ln_f16(x, self._folded(ln, False), ln.eps) if ln is not None else linear_f16(x, self.to_q.weight)
             if kv is None:
                 kv = self.project_kv(context)
             if hasattr(kv, "ld"):                          # column slice of the UNet's step-level K|V GEMM
@@ -128,7 +143,13 @@ class CrossAttention:
         else:
             os_ = (t * c, hs, c)                 # LDM-intended merge
         sdpa_strided(o, q, k, v, b, nh, t, tk, hs, qs, ks, ks, os_)
-        return self.to_out[0](o, residual=residual)
+        lo = self.to_out[0]
+        if fp8.linear_ok(b * t, lo.weight.shape[0], c):
+            if getattr(self, "_cache8", None) is None:
+                self._cache8 = {"qkv": {}, "q": {}, "out": {}}
+            w8, wsc = fp8.pack_weight(lo.weight, self._cache8["out"])
+            return fp8.linear_mx(fp8.quantize_mx(o), w8, wsc, lo.bias, residual=residual)
+        return lo(o, residual=residual)
 
 
 class BasicTransformerBlock:

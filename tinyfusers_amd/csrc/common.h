@@ -73,5 +73,28 @@ __device__ __forceinline__ uint2 pack8_fp8(f4 v0, f4 v1) {
   return make_uint2((unsigned)lo, (unsigned)hi);
 }
 
+// ---- block-scaled e4m3 ("MX") activation tensors: what feeds v_mfma_scale_f32_16x16x128_f8f6f4 on the activation side.  One buffer per
+// tensor: rows x C e4m3 codes (row = pixel / token, C % 32 == 0), followed by rows x C/32 E8M0 scale bytes -- every 32 consecutive channels
+// of a row share one power-of-two scale 2^e with amax / 2^e <= 448, e = ceil(log2(amax / 448)); code = e4m3(x / 2^e), round to nearest even
+// (no saturation can occur); a block of zeros has byte 0 (2^-127).  oracle/fp8.py::quant_act_mx restates it.
+//   mx_quant8: this lane's 8 consecutive channels; the lanes l ^ 1, l ^ 2 hold the other 24 of the block (EVERY lane of the wave must call).
+__device__ __forceinline__ uint2 mx_quant8(f4 v0, f4 v1, unsigned& scale_byte) {
+  float a = fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))), fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
+  a = fmaxf(a, __shfl_xor(a, 1, 64));
+  a = fmaxf(a, __shfl_xor(a, 2, 64));
+  const unsigned bits = __float_as_uint(a / 448.0f);      // (IEEE division: the same quotient as the oracle's)
+  const unsigned E = bits >> 23, M = bits & 0x7fffffu;    // a >= 0: no sign bit
+  unsigned byte = E == 0 ? 0u : (M ? E + 1u : E);         // e = ceil(log2(a / 448)), biased by 127; zero / subnormal quotient -> 2^-127
+  byte = byte > 254u ? 254u : byte;
+  scale_byte = byte;
+  const int ne = 127 - (int)byte;                         // x * 2^(-e)
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(v0[0], ne), ldexpf(v0[1], ne), lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(v0[2], ne), ldexpf(v0[3], ne), lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(v1[0], ne), ldexpf(v1[1], ne), hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(v1[2], ne), ldexpf(v1[3], ne), hi, true);
+  return make_uint2((unsigned)lo, (unsigned)hi);
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }

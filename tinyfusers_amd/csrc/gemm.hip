@@ -247,6 +247,26 @@ __global__ void __launch_bounds__(256) k_quantize_fp8(unsigned char* __restrict_
     *reinterpret_cast<uint2*>(y + i * 8) = pack8_fp8(a, b);
   }
 }
+// block-scaled form (common.h: mx_quant8): rows x C fp16 -> rows x C codes + rows x C/32 E8M0 bytes behind them; a thread = 8 channels, 4 lanes = a block
+__global__ void __launch_bounds__(256) k_quantize_mx8(unsigned char* __restrict__ y, const half_t* __restrict__ x, long long rows, int C) {
+  const long long n8 = rows * (C >> 3), gs = (long long)gridDim.x * 256;
+  const int cv8 = C >> 3;
+  for (long long i0 = (long long)blockIdx.x * 256; i0 < n8; i0 += gs) {       // (block-uniform loop bound: every lane reaches the shuffles)
+    const long long i = i0 + threadIdx.x;
+    const bool live = i < n8;
+    f4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      h8 v = *reinterpret_cast<const h8*>(x + i * 8);
+      for (int e = 0; e < 4; ++e) { a[e] = (float)v[e]; b[e] = (float)v[4 + e]; }
+    }
+    unsigned sb;
+    const uint2 code = mx_quant8(a, b, sb);
+    if (live) {
+      *reinterpret_cast<uint2*>(y + i * 8) = code;
+      if ((i & 3) == 0) { const long long row = i / cv8; y[rows * C + row * (C >> 5) + ((i - row * cv8) >> 2)] = (unsigned char)sb; }
+    }
+  }
+}
 // weights: one wave per output row n: scale[n] = max|w[n, :]| / 448 (1 for an all-zero row), w8[n, k] = e4m3(w[n, k] / scale[n])
 __global__ void __launch_bounds__(256) k_pack_weight_fp8(unsigned char* __restrict__ w8, float* __restrict__ scale, const half_t* __restrict__ w, int N, int K) {
   int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -400,7 +420,14 @@ static bool pp_ok(const GemmP& p, int bn, int bm = 256) {
   if (bm != 256 && !(bm == 192 && bn != 256)) return false;
   if (p.bf16 || p.gi_part || gemm_generic(p)) return false;
   if (p.ln_colsum && (p.fp8 || p.S != 1 || p.stride != 1 || p.ups)) return false;   // the LayerNorm fold: linears, fp16
-  if (p.fp8 && bn == 256) return false;                  // the e4m3 form holds a whole K tile's fragments: needs the three-slot ring
+  if (p.fp8) {
+    // the e4m3 form: block-scaled activations only, the lean addressing only (stride 1, no up-sampling), a whole K tile's fragments in
+    // registers (three-slot ring: no 256-wide tile), and room for the scale table behind the ring (not 256 x 160 with half-tile slabs)
+    if (!p.mx || bn == 256 || p.stride != 1 || p.ups || p.S * p.S > 31 || p.C3 || p.C4) return false;
+    const bool h2 = (p.C1 % 128) || (p.C2 % 128);
+    if (bm == 256 && bn == 160 && h2) return false;
+    if (p.out8 && !(p.act == 1 && bn == 128)) return false;   // a block-scaled output: the GEGLU epilogue of the 128-wide tile
+  }
   if (p.bias_nc && p.HoWo < bm) return false;            // the epilogue's time-embedding table holds two images per tile
   return p.act != 1 || bn % 64 == 0;                     // GEGLU pairs 16-row value | gate blocks inside a wave tile
 }
@@ -462,6 +489,7 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
     else p.gn_chunks = gn_pieces(p, c.bn) * (p.HoWo / stats_bm(c.bm, variant));
   }
   if (p.bf16) rc = tfk_launch_igemm_bf16(p, st, c.bm, c.bn);
+  else if (p.mx && variant != 4) { tf_set_error("run_gemm: block-scaled e4m3 operands run on the ping-pong kernel only (variant %d, tile %dx%d)", variant, c.bm, c.bn); return TF_E_UNSUPPORTED; }
   else if (p.fp8 && variant != 4) rc = tfk_launch_igemm8(p, st, c.bm, c.bn);
   else if (variant == 4) {
     if (!pp_ok(p, c.bn, c.bm)) { tf_set_error("run_gemm: the ping-pong kernel cannot run tile %dx%d of this launch", c.bm, c.bn); return TF_E_UNSUPPORTED; }
@@ -538,6 +566,22 @@ static TunedCfg gi_default(const GemmP& p) {
   return {m, 0, 0};
 }
 
+// block-scaled e4m3 launches: which (tile, split) of the ping-pong kernel a launch gets without a table row; tile.bm = 0 when none can take it
+static TunedCfg mx_default(const GemmP& p) {
+  static const int cand[][2] = {{192, 160}, {192, 128}, {256, 128}, {256, 160}};
+  TunedCfg best = {{0, 0, 1}, 4, 0};
+  long long best_blocks = -1;
+  for (int ci = 0; ci < 4; ++ci) {
+    const int bm = cand[ci][0], bn = cand[ci][1];
+    if (!pp_ok(p, bn, bm)) continue;
+    if (bn == 160 && p.N % 160 != 0 && p.N % 128 == 0) continue;
+    const long long blocks = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+    const long long waste = (long long)((p.M + bm - 1) / bm) * bm * (long long)((p.N + bn - 1) / bn) * bn - (long long)p.M * p.N;
+    if (best_blocks < 0 || waste < best_blocks) { best_blocks = waste; best = {{bm, bn, 1}, 4, 0}; }
+    (void)blocks;
+  }
+  return best;
+}
 #define TF_FLUSH_BYTES ((size_t)384 << 20)
 static void* g_flush = nullptr;
 static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hipStream_t st, TunedCfg* out) {
@@ -548,7 +592,8 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
   float best = 1e30f;
   TunedCfg bc = {choose_tiles(p.M, p.N, p.K, p.act, true), 0, 0};
   if (p.gi_part) bc = gi_default(p);
-  for (int ci = 0; ci < (p.fp8 ? kNumTiles8 : 7); ++ci) {
+  if (p.mx) bc = mx_default(p);
+  for (int ci = 0; ci < (p.mx ? 0 : p.fp8 ? kNumTiles8 : 7); ++ci) {        // (block-scaled launches have the ping-pong kernel only: below)
     int bm = p.fp8 ? kTiles8[ci][0] : cand[ci][0], bn = p.fp8 ? kTiles8[ci][1] : cand[ci][1];
     if (p.act == 1 && (bn % 64) != 0) continue;
     if (bm >= 128 && p.M <= 64) continue;
@@ -660,10 +705,18 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
   TunedCfg t = {choose_tiles(p.M, p.N, p.K, p.act, true), 0, 0};
   bool tuned = false;
   if (p.gi_part) { t = gi_default(p); tuned = true; }    // (tuned: keep gi_default's variant unless the tuner knows better)
-  if (p.fp8) {                                            // untuned fp8 default: the widest tile that still gives every CU a block
+  TunedCfg fp8_default = t;
+  if (p.fp8 && !p.mx) {                                   // untuned fp8 default: the widest tile that still gives every CU a block
     long long b128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     t.c = {p.M >= 128 ? 128 : 64, p.act == 1 || p.N >= 128 ? 128 : 64, b128 >= 128 ? 1 : t.c.splitk};
     t.variant = 0; tuned = true;
+    fp8_default = t;
+  }
+  if (p.mx) {                                             // block-scaled e4m3: the ping-pong kernel or nothing (tf_mx8_gemm_supported tells a caller beforehand)
+    t = mx_default(p);
+    if (!t.c.bm) { tf_set_error("run_gemm: no block-scaled e4m3 kernel for M=%d N=%d K=%d (S=%d stride=%d ups=%d act=%d): ask tf_mx8_gemm_supported first", p.M, p.N, p.K, p.S, p.stride, p.ups, p.act); return TF_E_UNSUPPORTED; }
+    tuned = true;
+    fp8_default = t;
   }
   if (p.bf16) {                                           // two tiles, no tuner: 128 x 128 once that gives every CU a block, else 64 x 64
     long long b128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
@@ -676,7 +729,7 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     if (p.gi_part) t.variant = p.S == 3 ? 2 : 0;
   } else if (g_autotune && !g_dbg) {
     std::array<int, 10> key = {p.M, p.N, p.K, p.C1, p.C2, p.S, p.stride, p.ups, p.act,
-                               (p.bias ? 1 : 0) | (p.residual ? 2 : 0) | (p.bias_nc ? 4 : 0) | (p.ln_colsum ? 8 : 0) | (p.gi_part ? 16 : 0) | (p.fp8 ? 64 : 0) | (p.out8 ? 128 : 0) | (p.out32 ? 256 : 0)};   // (on_z shares the plain key: same tile, another reduce kernel)
+                               (p.bias ? 1 : 0) | (p.residual ? 2 : 0) | (p.bias_nc ? 4 : 0) | (p.ln_colsum ? 8 : 0) | (p.gi_part ? 16 : 0) | (p.fp8 ? 64 : 0) | (p.out8 ? 128 : 0) | (p.out32 ? 256 : 0) | (p.mx ? 512 : 0)};   // (on_z shares the plain key: same tile, another reduce kernel)
     auto it = g_tuned.find(key);
     if (g_trace_keys) g_traced[key] = it != g_tuned.end();
     if (it != g_tuned.end()) {
@@ -684,6 +737,9 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
       // a table row (shipped, or loaded from a user's file) whose tile cannot carry this launch's input GroupNorm -- the key holds
       // only a gi flag, not HoWo / H / W -- falls back to the first admissible tile instead of failing the forward
       if (p.gi_part && !gi_tile_ok(p, t.c.bm, t.c.bn, t.variant)) t = gi_default(p);
+      // e4m3 rows: a fixed-scale launch has k_igemm8 only, a block-scaled one the ping-pong kernel only -- a row that says otherwise (an
+      // older table, a user's file) falls back to the default instead of failing the forward
+      if (p.fp8 && ((t.variant == 4) != (p.mx != 0) || (p.mx && !pp_ok(p, t.c.bn, t.c.bm)))) t = fp8_default;
     }
     else if (g_autotune == 2) {
       tf_set_error("run_gemm: shape M=%d N=%d K=%d C1=%d C2=%d S=%d stride=%d ups=%d act=%d flags=%d is not in the tuning table and tuning is off "
@@ -1232,6 +1288,101 @@ int tf_linear_fp8(void* y, const void* x8, const void* w8, const void* wscale, c
   {
     long long xb = (long long)M * K, wb = (long long)p.N * K;
     TF_REQUIRE(xb < (1LL << 31) && wb < (1LL << 31), "tf_linear_fp8: tensors must be < 2 GiB each");
+    p.x_bytes = (unsigned)xb; p.x2_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb; p.x3_bytes = p.x4_bytes = (unsigned)xb;
+  }
+  if (p.out8) workspace = nullptr, workspace_bytes = 0;   // the split-K reduce writes fp16: an e4m3 output runs unsplit
+  return run_gemm(p, workspace, workspace_bytes, g_force_bm, g_force_bn, g_force_split, tf_hs(s));
+}
+
+// ---- block-scaled e4m3 activations (round 4): one E8M0 scale per 32 consecutive channels of a pixel / token, fed to the scale operand of
+// v_mfma_scale_f32_16x16x128_f8f6f4.  An "mx8" tensor is ONE buffer: rows x C codes, then rows x C/32 scale bytes (tf_mx8_bytes).
+size_t tf_mx8_bytes(long long rows, int C) { return rows > 0 && C > 0 ? (size_t)rows * C + (size_t)rows * (C / 32) : 0; }
+int tf_quantize_mx8_f16(void* y_mx, const void* x, long long rows, int C, tfStream_t s) {
+  TF_REQUIRE(y_mx && x && rows >= 0 && C > 0 && C % 32 == 0, "tf_quantize_mx8_f16: C=%d must be a positive multiple of 32", C);
+  if (rows == 0) return TF_OK;
+  long long n8 = rows * (C / 8), grid = (n8 + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_quantize_mx8, dim3((unsigned)grid), dim3(256), 0, tf_hs(s), (unsigned char*)y_mx, (const half_t*)x, rows, C);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+// does the block-scaled kernel take a GEMM of M rows (pixels / tokens) x N outputs x K?  It is the ping-pong kernel: launches that fill the chip
+// with its 192- / 256-row tiles (BASELINE config 5's regime); stride-1 convolutions without up-sampling and linears; callers keep fp16 otherwise
+static bool mx_shape_ok(const GemmP& p) {
+  if (p.M <= 256 || p.K % 64 || p.N % 8) return false;
+  TunedCfg d = mx_default(p);
+  if (!d.c.bm) return false;
+  static const int cand[][2] = {{192, 160}, {192, 128}, {256, 128}, {256, 160}};
+  for (int ci = 0; ci < 4; ++ci)
+    if (pp_ok(p, cand[ci][1], cand[ci][0]) && (long long)((p.M + cand[ci][0] - 1) / cand[ci][0]) * ((p.N + cand[ci][1] - 1) / cand[ci][1]) >= 128) return true;
+  return false;
+}
+int tf_mx8_gemm_supported(int M, int N, int K, int act, int out_mx) {
+  if (M < 1 || N < 1 || K < 64) return 0;
+  GemmP p = {};
+  p.fp8 = 1; p.mx = 1; p.out8 = out_mx ? 1 : 0; p.act = act;
+  p.M = M; p.N = act == 1 ? 2 * N : N; p.K = K; p.Kc = K; p.C1 = K; p.C = K; p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.HoWo = M; p.S = 1; p.stride = 1;
+  return mx_shape_ok(p) ? 1 : 0;
+}
+int tf_mx8_conv_supported(int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample) {
+  int Ho, Wo;
+  if (N < 1 || C1 < 64 || C2 < 0 || R != S || stride != 1 || upsample || (C1 % 64) || (C2 % 64) || conv_geometry(H, W, R, S, stride, pad, 0, &Ho, &Wo)) return 0;
+  GemmP p = {};
+  p.fp8 = 1; p.mx = 1;
+  p.M = N * Ho * Wo; p.N = Cout; p.C1 = C1; p.C2 = C2; p.C = C1 + C2; p.Kc = R * S * p.C; p.K = p.Kc;
+  p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.HoWo = Ho * Wo; p.S = S; p.stride = 1; p.pad = pad;
+  p.bias_nc = (const half_t*)&p;                            // (the ResBlock convs carry a time-embedding bias: the stricter tile rule)
+  return mx_shape_ok(p) ? 1 : 0;
+}
+int tf_conv2d_mx8(void* y, const void* x_mx, const void* x2_mx, const void* w8, const void* wscale, const void* bias, const void* bias_nc,
+                  long long bias_nc_stride, const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad,
+                  void* workspace, size_t workspace_bytes, void* gn_partial, size_t gn_partial_bytes, int gn_groups, int* gn_chunks, tfStream_t s) {
+  if (gn_chunks) *gn_chunks = 0;
+  TF_REQUIRE(y && x_mx && w8 && wscale, "tf_conv2d_mx8: null tensor");
+  TF_REQUIRE(C1 > 0 && C2 >= 0 && (C2 == 0 || x2_mx) && C1 % 64 == 0 && C2 % 64 == 0, "tf_conv2d_mx8: channel counts must be multiples of 64 (C1=%d C2=%d)", C1, C2);
+  TF_REQUIRE(R >= 1 && R == S && stride == 1 && pad >= 0 && Cout >= 1 && N >= 0, "tf_conv2d_mx8: stride-1 square filters only (R=%d S=%d stride=%d pad=%d)", R, S, stride, pad);
+  TF_REQUIRE(!gn_partial || gn_chunks, "tf_conv2d_mx8: gn_chunks must be given with gn_partial");
+  int Ho, Wo;
+  TF_REQUIRE(!conv_geometry(H, W, R, S, stride, pad, 0, &Ho, &Wo), "tf_conv2d_mx8: empty output for H=%d W=%d", H, W);
+  if (N == 0) return TF_OK;
+  TF_REQUIRE((long long)N * Ho * Wo < (1LL << 31), "tf_conv2d_mx8: problem too large for 32-bit indexing");
+  GemmP p = {};
+  p.fp8 = 1; p.mx = 1; p.wscale = (const float*)wscale;
+  p.x = (const half_t*)x_mx; p.x2 = (const half_t*)x2_mx; p.w = (const half_t*)w8; p.y = (half_t*)y;
+  p.bias = (const half_t*)bias; p.bias_nc = (const half_t*)bias_nc; p.residual = (const half_t*)residual; p.bias_nc_stride = bias_nc_stride;
+  TF_REQUIRE(bias_nc_stride % 4 == 0 || Cout % 4 != 0, "tf_conv2d_mx8: bias_nc_stride must be a multiple of 4");
+  p.M = N * Ho * Wo; p.N = Cout; p.C1 = C1; p.C2 = C2; p.C = C1 + C2; p.Kc = R * S * p.C; p.K = p.Kc;
+  p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.HoWo = Ho * Wo; p.S = S; p.stride = stride; p.pad = pad; p.ups = 0;
+  {
+    long long xb = (long long)N * H * W * C1, x2b = (long long)N * H * W * C2, wb = (long long)Cout * p.K;
+    TF_REQUIRE(xb + xb / 32 < (1LL << 31) && x2b + x2b / 32 < (1LL << 31) && wb < (1LL << 31), "tf_conv2d_mx8: tensors must be < 2 GiB each");
+    p.x_bytes = (unsigned)xb; p.x2_bytes = C2 ? (unsigned)x2b : (unsigned)xb; p.w_bytes = (unsigned)wb;     // (the codes; the scale bytes sit behind them)
+    p.x3_bytes = p.x4_bytes = (unsigned)xb;
+  }
+  if (gn_partial) {
+    TF_REQUIRE(gn_groups >= 1 && Cout % gn_groups == 0, "tf_conv2d_mx8: Cout=%d not divisible by groups=%d", Cout, gn_groups);
+    TF_REQUIRE(gn_partial_bytes >= tf_conv2d_gn_partial_bytes(N, gn_groups), "tf_conv2d_mx8: statistics buffer too small (%zu bytes)", gn_partial_bytes);
+    int cpg = Cout / gn_groups;
+    if (cpg >= 4 && cpg <= 64 && Cout % 8 == 0 && Cout <= 4096 && gn_groups <= 256) { p.gn_part = (float*)gn_partial; p.gn_G = gn_groups; p.gn_cpg = cpg; }
+  }
+  return run_gemm(p, workspace, workspace_bytes, g_force_bm, g_force_bn, g_force_split, tf_hs(s), gn_chunks);
+}
+int tf_linear_mx8(void* y, const void* x_mx, const void* w8, const void* wscale, const void* bias, const void* residual, int M, int N, int K, int act,
+                  int out_mx, void* workspace, size_t workspace_bytes, tfStream_t s) {
+  TF_REQUIRE(y && x_mx && w8 && wscale, "tf_linear_mx8: null tensor");
+  TF_REQUIRE(M >= 0 && N >= 1 && K >= 64 && K % 64 == 0, "tf_linear_mx8: K=%d must be a positive multiple of 64", K);
+  TF_REQUIRE(act == 0 || act == 1, "tf_linear_mx8: act=%d", act);
+  TF_REQUIRE(act == 0 || (bias && N % 16 == 0), "tf_linear_mx8: GEGLU needs a bias and N %% 16 == 0 (N=%d)", N);
+  TF_REQUIRE(!out_mx || (act == 1 && N % 32 == 0 && !residual), "tf_linear_mx8: a block-scaled output is the GEGLU epilogue's (act = 1, N %% 32 == 0, no residual; N=%d)", N);
+  if (M == 0) return TF_OK;
+  GemmP p = {};
+  p.fp8 = 1; p.mx = 1; p.wscale = (const float*)wscale; p.out8 = out_mx ? 1 : 0;
+  p.x = (const half_t*)x_mx; p.w = (const half_t*)w8; p.y = (half_t*)y; p.bias = (const half_t*)bias; p.residual = (const half_t*)residual;
+  p.M = M; p.N = act == 1 ? 2 * N : N; p.K = K; p.Kc = K; p.C1 = K; p.C2 = 0; p.C = K;
+  p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.HoWo = M; p.S = 1; p.stride = 1; p.pad = 0; p.ups = 0; p.act = act;
+  {
+    long long xb = (long long)M * K, wb = (long long)p.N * K;
+    TF_REQUIRE(xb + xb / 32 < (1LL << 31) && wb < (1LL << 31), "tf_linear_mx8: tensors must be < 2 GiB each");
     p.x_bytes = (unsigned)xb; p.x2_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb; p.x3_bytes = p.x4_bytes = (unsigned)xb;
   }
   if (p.out8) workspace = nullptr, workspace_bytes = 0;   // the split-K reduce writes fp16: an e4m3 output runs unsplit

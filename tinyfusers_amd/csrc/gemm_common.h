@@ -65,6 +65,10 @@ struct GemmP {
   // weight scale applied to the fp32 accumulators in the epilogue (activations use scale 1: normalised tensors); out8: y is stored as
   // e4m3 as well (the GEGLU output that feeds the next fp8 GEMM)
   const float* wscale; int out8, fp8;
+  // mx: the e4m3 ACTIVATIONS are block scaled (common.h: mx_quant8) -- x / x2 hold their E8M0 bytes behind their codes (x_bytes / x2_bytes stay
+  // the codes' byte counts) -- and so is an e4m3 output (out8; GEGLU only).  Such launches run on k_igemm_pp<F8> only; without it (fixed scale 1:
+  // the round-2 API) only on k_igemm8
+  int mx;
   // bfloat16 operands, bias, residual and output (tf_linear_bf16 / tf_conv2d_bf16): the plain deep ring with the bf16 MFMA, no split-K
   int bf16;
   // tf_linear_f32out_f16: the raw fp32 accumulators go to out32[m, n] (no bias / residual / activation, never split along K) -- the
@@ -259,7 +263,7 @@ __device__ __forceinline__ void igemm_scratch_write(const GemmP& p, f4 (&acc)[BN
 // all 8 waves: wave (w4, half) stores rows [half*TM/2, (half+1)*TM/2) of consumer w4's tile
 // LB: bias and the time embedding (bias_nc) come from an fp32 LDS table `lb` the kernel filled for its tile ([0][BN]: bias, [1 + i][BN]:
 //   bias_nc of image lb_img0 + i, i < 2) instead of per-item global loads -- the only loads left in the epilogue are the residual's.
-template <int BM, int BN, bool OUT8 = false, bool BF = false, int KBMAX = 4, bool LB = false>     // OUT8: the output is stored as e4m3 (fp8 kernels only; a template parameter keeps it out of the fp16 kernels); BF: bias / residual / output are bfloat16; KBMAX: items whose loads are in flight together
+template <int BM, int BN, int OUT8 = 0, bool BF = false, int KBMAX = 4, bool LB = false>     // OUT8: the output is stored as e4m3 -- 1: at scale 1 (k_igemm8), 2: block scaled (k_igemm_pp, GEGLU only: codes, then the E8M0 bytes behind the M x N/2 codes) -- a template parameter keeps it out of the fp16 kernels; BF: bias / residual / output are bfloat16; KBMAX: items whose loads are in flight together
 __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m0, int n0, int split, int w4, int half, int lane, const float* lb = nullptr, int lb_n0 = 0, int lb_m1 = 0) {
   typedef typename std::conditional<BF, bf16_t, half_t>::type E;
   typedef E E8 __attribute__((ext_vector_type(8)));
@@ -299,14 +303,14 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
     }
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
-      if (!ok[k]) continue;
+      if (OUT8 != 2 && !ok[k]) continue;                  // (the block-scaled output shuffles across lanes: every lane stays, dead items contribute zeros)
       const int idx = lane + 64 * (k0 + k);
       const int row = idx / CPR, c8 = idx - row * CPR;
       const int m = mb + row;
       const int pc = 32 * (c8 >> 1) + 8 * (c8 & 1);      // packed column of the value chunk inside the wave tile
       const int n = nb + pc;
       const int no = (n >> 5) * 16 + (n & 15);
-      const float* r = sc + row * RS + pc;
+      const float* r = sc + (ok[k] ? row * RS + pc : 0);
       f4 a0 = *reinterpret_cast<const f4*>(r), a1 = *reinterpret_cast<const f4*>(r + 4);
       f4 g0 = *reinterpret_cast<const f4*>(r + 16), g1 = *reinterpret_cast<const f4*>(r + 20);
       E8 o;
@@ -325,11 +329,23 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
         o[4 + e] = (E)((a1[e] + (float)ba[k][4 + e]) * gelu_f(g1[e] + (float)bg[k][4 + e]));
       }
       }
-      if (p.residual) {
+      if (p.residual && ok[k]) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (E)((float)o[e] + (float)rv[k][e]);
       }
-      if constexpr (OUT8) {
+      if constexpr (OUT8 == 2) {
+        // CPR = 4 (a 64-wide wave tile): the 4 lanes of a row hold 32 consecutive output channels = one block
+        static_assert(OUT8 != 2 || CPR == 4, "block-scaled GEGLU output: 128-wide tiles");
+        f4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
+        if (ok[k]) { for (int e = 0; e < 4; ++e) { q0[e] = (float)o[e]; q1[e] = (float)o[4 + e]; } }
+        unsigned sb;
+        const uint2 code = mx_quant8(q0, q1, sb);
+        if (ok[k]) {
+          unsigned char* yb = reinterpret_cast<unsigned char*>(p.y);
+          *reinterpret_cast<uint2*>(yb + (long long)m * No + no) = code;
+          if (c8 == 0) yb[(long long)p.M * No + (long long)m * (No >> 5) + (no >> 5)] = (unsigned char)sb;
+        }
+      } else if constexpr (OUT8 == 1) {
         f4 q0, q1;
         for (int e = 0; e < 4; ++e) { q0[e] = (float)o[e]; q1[e] = (float)o[4 + e]; }
         *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.y) + (long long)m * No + no) = pack8_fp8(q0, q1);
@@ -383,7 +399,7 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
       if (p.residual) { for (int e = 0; e < 4; ++e) { v0[e] += (float)rv[k][e]; v1[e] += (float)rv[k][4 + e]; } }
       E8 out;
       for (int e = 0; e < 4; ++e) { out[e] = (E)v0[e]; out[4 + e] = (E)v1[e]; }
-      if constexpr (OUT8) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.y) + o) = pack8_fp8(v0, v1);
+      if constexpr (OUT8 != 0) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.y) + o) = pack8_fp8(v0, v1);
       else *reinterpret_cast<E8*>(e_y + o) = out;
       if (p.gn_part) {   // the statistics pass sums what the consumer will read: the fp16-rounded outputs
         for (int e = 0; e < 4; ++e) { v0[e] = (float)out[e]; v1[e] = (float)out[4 + e]; }
@@ -415,7 +431,7 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
       if (p.residual) { E8 b = *reinterpret_cast<const E8*>(e_res + o); for (int e = 0; e < 4; ++e) { v0[e] += (float)b[e]; v1[e] += (float)b[4 + e]; } }
       E8 out;
       for (int e = 0; e < 4; ++e) { out[e] = (E)v0[e]; out[4 + e] = (E)v1[e]; }
-      if constexpr (OUT8) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.y) + o) = pack8_fp8(v0, v1);
+      if constexpr (OUT8 != 0) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.y) + o) = pack8_fp8(v0, v1);
       else *reinterpret_cast<E8*>(e_y + o) = out;
       if (p.gn_part) {   // the statistics pass below sums what the consumer will read: the fp16-rounded outputs
         float* rw = sc + row * RS + c8 * 8;

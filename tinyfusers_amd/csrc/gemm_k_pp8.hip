@@ -3,8 +3,13 @@
 template <int BN, int BM>
 static int launch_pp8(const GemmP& p, hipStream_t st) {
   const bool h2 = (p.C1 % 128) || (p.C2 % 128) || (p.C3 % 128) || (p.C4 % 128);
-  if (pp_fast(p)) return h2 ? launch_pp2<BN, 1, true, true, true, BM>(p, st) : launch_pp2<BN, 1, true, true, false, BM>(p, st);
-  return h2 ? launch_pp2<BN, 1, false, true, true, BM>(p, st) : launch_pp2<BN, 1, false, true, false, BM>(p, st);
+  if (!pp_fast(p) || !p.mx) { tf_set_error("k_igemm_pp: the e4m3 instances take block-scaled activations and the lean addressing (stride 1, no up-sampling) only"); return TF_E_UNSUPPORTED; }
+  if constexpr (BM == 256 && BN == 160) {                  // (no room for the half-tile scale table behind a 3 x 52 KiB ring)
+    if (h2) { tf_set_error("k_igemm_pp: no 256x160 e4m3 instance for channel counts off the 128 grid"); return TF_E_UNSUPPORTED; }
+    return launch_pp2<BN, 1, true, true, false, BM>(p, st);
+  } else {
+    return h2 ? launch_pp2<BN, 1, true, true, true, BM>(p, st) : launch_pp2<BN, 1, true, true, false, BM>(p, st);
+  }
 }
 int tfk_launch_pp8(const GemmP& p, hipStream_t st, int bm, int bn) {
   if (bm == 192 && bn == 128) return launch_pp8<128, 192>(p, st);

@@ -31,14 +31,19 @@
 //   bit mask of the taps that fall inside the image, so a tile's source offset is one mad + one mask test instead of the bounds
 //   arithmetic of the general gather (the load segments, not the MFMAs, set this kernel's pace: every VALU / SALU instruction in them counts).
 // DBG: the ablation build (p.dbg: 1 no epilogue, 2 no MFMA, 4 no staging in the loop, 8 no fragment reads)
-// F8 = OCP e4m3 operands (BASELINE config 5) on the block-scaled MFMA v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales: 128-deep K per
-//   instruction at twice the fp16 rate.  The LDS image is the fp16 kernel's byte for byte -- a K tile is 128 BYTES of every row, i.e. 128
-//   e4m3 elements -- and so are the fragment reads: lane group lg takes chunk lg and chunk lg + 4 of its row (k = 16 lg .. 16 lg + 15 and
-//   64 + 16 lg ..), both operands cut the same way, so every k meets its partner whatever order the instruction walks them in; the two
-//   16-byte reads are the low and the high half of ONE MFMA's 32-byte operand.  A K tile is two 64-channel HALVES that may lie in
-//   different taps / source tensors (320 channels = 2.5 tiles): H2 = true issues every activation piece as two half-masked loads with
-//   their own descriptor and offsets (same count every tile: the vmcnt bookkeeping stays static); H2 = false (every channel count a
-//   multiple of 128) one load.  Per-output-channel weight scales multiply the accumulators in front of the shared epilogue.
+// F8 = OCP e4m3 operands (BASELINE config 5) on the block-scaled MFMA v_mfma_scale_f32_16x16x128_f8f6f4: 128-deep K per instruction at twice the
+//   fp16 rate.  The LDS image is the fp16 kernel's byte for byte -- a K tile is 128 BYTES of every row, i.e. 128 e4m3 elements -- and so are the
+//   fragment reads: lane group lg takes chunk lg and chunk lg + 4 of its row, which IS the instruction's register layout (registers 0-3 hold
+//   k = 16 lg .. 16 lg + 15, registers 4-7 hold k = 64 + 16 lg ..; tools/probe_mx.hip).  ACTIVATIONS are block scaled ("MX", common.h: mx_quant8):
+//   every 32 consecutive channels of a pixel share one E8M0 byte, stored behind the tensor's codes; the instruction takes the scale of K block b
+//   (k = 32 b .. 32 b + 31 of the 128) from lane group b, byte 0 of the scale operand (the same probe).  The four bytes of a (row, K tile) travel
+//   with the tile: waves 4-7 DMA them (buffer_load_dword / _ushort ... lds, one lane per row, 4 bytes of LDS per lane) into a small table
+//   behind the ring, slot by slot like the tile itself, and a lane reads the byte of (its row, block lg) with one ds_read_u8 per fragment.
+//   WEIGHTS carry one fp32 scale per output channel (tf_pack_weight_fp8), applied to the accumulators in front of the shared epilogue; their
+//   hardware scale is 2^0.  A K tile is two 64-channel HALVES that may lie in different taps / source tensors (320 channels = 2.5 tiles): H2 =
+//   true issues every activation piece as two half-masked loads with their own descriptor and offsets, and the scales as two 2-byte loads (same
+//   counts every tile: the vmcnt bookkeeping stays static); H2 = false (every channel count a multiple of 128) one load each.  F8 instances
+//   exist for the lean addressing only (FASTA: stride-1 convolutions without up-sampling, linears).
 // BM = 256 or 192 rows: 192 (wave tiles of 48 rows) exists for the tile COUNT -- 96 x 96 latents give M = 9216 * images rows, and
 //   e.g. 73728 x 320 is 576 tiles of 256 x 160 = 2.25 rounds on 256 CUs but 768 tiles of 192 x 160 = 3 rounds exactly.
 // LNF = the LayerNorm fold (tf_linear_ln_f16: Linear(LN(x)) = rstd[m] (x . w'^T - mean[m] colsum[n]) + bias'[n]): the row statistics come from
@@ -55,6 +60,9 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
   static_assert(BM == 256 || BM == 192, "block rows");
   static_assert(!F8 || NP == 1, "the 128-deep MFMA takes both 64-byte halves of a row at once");
   static_assert(F8 || !H2, "half-masked activation loads are the fp8 kernel's");
+  static_assert(!F8 || FASTA, "the e4m3 instances use the lean addressing");
+  constexpr int SCL = F8 ? (H2 ? 2 : 1) : 0;              // scale loads per K tile of a wave that stages scales (waves 4-7)
+  constexpr int SCS = SCL * 1024;                         // bytes of a ring slot's scale table: one dword per row and half, 4 waves x 64 rows (the 192-row tile leaves the last 64 unused)
   constexpr int NWG = BN / 8;                             // weight pieces (8 rows x 128 B) of a stage
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int NS = (163840 / STAGE) >= 3 ? 3 : 2;
@@ -122,6 +130,21 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
   for (int i = 0; i < WPW; ++i) {
     const int g = wid + 8 * i, n = n0 + 8 * g + sub;
     gw[i] = (g < NWG && n < p.N) ? (unsigned)(n * p.K) * ES + cs * 16u : TF_OOB;
+  }
+  // F8: lane L of wave 4 + w stages the scale bytes of tile row 64 w + L: (pixel index of the output position, tap-validity mask) as g_a / g_b
+  int s_pix = 0, s_mask = 0;
+  if constexpr (F8) {
+    const int m = m0 + 64 * (wid - 4) + lane;
+    if (wid >= 4 && 64 * (wid - 4) + lane < BM && m < p.M) {
+      int img = fast_div(m, p.dv_howo_mul, p.dv_howo_shr), rem = m - img * p.HoWo;
+      int ho = fast_div(rem, p.dv_wo_mul, p.dv_wo_shr), wo = rem - ho * p.Wo;
+      s_pix = img * p.H * p.W + ho * p.W + wo;
+      unsigned mask = 0x80000000u;
+      for (int r = 0; r < p.S; ++r)
+        for (int s_ = 0; s_ < p.S; ++s_)
+          if ((unsigned)(ho - p.pad + r) < (unsigned)p.H && (unsigned)(wo - p.pad + s_) < (unsigned)p.W) mask |= 1u << (r * p.S + s_);
+      s_mask = (int)mask;
+    }
   }
   const int klim = p.K * ES - cs * 16;                     // this lane's 16 bytes of K tile kt lie inside the row iff kt * 128 < klim (fp8: K need not be a multiple of 128)
   const int Hl = p.H << p.ups, Wl = p.W << p.ups;
@@ -245,10 +268,37 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
     for (int i = 0; i < WPW; ++i)
       if (WREM == 0 || i < WPW - 1 || wid < WREM) dma16(rs_w, (gw[i] != TF_OOB && (!F8 || (int)kb < klim)) ? gw[i] + kb : TF_OOB, base + (unsigned)i * 8192u);
   };
+  // F8: the E8M0 bytes of the tile's activation rows (waves 4-7; every one of them issues SCL loads so that the counts stay uniform -- the
+  // rows beyond BM of the 192-row tile fetch out of range).  A source tensor holds its scale bytes behind its codes (offset = the codes'
+  // byte count `nb`), C / 32 per pixel; a 64-channel slab starting at byte offset c0 of a pixel's codes has its 2 bytes at c0 / 32.
+  auto stage_sc = [&](int slot) {
+    if constexpr (F8) {
+      if (wid < 4) return;
+      const unsigned base = lds0 + (unsigned)NS * STAGE + (unsigned)slot * SCS + (unsigned)(wid - 4) * 256u;
+      auto one = [&](int lo, int hi, int nb, int r_, int c0_, int ld_, unsigned ldsb, auto wide) {
+        i4v rs;
+        const int s_nb = __builtin_amdgcn_readfirstlane(nb);
+        rs[0] = __builtin_amdgcn_readfirstlane(lo); rs[1] = __builtin_amdgcn_readfirstlane(hi);
+        rs[2] = s_nb + (s_nb >> 5); rs[3] = 0x00020000;
+        const int s_r = __builtin_amdgcn_readfirstlane(r_), s_c0 = __builtin_amdgcn_readfirstlane(c0_) >> 5, s_ld = __builtin_amdgcn_readfirstlane(ld_) >> 5;
+        const unsigned off = (s_mask & s_r) ? (unsigned)s_nb + __umul24((unsigned)s_pix, (unsigned)s_ld) + (unsigned)s_c0 : TF_OOB;
+        if constexpr (decltype(wide)::value)
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" :: "s"(__builtin_amdgcn_readfirstlane((int)ldsb)), "v"(off), "s"(rs) : "memory");
+        else
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_ushort %1, %2, 0 offen lds" :: "s"(__builtin_amdgcn_readfirstlane((int)ldsb)), "v"(off), "s"(rs) : "memory");
+      };
+      if constexpr (H2) {
+        one(b_lo, b_hi, b_nb, b_r, b_c0, b_ld, base, std::false_type{});
+        one(a_lo, a_hi, a_nb, a_r, a_c0, a_ld, base + 1024u, std::false_type{});
+      } else one(b_lo, b_hi, b_nb, b_r, b_c0, b_ld, base, std::true_type{});
+    }
+  };
   // "this wave's pieces of every tile but the newest one (NEWEST) / of every tile (!NEWEST) have landed"
   auto wait_landed = [&](auto newest) {
     if constexpr (decltype(newest)::value && D >= 2) {
-      if (WREM == 0 || wid < WREM) wait_vm<APL + WPW>(); else wait_vm<APL + WPW - 1>();
+      // loads of one tile by this wave: APL activation pieces, WPW (or one fewer from wave WREM on) weight pieces, SCL scale loads on waves 4-7
+      static_assert(WREM == 0 || WREM == 4, "the wave classes below");
+      if (wid < 4) wait_vm<APL + WPW>(); else wait_vm<APL + WPW - (WREM ? 1 : 0) + SCL>();
     } else wait_vm<0>();
   };
 
@@ -278,6 +328,18 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
     for (int j = 0; j < MJ; ++j) xf[f][j] = *reinterpret_cast<const h8*>(sb + ((xo + j * 2048) ^ (k2 * 64)));
 #pragma unroll
     for (int i = 0; i < NI; ++i) wf[f][i] = *reinterpret_cast<const h8*>(sb + ((wo_ + i * 2048) ^ (k2 * 64)));
+  };
+  // F8: the E8M0 byte of (row lr of pixel tile j, K block lg) of the tile being multiplied: the instruction takes block b's scale from lane group b
+  int sx[MJ];
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) sx[j] = 0x7F;
+  const int sc_lane = NS * STAGE + (H2 ? (lg >> 1) * 1024 + (lg & 1) : lg) + (wm * (BM / 4) + lr) * 4;
+  auto read_sc = [&](int slot) {
+    if constexpr (F8) {
+      const unsigned char* sc = reinterpret_cast<const unsigned char*>(smem) + sc_lane + slot * SCS;
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) sx[j] = sc[j * 64];
+    }
   };
   float ls[MJ], lq[MJ];                                    // LNF: this lane's share of (sum x, sum x^2) of row lr of every pixel tile
 #pragma unroll
@@ -325,8 +387,8 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
         v4i lo = __builtin_bit_cast(v4i, wf[0][i]), hi = __builtin_bit_cast(v4i, wf[KF - 1][i]);
         const v8i wv = (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-        for (int j = 0; j < MJ; ++j)      // e4m3 x e4m3, block scales 2^0 (E8M0 0x7F) on both sides
-          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, xv[j], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        for (int j = 0; j < MJ; ++j)      // e4m3 x e4m3; weights at 2^0 (their per-channel scale multiplies the accumulators later), activations with their block scales
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, xv[j], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, sx[j]);
       }
     } else {
 #pragma unroll
@@ -358,7 +420,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
   // ---- prologue: the first D tiles, whole
 #pragma unroll
   for (int s_ = 0; s_ < D; ++s_)
-    if (s_ < nt) { prep_tile(); stage_act(s_); stage_w(s_, kt_begin + s_); }
+    if (s_ < nt) { prep_tile(); stage_act(s_); stage_w(s_, kt_begin + s_); stage_sc(s_); }
   if (D < nt) prep_tile();                                 // the scalars of tile D: its pieces ride on tile 0
   if (D >= 2 && nt >= 2) wait_landed(std::true_type{}); else wait_landed(std::false_type{});     // tile 0 landed
   barrier();                                               // P: tile 0 is visible to every wave
@@ -375,7 +437,8 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
     if constexpr (NP == 1) {
       read_k(sb, 0, 0);
       read_k(sb, 1, 1);
-      if (more) { stage_act(ws); stage_w(ws, ktw); }
+      read_sc(rs);
+      if (more) { stage_act(ws); stage_w(ws, ktw); stage_sc(ws); }
       if constexpr (NEXT) { if (grp == 1) wait_landed(more_c); }
       wait_lds_reads();
       barrier();
@@ -476,7 +539,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     barrier();
     // (two items' loads in flight at a time: half of the accumulators is still live during the first pass)
-    if (F8 && p.out8) igemm_epilogue<BS, BN, true, false, 2, true>(p, smem, m0 + sm * BS, n0, split, wid & 3, wid >> 2, lane, lbt, n0, lb_m1);
+    if (F8 && BN == 128 && p.out8) igemm_epilogue<BS, BN, (F8 && BN == 128) ? 2 : 0, false, 2, true>(p, smem, m0 + sm * BS, n0, split, wid & 3, wid >> 2, lane, lbt, n0, lb_m1);   // (block-scaled GEGLU output: the host admits it for act = 1 and 128-wide tiles only)
     else igemm_epilogue<BS, BN, false, false, 2, true>(p, smem, m0 + sm * BS, n0, split, wid & 3, wid >> 2, lane, lbt, n0, lb_m1);
     if (p.gn_part && m0 + sm * BS < p.M) igemm_gn_stats<BS, BN>(p, smem, m0 + sm * BS, n0, wid & 3, wid >> 2, lane);   // (block-uniform: the barrier inside is safe)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -73,7 +73,7 @@ __global__ void k_gn_stats(float* __restrict__ partial, const T* __restrict__ x,
 // fixed order -> every block gets the same bits) -- cheaper than a separate finalize launch; then many small blocks
 // stream the tensor (the kernel is latency-bound otherwise).
 #define GN_APPLY_PPT 4
-template <bool OUT8, typename T = half_t>
+template <int OUT8, typename T = half_t>     // OUT8: 0 = 16-bit output, 1 = e4m3 at scale 1, 2 = block-scaled e4m3 (common.h: mx_quant8; codes, then the scale bytes behind the N x HW x C codes)
 __global__ void k_gn_apply(T* __restrict__ y, const T* __restrict__ x, const T* __restrict__ x2, const T* __restrict__ gamma,
                            const T* __restrict__ beta, const float* __restrict__ partial, int HW, int C1, int C2, int G, float eps,
                            int do_silu, int chunks, int pix_per_block, int CV, int RPB, const float* __restrict__ partial2, int chunks2,
@@ -151,9 +151,9 @@ __global__ void k_gn_apply(T* __restrict__ y, const T* __restrict__ x, const T* 
     }
   }
   __syncthreads();
-  if (!active) return;
+  if (OUT8 != 2 && !active) return;                       // (the block-scaled form shuffles across lanes: every lane stays)
   float a[8], b[8];
-  {
+  if (active) {
     int g = c / cpg, gend = (g + 1) * cpg;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -168,17 +168,30 @@ __global__ void k_gn_apply(T* __restrict__ y, const T* __restrict__ x, const T* 
 #pragma unroll
   for (int i = 0; i < GN_APPLY_PPT; ++i) {
     int p = p0 + rr + i * RPB;
-    if (p < p1) {
+    const bool live = active && p < p1;
+    if (OUT8 == 2 || live) {
       V8 o;
-      f4 q0, q1;
+      f4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
+      if (live) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float f = (float)v[i][j] * a[j] + b[j];
-        f = do_silu ? silu_f(f) : f;
-        o[j] = (T)f;
-        if (j < 4) q0[j] = f; else q1[j - 4] = f;
+        for (int j = 0; j < 8; ++j) {
+          float f = (float)v[i][j] * a[j] + b[j];
+          f = do_silu ? silu_f(f) : f;
+          o[j] = (T)f;
+          if (j < 4) q0[j] = f; else q1[j - 4] = f;
+        }
       }
-      if constexpr (OUT8) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(y) + (long long)n * HW * C + c + (long long)p * C) = pack8_fp8(q0, q1);   // e4m3 operand of an fp8 conv
+      if constexpr (OUT8 == 2) {
+        // 4 consecutive lanes = 4 consecutive channel vectors of one pixel = one 32-channel block (CV % 4 == 0, so the quads never straddle rows)
+        unsigned sb;
+        const uint2 code = mx_quant8(q0, q1, sb);
+        if (live) {
+          unsigned char* yb = reinterpret_cast<unsigned char*>(y);
+          *reinterpret_cast<uint2*>(yb + ((long long)n * HW + p) * C + c) = code;
+          if ((cv & 3) == 0) yb[(long long)gridDim.y * HW * C + ((long long)n * HW + p) * (C >> 5) + (c >> 5)] = (unsigned char)sb;
+        }
+      }
+      else if constexpr (OUT8 == 1) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(y) + (long long)n * HW * C + c + (long long)p * C) = pack8_fp8(q0, q1);   // e4m3 operand of an fp8 conv
       else *reinterpret_cast<V8*>(yo + (long long)p * C) = o;
     }
   }
@@ -224,6 +237,35 @@ __global__ void __launch_bounds__(256) k_layer_norm(T* __restrict__ y, const T* 
 #pragma unroll
   for (int o = 1; o < LPR; o <<= 1) q += __shfl_xor(q, o, 64);
   float rstd = rsqrtf(q / (float)C + eps);
+  if (out8 == 2) {
+    // block-scaled e4m3 (common.h: mx_quant8): 4 consecutive lanes hold the 4 channel vectors of one 32-channel block; every lane stays for
+    // the shuffles, dead rows / vectors contribute zeros and store nothing.  Codes at y, scale bytes behind the rows x C codes.
+    unsigned char* yb = reinterpret_cast<unsigned char*>(y);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int cv = li + LPR * i;
+      if (LPR * i >= CV) break;                            // (wave-uniform: no lane has a vector in this round)
+      const bool on = live && cv < CV;
+      f4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
+      if (on) {
+        V8 gm, bt;
+        if (gamma) { gm = *reinterpret_cast<const V8*>(gamma + cv * 8); bt = *reinterpret_cast<const V8*>(beta + cv * 8); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float f = ((float)v[i][j] - mean) * rstd;
+          if (gamma) f = f * (float)gm[j] + (float)bt[j];
+          if (j < 4) q0[j] = f; else q1[j - 4] = f;
+        }
+      }
+      unsigned sb;
+      const uint2 code = mx_quant8(q0, q1, sb);
+      if (on) {
+        *reinterpret_cast<uint2*>(yb + (long long)row * C + cv * 8) = code;
+        if ((cv & 3) == 0) yb[(long long)rows * C + (long long)row * (C >> 5) + (cv >> 2)] = (unsigned char)sb;
+      }
+    }
+    return;
+  }
   if (!live) return;
   T* yr = y + (long long)row * C;
 #pragma unroll
@@ -368,7 +410,7 @@ static int group_norm_impl(void* y, const void* x, const void* x2, const void* g
   hipLaunchKernelGGL(k_gn_stats<T>, dim3(chunks, N), dim3(tl), (size_t)threads * 16 * sizeof(float), tf_hs(s), partial, (const T*)x,
                      (const T*)x2, HW, C1, C2, G, chunks, ppc, CV, RPB);
   TF_LAUNCH_CHECK();
-  hipLaunchKernelGGL((k_gn_apply<false, T>), dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (T*)y, (const T*)x, (const T*)x2,
+  hipLaunchKernelGGL((k_gn_apply<0, T>), dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (T*)y, (const T*)x, (const T*)x2,
                      (const T*)gamma, (const T*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
   TF_LAUNCH_CHECK();
   return TF_OK;
@@ -402,7 +444,7 @@ int tf_group_norm_apply_f16(void* y, const void* x, const void* gamma, const voi
   int CV, RPB, threads, sc, ppc, ablocks, appb;
   gn_geometry(HW, C, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
   int tl = (threads + 7) & ~7;
-  hipLaunchKernelGGL(k_gn_apply<false>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)nullptr,
+  hipLaunchKernelGGL(k_gn_apply<0>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)nullptr,
                      (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
   TF_LAUNCH_CHECK();
   return TF_OK;
@@ -416,10 +458,12 @@ int tf_group_norm_apply_cat_f16(void* y, const void* x, const void* x2, const vo
                                 tfStream_t s) {
   return gn_apply_cat(y, x, x2, gamma, beta, partial, chunks, groups1, partial2, chunks2, groups2, N, HW, C1, C2, G, eps, silu, 0, s);
 }
-/* the same with an e4m3 (fp8) output -- the operand of an fp8 conv (config 5); x2 / partial2 may be NULL (single source: groups1 = G) */
-int tf_group_norm_apply_fp8(void* y8, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial, int chunks,
-                            int groups1, const void* partial2, int chunks2, int groups2, int N, int HW, int C1, int C2, int G, float eps, int silu,
-                            tfStream_t s) {
+/* the same with an e4m3 (fp8) output -- the operand of an fp8 conv (config 5); x2 / partial2 may be NULL (single source: groups1 = G).
+ * mode 1: e4m3 at scale 1 (tf_group_norm_apply_fp8); mode 2: block-scaled e4m3 (tf_group_norm_apply_mx8: codes, then the E8M0 bytes) */
+static int gn_apply_8(void* y8, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial, int chunks,
+                      int groups1, const void* partial2, int chunks2, int groups2, int N, int HW, int C1, int C2, int G, float eps, int silu,
+                      int mode, tfStream_t s) {
+  if (mode == 2) TF_REQUIRE((C1 + C2) % 32 == 0, "tf_group_norm_apply_mx8: C=%d must be a multiple of 32 (one scale per 32 channels)", C1 + C2);
   if (!x2) {
     TF_REQUIRE(y8 && x && partial && C2 == 0 && groups1 == G, "tf_group_norm_apply_fp8: single source needs C2 = 0 and groups1 = G");
     TF_REQUIRE((gamma == nullptr) == (beta == nullptr), "tf_group_norm_apply_fp8: gamma and beta must both be given or both NULL");
@@ -429,12 +473,24 @@ int tf_group_norm_apply_fp8(void* y8, const void* x, const void* x2, const void*
     int CV, RPB, threads, sc, ppc, ablocks, appb;
     gn_geometry(HW, C1, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
     int tl = (threads + 7) & ~7;
-    hipLaunchKernelGGL(k_gn_apply<true>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y8, (const half_t*)x, (const half_t*)nullptr,
+    if (mode == 2) hipLaunchKernelGGL(k_gn_apply<2>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y8, (const half_t*)x, (const half_t*)nullptr,
+                       (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
+    else hipLaunchKernelGGL(k_gn_apply<1>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y8, (const half_t*)x, (const half_t*)nullptr,
                        (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
     TF_LAUNCH_CHECK();
     return TF_OK;
   }
-  return gn_apply_cat(y8, x, x2, gamma, beta, partial, chunks, groups1, partial2, chunks2, groups2, N, HW, C1, C2, G, eps, silu, 1, s);
+  return gn_apply_cat(y8, x, x2, gamma, beta, partial, chunks, groups1, partial2, chunks2, groups2, N, HW, C1, C2, G, eps, silu, mode, s);
+}
+int tf_group_norm_apply_fp8(void* y8, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial, int chunks,
+                            int groups1, const void* partial2, int chunks2, int groups2, int N, int HW, int C1, int C2, int G, float eps, int silu,
+                            tfStream_t s) {
+  return gn_apply_8(y8, x, x2, gamma, beta, partial, chunks, groups1, partial2, chunks2, groups2, N, HW, C1, C2, G, eps, silu, 1, s);
+}
+int tf_group_norm_apply_mx8(void* y_mx, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial, int chunks,
+                            int groups1, const void* partial2, int chunks2, int groups2, int N, int HW, int C1, int C2, int G, float eps, int silu,
+                            tfStream_t s) {
+  return gn_apply_8(y_mx, x, x2, gamma, beta, partial, chunks, groups1, partial2, chunks2, groups2, N, HW, C1, C2, G, eps, silu, 2, s);
 }
 static int gn_apply_cat(void* y, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial, int chunks,
                         int groups1, const void* partial2, int chunks2, int groups2, int N, int HW, int C1, int C2, int G, float eps, int silu,
@@ -453,10 +509,13 @@ static int gn_apply_cat(void* y, const void* x, const void* x2, const void* gamm
   int CV, RPB, threads, sc, ppc, ablocks, appb;
   gn_geometry(HW, C, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
   int tl = (threads + 7) & ~7;
-  if (out8) hipLaunchKernelGGL(k_gn_apply<true>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
+  if (out8 == 2) hipLaunchKernelGGL(k_gn_apply<2>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
                                (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB,
                                (const float*)partial2, chunks2, groups1, groups2, cpg / sub);
-  else hipLaunchKernelGGL(k_gn_apply<false>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
+  else if (out8) hipLaunchKernelGGL(k_gn_apply<1>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
+                               (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB,
+                               (const float*)partial2, chunks2, groups1, groups2, cpg / sub);
+  else hipLaunchKernelGGL(k_gn_apply<0>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
                           (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB,
                           (const float*)partial2, chunks2, groups1, groups2, cpg / sub);
   TF_LAUNCH_CHECK();
@@ -480,6 +539,11 @@ int tf_layer_norm_bf16(void* y, const void* x, const void* gamma, const void* be
 int tf_layer_norm_fp8(void* y8, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s) {
   TF_REQUIRE(C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXV, "tf_layer_norm_fp8: C=%d must be a multiple of 8 and <= %d", C, 64 * 8 * LN_MAXV);
   return layer_norm_impl<half_t>(y8, x, gamma, beta, rows, C, eps, 1, s);
+}
+/* LayerNorm with a block-scaled e4m3 output (rows x C codes, then rows x C/32 E8M0 bytes): the operand of tf_linear_mx8; C a multiple of 32 */
+int tf_layer_norm_mx8(void* y_mx, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s) {
+  TF_REQUIRE(C > 0 && C % 32 == 0 && C <= 64 * 8 * LN_MAXV, "tf_layer_norm_mx8: C=%d must be a multiple of 32 and <= %d", C, 64 * 8 * LN_MAXV);
+  return layer_norm_impl<half_t>(y_mx, x, gamma, beta, rows, C, eps, 2, s);
 }
 
 }  // extern "C"

@@ -1,24 +1,30 @@
 """fp8 (OCP e4m3) conv / linear path for BASELINE config 5 ("SD1.5 768x768 batch 32 on 8 GPUs, fp8 MFMA conv/linear path") -- the
 precision variant of vision/conv2d.py:9-58 and ff/linear.py:112-121, selected with ``config.set_dtype("fp8")``.
 
-Which layers run in fp8 (measured on the CPU oracle with e4m3 emulation, BASELINE.md section 4 gate: UNet rel-L2 <= 0.1):
-every conv and linear in e4m3 gives 0.16; the 3x3 convolutions (Cin, Cout >= 64) + the FeedForward linears give 0.088 and hold
-86 % of the conv / linear FLOPs.  The policy is the part of that set whose activation operand is a NORMALISED tensor: the two 3x3
-convs of every ResBlock (they read GroupNorm + SiLU outputs; opt-in through ``Conv2d._fp8_ok``) and the FeedForward linears of width >= 640 behind a
-LayerNorm.  The 1x1 projections, the attention projections, conv_in / conv_out, the time-embedding GEMVs, the six up / down-sampling
-convs (their input is the raw residual stream: e4m3 at a fixed scale of 1 saturates at 448 and flushes everything below 2e-3) and
-every module outside the UNet (the VAE's convs) stay fp16.
+Operands (round 4): weights e4m3 with one fp32 scale per output channel (tf_pack_weight_fp8, packed once per weight set); ACTIVATIONS
+block-scaled e4m3 ("mx8": every 32 consecutive channels of a pixel / token share one power-of-two E8M0 scale, amax / 2^e <= 448 -- so any
+tensor may be quantised, not only a normalised one), written directly by the kernel that produces them (GroupNorm apply, LayerNorm, the
+GEGLU epilogue) or by one quantise pass (``quantize_mx``); the GEMM (k_igemm_pp<F8>) hands the scale bytes to the hardware's scale operand
+(v_mfma_scale_f32_16x16x128_f8f6f4).  An mx8 tensor is ONE buffer: codes, then the scale bytes (include/tinyfusers_hip.h).
 
-Weights: e4m3 with one fp32 scale per output channel (tf_pack_weight_fp8, packed once per weight set).  Activations: e4m3 with
-scale 1 -- they are normalised tensors (GroupNorm + SiLU, LayerNorm, GEGLU output) -- written directly by the kernel that produces
-them.  ``quantize`` (tf_quantize_fp8_f16) remains for callers that hold a normalised fp16 tensor and for the op-level tests.
+Which layers (measured on the CPU oracle with the same quantisers, tests/fp8_policy_study.py; BASELINE.md section 4 gate: UNet rel-L2 <= 0.1):
+e4m3 rounding noise adds up in quadrature whatever the scales -- every conv and linear in e4m3 gives 0.15 with block scales and with a
+fixed scale alike -- so the policy is a precision budget, spent where the FLOPs are: the two 3x3 convs of every ResBlock (0.048), the
+FeedForward pair (0.042 + 0.029), the attention projections q|k|v / q / to_out (0.018 + 0.010 + 0.022): 0.076 together at 32 x 32, 0.09 at
+64 x 64.  The 1x1 convs on the residual path (proj_in 0.060, proj_out 0.055, skip 0.092) and the up / down-sampling convs (0.056) stay fp16,
+as do conv_in / conv_out, the time-embedding GEMVs and everything outside the UNet.  A layer also stays fp16 where the block-scaled kernel
+cannot take its shape (tf_mx8_*_supported: it is the 192- / 256-row ping-pong kernel, i.e. launches that fill the chip -- config 5's
+regime) or where the fp16 kernels are faster (K = 320: ``MIN_K``).
+
+The fixed-scale entries of round 2 (``quantize``, ``conv2d_fp8``, ``linear_fp8``, ``group_norm_fp8``, ``layer_norm_fp8``: scale 1, k_igemm8)
+remain as an op-level API; the model no longer uses them.
 """
 import ctypes
 
 import numpy as np
 
 from .. import config
-from ..native import hip
+from ..native import hip, lib
 from ..storage.tensor import DeviceArray, _sh
 from .linear import workspace
 
@@ -128,4 +134,124 @@ def layer_norm_fp8(x, ln):
     y = DeviceArray.empty(x.shape, np.uint8, x.layout)
     hip.tf_layer_norm_fp8(y.ptr, x.ptr, ln.weight.ptr if ln.weight is not None else None, ln.bias.ptr if ln.bias is not None else None,
                           x.size // c, c, float(np.asarray(ln.eps).reshape(-1)[0]), _sh())
+    return y
+
+
+# ---- block-scaled e4m3 ("mx8") -------------------------------------------------------------------------------------------------------
+MIN_K = 640        # below this the fp16 kernels win (LayerNorm folded into the persistent short-K kernel: 215 + 90 us against 293 + 74 us for the
+                   # e4m3 FeedForward pair at config 5's first level) -- K = 320 layers stay fp16
+_supported = {}
+
+
+def mx_empty(shape, layout=None):
+    """An mx8 tensor of the logical shape `shape` (channels = shape[1] for an NHWC image, shape[-1] for rows): codes + scale bytes in one
+    allocation; the returned uint8 array views the codes, the scale bytes sit right behind them."""
+    n = int(np.prod(shape, dtype=np.int64))
+    c = shape[1] if len(shape) == 4 else shape[-1]
+    assert c % 32 == 0, shape
+    buf = DeviceArray.empty((n + n // 32,), np.uint8, "row")
+    return buf.view(tuple(shape), layout or ("nhwc" if len(shape) == 4 else "row"))
+
+
+def quantize_mx(x):
+    """fp16 DeviceArray (NHWC image or rows) -> mx8 tensor of the same logical shape."""
+    c = x.shape[1] if x.ndim == 4 else x.shape[-1]
+    y = mx_empty(x.shape, x.layout)
+    hip.tf_quantize_mx8_f16(y.ptr, x.ptr, x.size // c, c, _sh())
+    return y
+
+
+def linear_ok(rows, n, k, act=0, out_mx=False):
+    """Does the block-scaled kernel take (and pay for) this Linear?"""
+    if not enabled() or k < MIN_K:
+        return False
+    key = ("lin", rows, n, k, act, out_mx)
+    if key not in _supported:
+        _supported[key] = bool(lib.tf_mx8_gemm_supported(rows, n, k, act, 1 if out_mx else 0))
+    return _supported[key]
+
+
+def conv_ok(x_shape, weight_shape, stride, padding, upsample):
+    n, c, h, w = x_shape
+    k, cw, r, s = weight_shape
+    if not enabled() or upsample or stride[0] != 1 or stride[1] != 1 or r != s or c != cw or c < 64 or k < 64:
+        return False
+    key = ("conv", n, h, w, c, k, r, padding[0])
+    if key not in _supported:
+        _supported[key] = bool(lib.tf_mx8_conv_supported(n, h, w, c, 0, k, r, s, 1, padding[0], 0))
+    return _supported[key]
+
+
+def group_norm_mx(x, norm, silu):
+    """GroupNorm(x) [-> SiLU] written as an mx8 tensor: one apply launch when the statistics came with x (and its concat partner), the fp16
+    GroupNorm followed by a quantise pass otherwise."""
+    x2 = None
+    if isinstance(x, (tuple, list)):
+        x, x2 = x
+    n, c1, h, w = x.shape
+    c2 = x2.shape[1] if x2 is not None else 0
+    G = norm.num_groups
+    gm = norm.weight.ptr if norm.weight is not None else None
+    bt = norm.bias.ptr if norm.bias is not None else None
+    if x2 is None and x.gn is not None and x.gn[2] == G:
+        y = mx_empty((n, c1, h, w), "nhwc")
+        hip.tf_group_norm_apply_mx8(y.ptr, x.ptr, None, gm, bt, x.gn[0].ptr, x.gn[1], G, None, 0, 0, n, h * w, c1, 0, G, float(norm.eps), 1 if silu else 0, _sh())
+        return y
+    if x2 is not None and x.gn is not None and x2.gn is not None and config.concat_stats:
+        g1, g2 = x.gn[2], x2.gn[2]
+        cpg = (c1 + c2) // G
+        if c1 % g1 == 0 and c2 % g2 == 0 and c1 // g1 == c2 // g2 and cpg % (c1 // g1) == 0 and cpg // (c1 // g1) <= 8:
+            y = mx_empty((n, c1 + c2, h, w), "nhwc")
+            hip.tf_group_norm_apply_mx8(y.ptr, x.ptr, x2.ptr, gm, bt, x.gn[0].ptr, x.gn[1], g1, x2.gn[0].ptr, x2.gn[1], g2, n, h * w, c1, c2, G,
+                                        float(norm.eps), 1 if silu else 0, _sh())
+            return y
+    return quantize_mx(norm((x, x2) if x2 is not None else x, silu=silu))
+
+
+def layer_norm_mx(x, ln):
+    c = x.shape[-1]
+    y = mx_empty(x.shape, x.layout)
+    hip.tf_layer_norm_mx8(y.ptr, x.ptr, ln.weight.ptr if ln.weight is not None else None, ln.bias.ptr if ln.bias is not None else None,
+                          x.size // c, c, float(np.asarray(ln.eps).reshape(-1)[0]), _sh())
+    return y
+
+
+def conv2d_mx(x8, w8, wscale, bias, weight_shape, padding, bias_nc=None, residual=None, gn=0):
+    """mx8 activations (one tensor: a concat arrives materialised from group_norm_mx) x e4m3 weights -> fp16 NHWC output; stride 1; same
+    epilogue as the fp16 conv (bias, time embedding, residual, the statistics of the output)."""
+    n, c1, h, wd = x8.shape
+    k, c, r, s = weight_shape
+    assert c == c1
+    ho, wo = h + 2 * padding[0] - r + 1, wd + 2 * padding[1] - s + 1
+    y = DeviceArray.empty((n, k, ho, wo), np.float16, "nhwc")
+    nb = hip.tf_conv2d_fp8_workspace(n, h, wd, c1, 0, k, r, s, 1, padding[0], 0)
+    ws = workspace(nb)
+    bnc_stride = 0
+    if bias_nc is not None:
+        bnc_stride = k if bias_nc.size // k > 1 else 0
+    part, pb, chunks = None, 0, ctypes.c_int(0)
+    if gn:
+        pb = hip.tf_conv2d_gn_partial_bytes(n, gn)
+        part = workspace(pb)
+    hip.tf_conv2d_mx8(y.ptr, x8.ptr, None, w8.ptr, wscale.ptr, bias.ptr if bias is not None else None,
+                      bias_nc.ptr if bias_nc is not None else None, bnc_stride, residual.ptr if residual is not None else None,
+                      n, h, wd, c1, 0, k, r, s, 1, padding[0], ws.ptr if ws else None, nb,
+                      part.ptr if part is not None else None, pb, gn, ctypes.byref(chunks), _sh())
+    if chunks.value > 0:
+        y.gn = (part, chunks.value, gn)
+    return y
+
+
+def linear_mx(x8, w8, wscale, bias, residual=None, act=0, out_features=None, out_mx=False):
+    """y = act(x8 . w8^T * wscale + bias) + residual; x8 (..., K) mx8, w8 (N, K) e4m3; y fp16, or an mx8 tensor (out_mx: the GEGLU output that
+    feeds the next block-scaled GEMM)."""
+    K = x8.shape[-1]
+    rows = x8.size // K
+    n_out = out_features if out_features is not None else w8.shape[0]
+    shape = x8.shape[:-1] + (n_out,)
+    y = mx_empty(shape, "row") if out_mx else DeviceArray.empty(shape, np.float16, "row")
+    nb = 0 if out_mx else hip.tf_linear_workspace(rows, n_out, K, act)
+    ws = workspace(nb)
+    hip.tf_linear_mx8(y.ptr, x8.ptr, w8.ptr, wscale.ptr, bias.ptr if bias is not None else None, residual.ptr if residual is not None else None,
+                      rows, n_out, K, act, 1 if out_mx else 0, ws.ptr if ws else None, nb, _sh())
     return y

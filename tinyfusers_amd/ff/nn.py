@@ -71,19 +71,19 @@ class FeedForward:
     def __call__(self, x, residual=None, ln=None):
         from . import fp8
         g, l2 = self.net[0], self.net[2]
-        # (dim >= 640 only: at K = 320 the fp16 pair -- LayerNorm folded into the persistent short-K kernel, then the ping-pong kernel -- is faster
-        # than the e4m3 pair, 305 vs 366 us at config 5's first level, and exact)
-        if fp8.enabled() and ln is not None and x.shape[-1] >= 640 and x.shape[-1] % 64 == 0 and g.dim_out % 64 == 0 and g.proj.bias is not None:
-            # config 5: LayerNorm -> e4m3, GEGLU projection in fp8 with an e4m3 output, second Linear in fp8 (+ bias + residual, fp16 out);
-            # only behind a LayerNorm (a raw input has no fixed scale)
-            h8 = fp8.layer_norm_fp8(x, ln)
+        rows = x.size // x.shape[-1]
+        if ln is not None and g.dim_out % 64 == 0 and g.proj.bias is not None and fp8.linear_ok(rows, g.dim_out, x.shape[-1], 1, True) \
+                and fp8.linear_ok(rows, l2.weight.shape[0], g.dim_out):
+            # config 5: LayerNorm -> block-scaled e4m3, GEGLU projection with a block-scaled e4m3 output, second Linear (+ bias + residual, fp16 out);
+            # K >= fp8.MIN_K only (at K = 320 the fp16 pair -- LayerNorm folded into the persistent short-K kernel -- is faster, and exact)
+            h8 = fp8.layer_norm_mx(x, ln)
             if getattr(g, "_cache8", None) is None:
                 g._cache8, l2._cache8 = {}, {}
             wp, bp = g._pack()                              # value | gate rows interleaved in 16-row blocks, then quantised row by row
             w8, wsc = fp8.pack_weight(wp, g._cache8)
-            hid8 = fp8.linear_fp8(h8, w8, wsc, bp, act=1, out_features=g.dim_out, out_fp8=True)
+            hid8 = fp8.linear_mx(h8, w8, wsc, bp, act=1, out_features=g.dim_out, out_mx=True)
             w28, wsc2 = fp8.pack_weight(l2.weight, l2._cache8)
-            return fp8.linear_fp8(hid8, w28, wsc2, l2.bias, residual=residual)
+            return fp8.linear_mx(hid8, w28, wsc2, l2.bias, residual=residual)
         h = self.net[0](x, ln=ln) if ln is not None else self.net[0](x)
         return self.net[2](h, residual=residual)
 

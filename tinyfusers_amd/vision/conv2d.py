@@ -224,8 +224,8 @@ class Conv2d:
             bound = 1 / math.sqrt(functools.reduce(operator.mul, shape[1:], 1))
             self.bias = asarray(np.random.uniform(-bound, bound, (out_channels,)).astype(np.float16)) if bias else None
         self._cache = {}
-        # config 5 (fp8): only modules that opt in run on e4m3 operands -- the UNet's ResBlocks set this on their two 3x3 convs, whose
-        # input is a GroupNorm + SiLU output (scale 1 fits).  Everything else (VAE, up / down-sampling convs: raw residual stream) stays fp16
+        # config 5 (fp8): only modules that opt in run on e4m3 operands -- the UNet's ResBlocks set this on their two 3x3 convs (the layer
+        # policy is a precision budget: ff/fp8.py).  Everything else (VAE, 1x1 and up / down-sampling convs) stays fp16
         self._fp8_ok = False
 
     def fold_1x1(self, proj):
@@ -261,12 +261,13 @@ class Conv2d:
                          {"x": x3, "cout": k, "r": r, "s": s}, gn_in=gn_in, out_norm=out_norm)
         cin = (x[0].shape[1] + x[1].shape[1]) if isinstance(x, (tuple, list)) else x.shape[1]
         from ..ff import fp8
-        if self._fp8_ok and gn_in is not None and fp8.conv_eligible(self.weight.shape, [t.shape[1] for t in x] if isinstance(x, (tuple, list)) else [cin], extra):
-            # config 5: e4m3 operands.  The activation operand comes straight out of the GroupNorm apply (gn_in: a normalised tensor, which
-            # is what the fixed activation scale of 1 is good for); bias / time embedding / residual / statistics as in the fp16 conv
+        if self._fp8_ok and gn_in is not None and extra is None and fp8.conv_ok((x[0].shape[0], cin) + tuple(x[0].shape[2:]) if isinstance(x, (tuple, list)) else x.shape,
+                                                                                 self.weight.shape, self.stride, self.padding, upsample):
+            # config 5: e4m3 operands.  The activation operand comes straight out of the GroupNorm apply as a block-scaled tensor (the concat of the
+            # output path arrives materialised); bias / time embedding / residual / statistics as in the fp16 conv
             w8, wsc = fp8.pack_weight(self.weight, self._cache)
-            x8 = fp8.group_norm_fp8(x, gn_in[0], gn_in[1])
-            return fp8.conv2d_fp8(x8, w8, wsc, self.bias, self.weight.shape, self.padding, self.stride, bias_nc, residual, upsample, gn)
+            x8 = fp8.group_norm_mx(x, gn_in[0], gn_in[1])
+            return fp8.conv2d_mx(x8, w8, wsc, self.bias, self.weight.shape, self.padding, bias_nc, residual, gn)
         if cin % 8 != 0:
             assert bias_nc is None and residual is None and not upsample
             if gn_in is not None:
