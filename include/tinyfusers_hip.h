@@ -156,6 +156,9 @@ int tf_prof_read(double* gemm_ms, double* gemm_flops, long long* gemm_launches);
 int tf_prof_read_full(double* ms_with_reduce, double* ms_gemm_kernel_only, double* gemm_flops, long long* gemm_launches);
 float tf_prof_overhead_us(void);   /* the per-bracket event overhead tf_prof_enable(1) measured (spin-kernel pair, see csrc/gemm.hip) and subtracts */
 int tf_prof_dump(const char* csv_path);   /* per-shape table: M,N,K,taps,tile,split-K,launches,ms,TFLOP/s */
+/* element type of the split-K partial slabs a split GEMM hands to its reduce launch: 16 (default) = fp16 -- half the bytes of that seam,
+ * accumulated in fp32 in split order by the reducer -- or 32 = fp32 (rounds 1-3) */
+int tf_gemm_splitk_partials(int bits);
 /* test / tuning hook: force the GEMM tile (bm x bn in {256,128,64} x {256,160,128,64}) and split-K; 0,0,0 = heuristic */
 int tf_gemm_force_config(int bm, int bn, int splitk);
 /* per-shape choice of (tile, split-K, ring variant).  mode 1 (default): a shape that is not in the table is timed on its first eager

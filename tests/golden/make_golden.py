@@ -20,7 +20,8 @@ Usage:  python tests/golden/make_golden.py [ops] [blocks] [unet] [unet50] [vae] 
 ``unet50`` runs the reference's StableDiffusion.__call__ over the WHOLE schedule of example/sd1.py:54-73 (50 steps) and keeps the
 latent after every tenth step and the final one (unet50_sd15.npz).  For that long run the cupy stand-in sends the five array functions
 that dominate the reference glue's CPU time (exp, tanh, matmul, dot, sqrt on large fp32 arrays) through multi-threaded torch instead of
-single-threaded numpy (TF_GOLDEN_FAST=0 keeps plain numpy); the reference's code is what runs either way.
+single-threaded numpy -- ON by default when ``unet50`` is among the arguments (that is how the committed unet50_sd15.npz was produced),
+off otherwise; TF_GOLDEN_FAST=0 / 1 overrides.  The reference's code is what runs either way.
 """
 import os
 import sys
@@ -47,7 +48,7 @@ def install_stubs():
                 pass
     cp.asnumpy = lambda a: np.asarray(a)
     cp.single = np.single
-    if os.environ.get("TF_GOLDEN_FAST", "0") != "0":
+    if os.environ.get("TF_GOLDEN_FAST", "1" if "unet50" in sys.argv[1:] else "0") != "0":
         def _big(a):
             return isinstance(a, np.ndarray) and a.dtype == np.float32 and a.size >= (1 << 16)
 

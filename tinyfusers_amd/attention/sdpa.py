@@ -60,16 +60,21 @@ def sdpa_unfused(q, k, v, mask=None, scale=None):
     vt = DeviceArray.empty((heads, HS, Tkp), np.float16, "row")
     hip.tf_nhwc_to_nchw_f16(vt.ptr, vp.ptr, heads, HS, 1, Tkp, _sh())         # (Tkp, HS) -> (HS, Tkp) for every head
     o = DeviceArray.empty((B, NH, Tq, HS), np.float16, "row")
-    s32 = DeviceArray.empty((Tq, Tk), np.float32, "row")            # one head's scores / probabilities, reused (stream order)
-    pr = DeviceArray.empty((Tq, Tkp), np.float16, "row")
+    # one head's scores / probabilities, reused (stream order) -- tiled over query rows so that the fp32 score buffer stays below 64 MiB
+    # whatever the sequence length (a 96 x 96 latent's single-head attention would otherwise hold 9216 x 9216 x 4 B = 340 MB)
+    RB = max(8, min(Tq, (64 << 20) // (4 * max(Tk, 1)) // 8 * 8))
+    s32 = DeviceArray.empty((RB, Tk), np.float32, "row")
+    pr = DeviceArray.empty((RB, Tkp), np.float16, "row")
     mrows = mask.shape[0] if mask is not None else 1
     for bh in range(heads):
-        hip.tf_linear_f32out_f16(s32.ptr, q.ptr + bh * Tq * HS * 2, k.ptr + bh * Tk * HS * 2, Tq, Tk, HS, _sh())
-        mk = None
-        if mask is not None:
-            mk = mask.ptr + (bh * Tq * Tk * 4 if mrows != Tq else 0)
-        hip.tf_softmax_mask_rows_f32in_f16(pr.ptr, Tkp, s32.ptr, Tk, mk, Tq, Tk, scale, Tq, _sh())
-        hip.tf_linear_f16(o.ptr + bh * Tq * HS * 2, pr.ptr, vt.ptr + bh * HS * Tkp * 2, None, None, Tq, HS, Tkp, 0, None, 0, _sh())
+        for r0 in range(0, Tq, RB):
+            rows = min(RB, Tq - r0)
+            hip.tf_linear_f32out_f16(s32.ptr, q.ptr + (bh * Tq + r0) * HS * 2, k.ptr + bh * Tk * HS * 2, rows, Tk, HS, _sh())
+            mk = None
+            if mask is not None:
+                mk = mask.ptr + ((bh * Tq if mrows != Tq else 0) + r0) * Tk * 4
+            hip.tf_softmax_mask_rows_f32in_f16(pr.ptr, Tkp, s32.ptr, Tk, mk, rows, Tk, scale, rows, _sh())
+            hip.tf_linear_f16(o.ptr + (bh * Tq + r0) * HS * 2, pr.ptr, vt.ptr + bh * HS * Tkp * 2, None, None, rows, HS, Tkp, 0, None, 0, _sh())
     return o
 
 

@@ -36,9 +36,11 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, ablation=False):
-    objdir = os.path.join(LIBDIR, "ablation") if ablation else LIBDIR
-    lib = LIB_ABLATION if ablation else LIB
+def build(force=False, verbose=False, ablation=False, tag=None, defs=()):
+    """tag / defs: an EXPERIMENTAL build for same-box A/B runs (tools/ab_lib.sh, TF_LIB_PATH): the sources compiled with extra -D definitions into
+    lib/<tag>/ and lib/libtinyfusers_hip_<tag>.so (`python -m tinyfusers_amd.build --tag prio1 -DTF_PP_PRIO=1`); never loaded by default."""
+    objdir = os.path.join(LIBDIR, "ablation") if ablation else os.path.join(LIBDIR, tag) if tag else LIBDIR
+    lib = LIB_ABLATION if ablation else os.path.join(LIBDIR, f"libtinyfusers_hip_{tag}.so") if tag else LIB
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))] + [os.path.join(os.path.dirname(HERE), "include", "tinyfusers_hip.h")]
@@ -48,7 +50,7 @@ def build(force=False, verbose=False, ablation=False):
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([hipcc] + FLAGS + (["-DTF_ABLATION"] if ablation else []) + EXTRA.get(s, []) + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + (["-DTF_ABLATION"] if ablation else []) + list(defs) + EXTRA.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -64,4 +66,5 @@ def build(force=False, verbose=False, ablation=False):
 
 
 if __name__ == "__main__":
-    print(build(force="-f" in sys.argv, verbose=True, ablation="--ablation" in sys.argv))
+    _tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else None
+    print(build(force="-f" in sys.argv, verbose=True, ablation="--ablation" in sys.argv, tag=_tag, defs=[a for a in sys.argv[1:] if a.startswith("-D")]))

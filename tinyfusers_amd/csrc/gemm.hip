@@ -4,8 +4,17 @@
 // parallel; gemm_common.h holds GemmP, the shared epilogue and the launcher declarations (its head comment describes the computation).
 #include "gemm_common.h"
 
+// Split-K partial slabs are fp32 or -- round 4, GemmP::part16 -- fp16 (half the bytes of the seam: a slab is written once and read once, both
+// through HBM / L2; the reducer accumulates in fp32 in split order either way).  PT = the slab's element type.
+template <typename PT> __device__ __forceinline__ f4 part_load4(const PT* p);
+template <> __device__ __forceinline__ f4 part_load4<float>(const float* p) { return *reinterpret_cast<const f4*>(p); }
+template <> __device__ __forceinline__ f4 part_load4<half_t>(const half_t* p) {
+  const h4 h = *reinterpret_cast<const h4*>(p);
+  return (f4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
 // split-K reduce + epilogue: y[m,n] = sum_z partial[z,m,n] + bias + bias_nc + residual   (N % 4 == 0 fast path)
-__global__ void __launch_bounds__(256) k_splitk_reduce(half_t* __restrict__ y, const float* __restrict__ partial, const half_t* __restrict__ bias,
+template <typename PT>
+__global__ void __launch_bounds__(256) k_splitk_reduce(half_t* __restrict__ y, const PT* __restrict__ partial, const half_t* __restrict__ bias,
                                                        const half_t* __restrict__ bias_nc, const half_t* __restrict__ residual, int M, int N,
                                                        int HoWo, int splitk, long long bnc_stride) {
   long long total = (long long)M * N;
@@ -19,7 +28,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(half_t* __restrict__ y, c
       for (int z0 = 0; z0 < splitk; z0 += 8) {           // 8 independent loads in flight, added in split order
         f4 u[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) u[i] = z0 + i < splitk ? *reinterpret_cast<const f4*>(partial + (long long)(z0 + i) * total + e0) : (f4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 8; ++i) u[i] = z0 + i < splitk ? part_load4<PT>(partial + (long long)(z0 + i) * total + e0) : (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 8; ++i) v += u[i];
       }
@@ -34,7 +43,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(half_t* __restrict__ y, c
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += gs) {
       int m = (int)(i / N), n = (int)(i - (long long)m * N);
       float v = 0.f;
-      for (int z = 0; z < splitk; ++z) v += partial[(long long)z * total + i];
+      for (int z = 0; z < splitk; ++z) v += (float)partial[(long long)z * total + i];
       if (bias) v += (float)bias[n];
       if (bias_nc) v += (float)bias_nc[(long long)(m / HoWo) * bnc_stride + n];
       if (residual) v += (float)residual[i];
@@ -47,7 +56,8 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(half_t* __restrict__ y, c
 // whole output rows (R = HoWo / chunks); thread t owns column quad t % nq and the rows r = t / nq (mod RL), so the
 // per-channel sums stay in its registers; row lanes and channels -> groups meet through LDS in a fixed order.
 // The split partials of an element are fetched 8 at a time (independent loads) and added in split order.
-__global__ void __launch_bounds__(1024) k_splitk_reduce_gn(half_t* __restrict__ y, const float* __restrict__ partial, const half_t* __restrict__ bias,
+template <typename PT>
+__global__ void __launch_bounds__(1024) k_splitk_reduce_gn(half_t* __restrict__ y, const PT* __restrict__ partial, const half_t* __restrict__ bias,
                                                            const half_t* __restrict__ bias_nc, const half_t* __restrict__ residual, int M, int N,
                                                            int HoWo, int splitk, long long bnc_stride, float* __restrict__ gn_part, int G, int cpg,
                                                            int chunks, int R, int RL) {
@@ -71,7 +81,7 @@ __global__ void __launch_bounds__(1024) k_splitk_reduce_gn(half_t* __restrict__ 
       for (int z0 = 0; z0 < splitk; z0 += 8) {
         f4 u[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) u[i] = z0 + i < splitk ? *reinterpret_cast<const f4*>(partial + (long long)(z0 + i) * total + e0) : (f4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 8; ++i) u[i] = z0 + i < splitk ? part_load4<PT>(partial + (long long)(z0 + i) * total + e0) : (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 8; ++i) v += u[i];
       }
@@ -110,7 +120,8 @@ __global__ void __launch_bounds__(1024) k_splitk_reduce_gn(half_t* __restrict__ 
 // residual, rounded to fp16 (y, optional), per-channel sums in registers -> LDS -> fixed-order fold -> (mean, rstd) -> z = silu?(y a + b).
 // Also leaves the (sum, sum of squares) of every group as a one-chunk partial table, so y.gn stays available to later consumers.
 #define RGA_MAXR 8
-__global__ void __launch_bounds__(1024) k_splitk_reduce_gn_apply(half_t* __restrict__ y, half_t* __restrict__ z, const float* __restrict__ partial,
+template <typename PT>
+__global__ void __launch_bounds__(1024) k_splitk_reduce_gn_apply(half_t* __restrict__ y, half_t* __restrict__ z, const PT* __restrict__ partial,
                                                                  const half_t* __restrict__ bias, const half_t* __restrict__ bias_nc,
                                                                  const half_t* __restrict__ residual, int M, int N, int HoWo, int splitk, long long bnc_stride,
                                                                  float* __restrict__ gn_part, int G, int cpg, int gpb, const half_t* __restrict__ gamma,
@@ -144,7 +155,7 @@ __global__ void __launch_bounds__(1024) k_splitk_reduce_gn_apply(half_t* __restr
       for (int z0 = 0; z0 < splitk; z0 += 8) {
         f4 u[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) u[i] = z0 + i < splitk ? *reinterpret_cast<const f4*>(partial + (long long)(z0 + i) * total + e0) : (f4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 8; ++i) u[i] = z0 + i < splitk ? part_load4<PT>(partial + (long long)(z0 + i) * total + e0) : (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc += u[i];
       }
@@ -355,6 +366,7 @@ static std::map<std::array<int, 8>, std::pair<long long, double>> g_prof_shapes;
 static std::vector<ProfRec> g_prof_pending;
 
 static int g_dbg = 0, g_force_wide = -1, g_force_order = -1;
+static int g_part16 = 1;                                  // split-K partial slabs in fp16 (tf_gemm_splitk_partials: 16 / 32)
 struct TileCfg { int bm, bn, splitk; };
 
 // Cost model (microseconds) calibrated on MI355X with tools/gemm_bench.py: a K tile costs the larger of its LDS-DMA
@@ -464,6 +476,14 @@ static bool gi_any_ok(const GemmP& p) {
   return false;
 }
 
+// K tiles of a launch: 64 elements, except the e4m3 ping-pong kernel's 128 (128 BYTES of a row either way).  Everything that reasons about
+// split-K -- the effective split count, whether a reduce launch follows, the tuner's "at least 4 K tiles per split" -- goes through this
+static int ktiles_for(const GemmP& p, int variant) { return (variant == 4 && p.fp8) ? (p.K + 127) / 128 : (p.K + 63) / 64; }
+// the split count a launch really runs with (launch_one rounds the requested one to whole K tiles)
+static int eff_splitk(const GemmP& p, int variant, int splitk) {
+  const int kt = ktiles_for(p, variant), kps = (kt + splitk - 1) / splitk;
+  return (kt + kps - 1) / kps;
+}
 // one fully specified launch (tile, split-K, ring variant) of the kernel family (+ the split-K reduce)
 // variant: 0 deep ring, 1 WIDE (two blocks per CU), 2 PATCH (k_igemm_patch; falls back to 0 when the shape is not eligible),
 // 3 ALL8 (deep ring, the consumer waves issue part of the weight pieces; falls back to 0 for channel counts off the 64 grid)
@@ -476,10 +496,11 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
     return TF_E_UNSUPPORTED;
   }
   p.order = order;
-  if (variant == 4 && p.fp8) p.ktiles = (p.K + 127) / 128;   // the e4m3 ping-pong kernel's K tile is 128 elements (128 bytes of a row)
+  p.ktiles = ktiles_for(p, variant);
   p.ktiles_per_split = (p.ktiles + c.splitk - 1) / c.splitk;
   p.splitk = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
   p.partial = (float*)workspace;
+  p.part16 = (g_part16 && p.splitk > 1 && (p.N & 7) == 0) ? 1 : 0;     // 16-byte rows segments of halves; other widths keep fp32 slabs
   p.ntm = (p.M + c.bm - 1) / c.bm;
   p.ntn = (p.N + c.bn - 1) / c.bn;
   float* gn_part = p.gn_part;
@@ -514,9 +535,16 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
   if (p.splitk > 1 && p.on_z && p.gn_part && rga_geometry(p.HoWo, p.N, p.gn_G, &rg_gpb, &rg_cv, &rg_rps, &rg_lds)) {
 
     static bool attr_set = false;
-    if (!attr_set) { TF_HIP(hipFuncSetAttribute((const void*)k_splitk_reduce_gn_apply, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+    if (!attr_set) {
+      TF_HIP(hipFuncSetAttribute((const void*)k_splitk_reduce_gn_apply<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      TF_HIP(hipFuncSetAttribute((const void*)k_splitk_reduce_gn_apply<half_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
     const int nimg = p.M / p.HoWo;
-    hipLaunchKernelGGL(k_splitk_reduce_gn_apply, dim3(nimg * (p.gn_G / rg_gpb)), dim3(1024), rg_lds, st, p.y, p.on_z, (const float*)p.partial, p.bias, p.bias_nc,
+    if (p.part16) hipLaunchKernelGGL(k_splitk_reduce_gn_apply<half_t>, dim3(nimg * (p.gn_G / rg_gpb)), dim3(1024), rg_lds, st, p.y, p.on_z, (const half_t*)p.partial, p.bias, p.bias_nc,
+                       p.residual, p.M, p.N, p.HoWo, p.splitk, p.bias_nc_stride, p.gn_part, p.gn_G, p.gn_cpg, rg_gpb, p.on_gamma, p.on_beta, p.on_eps, p.on_silu,
+                       rg_rps, rg_cv);
+    else hipLaunchKernelGGL(k_splitk_reduce_gn_apply<float>, dim3(nimg * (p.gn_G / rg_gpb)), dim3(1024), rg_lds, st, p.y, p.on_z, (const float*)p.partial, p.bias, p.bias_nc,
                        p.residual, p.M, p.N, p.HoWo, p.splitk, p.bias_nc_stride, p.gn_part, p.gn_G, p.gn_cpg, rg_gpb, p.on_gamma, p.on_beta, p.on_eps, p.on_silu,
                        rg_rps, rg_cv);
     TF_LAUNCH_CHECK();
@@ -526,7 +554,9 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
     int RL = 1024 / nq;
     if (RL > R) RL = R;
     int threads = (RL * nq + 63) & ~63;
-    hipLaunchKernelGGL(k_splitk_reduce_gn, dim3(p.M / R), dim3(threads), (size_t)RL * p.N * 2 * sizeof(float), st, p.y, (const float*)p.partial,
+    if (p.part16) hipLaunchKernelGGL(k_splitk_reduce_gn<half_t>, dim3(p.M / R), dim3(threads), (size_t)RL * p.N * 2 * sizeof(float), st, p.y, (const half_t*)p.partial,
+                       p.bias, p.bias_nc, p.residual, p.M, p.N, p.HoWo, p.splitk, p.bias_nc_stride, p.gn_part, p.gn_G, p.gn_cpg, p.gn_chunks, R, RL);
+    else hipLaunchKernelGGL(k_splitk_reduce_gn<float>, dim3(p.M / R), dim3(threads), (size_t)RL * p.N * 2 * sizeof(float), st, p.y, (const float*)p.partial,
                        p.bias, p.bias_nc, p.residual, p.M, p.N, p.HoWo, p.splitk, p.bias_nc_stride, p.gn_part, p.gn_G, p.gn_cpg, p.gn_chunks, R, RL);
     TF_LAUNCH_CHECK();
   } else if (p.splitk > 1) {
@@ -534,7 +564,9 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
     int grid = (int)((nv + 255) / 256);
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_splitk_reduce, dim3(grid), dim3(256), 0, st, p.y, (const float*)p.partial, p.bias, p.bias_nc, p.residual, p.M, p.N,
+    if (p.part16) hipLaunchKernelGGL(k_splitk_reduce<half_t>, dim3(grid), dim3(256), 0, st, p.y, (const half_t*)p.partial, p.bias, p.bias_nc, p.residual, p.M, p.N,
+                       p.HoWo, p.splitk, p.bias_nc_stride);
+    else hipLaunchKernelGGL(k_splitk_reduce<float>, dim3(grid), dim3(256), 0, st, p.y, (const float*)p.partial, p.bias, p.bias_nc, p.residual, p.M, p.N,
                        p.HoWo, p.splitk, p.bias_nc_stride);
     TF_LAUNCH_CHECK();
   }
@@ -646,7 +678,7 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
     const int bm = ppbm[bi], bn = ppbn[ci];
     if (!pp_ok(p, bn, bm) || p.M <= 256) continue;
     for (int sk = 1; sk <= 8; sk *= 2) {
-      if (sk > 1 && (p.act == 1 || p.out32 || p.ln_colsum || p.ktiles / sk < 4 || !workspace || (size_t)sk * p.M * p.N * 4 > workspace_bytes)) break;
+      if (sk > 1 && (p.act == 1 || p.out32 || p.ln_colsum || ktiles_for(p, 4) / sk < 4 || !workspace || (size_t)sk * p.M * p.N * 4 > workspace_bytes)) break;
       long long blocks = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * sk;
       if (blocks < 128) continue;
       if (sk > 1 && blocks > 1024) break;
@@ -793,7 +825,7 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
   if (p.gn_part) {
     // statistics ride along only when the chosen tiling maps m-tiles onto whole images; otherwise the caller is told
     // (chunks = 0) and runs the stand-alone statistics pass
-    int kps = (p.ktiles + t.c.splitk - 1) / t.c.splitk, eff = (p.ktiles + kps - 1) / kps;
+    const int eff = eff_splitk(p, wide, t.c.splitk);
     TileCfg sc = t.c;
     sc.bm = stats_bm(t.c.bm, wide);
     if (eff == 1 && !gn_tile_ok(p, sc.bm, sc.bn)) p.gn_part = nullptr;
@@ -807,8 +839,7 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
   if (rc) return rc;
   if (g_prof) {
     // the second bracket only where a reduce launch followed the GEMM (an event pair of its own costs ~2 us of stream time)
-    const int kps = (p.ktiles + t.c.splitk - 1) / t.c.splitk;
-    rec.has_reduce = (p.ktiles + kps - 1) / kps > 1;
+    rec.has_reduce = eff_splitk(p, wide, t.c.splitk) > 1;
     if (rec.has_reduce) TF_HIP(hipEventRecord(rec.c, st));
     g_prof_pending.push_back(rec);
   }
@@ -916,6 +947,12 @@ int tf_gemm_tune_load(const char* path) {
     if (ok) g_tuned[k] = {{bm, bn, sk}, wide < 0 || wide > 5 ? 0 : wide, order != 0 ? 1 : 0};
   }
   fclose(f);
+  return TF_OK;
+}
+// element type of the split-K partial slabs: 16 = fp16 (default; half the bytes of the split-K seam, fp32 accumulation in the reducer), 32 = fp32
+int tf_gemm_splitk_partials(int bits) {
+  TF_REQUIRE(bits == 16 || bits == 32, "tf_gemm_splitk_partials: bits=%d (16 or 32)", bits);
+  g_part16 = bits == 16;
   return TF_OK;
 }
 int tf_gemm_force_config(int bm, int bn, int splitk) { g_force_bm = bm; g_force_bn = bn; g_force_split = splitk; return TF_OK; }

@@ -69,6 +69,7 @@ struct GemmP {
   // the codes' byte counts) -- and so is an e4m3 output (out8; GEGLU only).  Such launches run on k_igemm_pp<F8> only; without it (fixed scale 1:
   // the round-2 API) only on k_igemm8
   int mx;
+  int part16;           // the split-K partial slabs hold fp16 (p.partial then points at halves; N % 8 == 0): half the bytes of the seam, fp32 accumulation in the reducer
   // bfloat16 operands, bias, residual and output (tf_linear_bf16 / tf_conv2d_bf16): the plain deep ring with the bf16 MFMA, no split-K
   int bf16;
   // tf_linear_f32out_f16: the raw fp32 accumulators go to out32[m, n] (no bias / residual / activation, never split along K) -- the
@@ -419,6 +420,12 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
     const float* r = sc + row * RS + c8 * 8;
     f4 v0 = *reinterpret_cast<const f4*>(r), v1 = *reinterpret_cast<const f4*>(r + 4);
     const long long o = (long long)m * p.N + n;
+    if (part && p.part16 && p.splitk > 1) {                 // fp16 slab (N % 8 == 0: one 16-byte store per item)
+      h8 hv;
+      for (int e = 0; e < 4; ++e) { hv[e] = (half_t)v0[e]; hv[4 + e] = (half_t)v1[e]; }
+      *reinterpret_cast<h8*>(reinterpret_cast<half_t*>(p.partial) + (long long)split * p.M * p.N + o) = hv;
+      continue;
+    }
     if (part) {
       if (vec) { *reinterpret_cast<f4*>(part + o) = v0; *reinterpret_cast<f4*>(part + o + 4) = v1; }
       else { for (int e = 0; e < 8 && n + e < p.N; ++e) part[o + e] = e < 4 ? v0[e] : v1[e - 4]; }

@@ -50,6 +50,12 @@
 //   the activation FRAGMENTS the wave multiplies anyway -- lane (lr, lg) holds the 8 k-values k = 8 lg .. of row lr of every fragment, so
 //   8 v_dot2_f32_f16 per fragment (in the MFMA block's spare issue slots) keep (sum, sum of squares) of that row's share, two lane
 //   shuffles at the end complete the row -- and they end up in exactly the lanes whose accumulators belong to that row.
+#ifndef TF_PP_V2
+#define TF_PP_V2 0        // experiment switch (tagged build): 1 = one barrier per K tile, loads issued between MFMA chunks (see the tile loop)
+#endif
+#ifndef TF_PP_PRIO
+#define TF_PP_PRIO 0      // experiment switch of tools' tagged builds: 0 = s_setprio 1 around every MFMA block (shipped), 1 = static priority for waves 4-7, 2 = none
+#endif
 template <int BN, int NP, bool FASTA, bool DBG = false, bool F8 = false, bool H2 = false, int BM = 256, bool LNF = false>
 __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
   static_assert(!LNF || !F8, "the LayerNorm fold is an fp16 path");
@@ -225,12 +231,14 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
       prep_act();
     }
   };
-  auto stage_act = [&](int slot) {
+  // pieces [i0, i1) of this wave's APL activation loads of a tile (H2: the first APW are the first slab's half-masked loads, the next APW the second's)
+  auto stage_act = [&](int slot, int i0 = 0, int i1 = 64) {
     const unsigned base = lds0 + (unsigned)slot * STAGE + (unsigned)wid * 1024u;
     // (the scalars are wave-uniform by construction; the readfirstlanes are no-ops that keep them in SGPRs whatever the compiler's
     // divergence analysis makes of the bookkeeping's control flow)
-    auto one = [&](int lo, int hi, int nb, int r_, int s_, int c0_, int ld_, int cq, int hsel) {
-      // cq: this lane's 16-byte chunk inside the slab; hsel < 0: every lane issues, else only the lanes of half hsel
+    auto one = [&](int lo, int hi, int nb, int r_, int s_, int c0_, int ld_, int cq, int hsel, int j0, int j1) {
+      // cq: this lane's 16-byte chunk inside the slab; hsel < 0: every lane issues, else only the lanes of half hsel; pieces [j0, j1) of APW
+      if (j0 >= j1) return;
       i4v rs;
       rs[0] = __builtin_amdgcn_readfirstlane(lo); rs[1] = __builtin_amdgcn_readfirstlane(hi);
       rs[2] = __builtin_amdgcn_readfirstlane(nb); rs[3] = 0x00020000;
@@ -240,6 +248,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
         const int vc = s_c0 + cq * 16;
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
+          if (i < j0 || i >= j1) continue;
           unsigned off = __umul24((unsigned)g_a[i], (unsigned)s_ld) + (unsigned)vc;
           if (mine) dma16(rs, (g_b[i] & s_r) ? off : TF_OOB, base + (unsigned)i * 8192u);
         }
@@ -248,6 +257,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
         const int cc = s_c0 + cq * (16 / ES);
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
+          if (i < j0 || i >= j1) continue;
           int hi_ = g_a[i] + s_r, wi = g_b[i] + s_s;
           bool ok = (unsigned)hi_ < (unsigned)Hl && (unsigned)wi < (unsigned)Wl;
           int pix = g_c[i] + (hi_ >> ups) * Wd + (wi >> ups);
@@ -255,23 +265,24 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
         }
       }
     };
-    if constexpr (!F8) one(a_lo, a_hi, a_nb, a_r, a_s, a_c0, a_ld, cs, -1);
+    const auto lim = [](int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; };
+    if constexpr (!F8) one(a_lo, a_hi, a_nb, a_r, a_s, a_c0, a_ld, cs, -1, i0, i1);
     else if constexpr (H2) {
-      one(b_lo, b_hi, b_nb, b_r, b_s, b_c0, b_ld, cs & 3, 0);
-      one(a_lo, a_hi, a_nb, a_r, a_s, a_c0, a_ld, cs & 3, 1);
-    } else one(b_lo, b_hi, b_nb, b_r, b_s, b_c0, b_ld, cs, -1);       // channel counts on the 128 grid: the two slabs of a tile are 128 contiguous bytes
+      one(b_lo, b_hi, b_nb, b_r, b_s, b_c0, b_ld, cs & 3, 0, lim(i0, 0, APW), lim(i1, 0, APW));
+      one(a_lo, a_hi, a_nb, a_r, a_s, a_c0, a_ld, cs & 3, 1, lim(i0 - APW, 0, APW), lim(i1 - APW, 0, APW));
+    } else one(b_lo, b_hi, b_nb, b_r, b_s, b_c0, b_ld, cs, -1, i0, i1);       // channel counts on the 128 grid: the two slabs of a tile are 128 contiguous bytes
   };
-  auto stage_w = [&](int slot, int kt) {
+  auto stage_w = [&](int slot, int kt, int i0 = 0, int i1 = 64) {
     const unsigned base = lds0 + (unsigned)slot * STAGE + (unsigned)(BM / 8 + wid) * 1024u;
     const unsigned kb = (unsigned)kt * 128u;
 #pragma unroll
     for (int i = 0; i < WPW; ++i)
-      if (WREM == 0 || i < WPW - 1 || wid < WREM) dma16(rs_w, (gw[i] != TF_OOB && (!F8 || (int)kb < klim)) ? gw[i] + kb : TF_OOB, base + (unsigned)i * 8192u);
+      if (i >= i0 && i < i1 && (WREM == 0 || i < WPW - 1 || wid < WREM)) dma16(rs_w, (gw[i] != TF_OOB && (!F8 || (int)kb < klim)) ? gw[i] + kb : TF_OOB, base + (unsigned)i * 8192u);
   };
   // F8: the E8M0 bytes of the tile's activation rows (waves 4-7; every one of them issues SCL loads so that the counts stay uniform -- the
   // rows beyond BM of the 192-row tile fetch out of range).  A source tensor holds its scale bytes behind its codes (offset = the codes'
   // byte count `nb`), C / 32 per pixel; a 64-channel slab starting at byte offset c0 of a pixel's codes has its 2 bytes at c0 / 32.
-  auto stage_sc = [&](int slot) {
+  auto stage_sc = [&](int slot, int i0 = 0, int i1 = 2) {
     if constexpr (F8) {
       if (wid < 4) return;
       const unsigned base = lds0 + (unsigned)NS * STAGE + (unsigned)slot * SCS + (unsigned)(wid - 4) * 256u;
@@ -288,9 +299,9 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
           asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_ushort %1, %2, 0 offen lds" :: "s"(__builtin_amdgcn_readfirstlane((int)ldsb)), "v"(off), "s"(rs) : "memory");
       };
       if constexpr (H2) {
-        one(b_lo, b_hi, b_nb, b_r, b_c0, b_ld, base, std::false_type{});
-        one(a_lo, a_hi, a_nb, a_r, a_c0, a_ld, base + 1024u, std::false_type{});
-      } else one(b_lo, b_hi, b_nb, b_r, b_c0, b_ld, base, std::true_type{});
+        if (i0 <= 0 && i1 > 0) one(b_lo, b_hi, b_nb, b_r, b_c0, b_ld, base, std::false_type{});
+        if (i0 <= 1 && i1 > 1) one(a_lo, a_hi, a_nb, a_r, a_c0, a_ld, base + 1024u, std::false_type{});
+      } else if (i0 <= 0 && i1 > 0) one(b_lo, b_hi, b_nb, b_r, b_c0, b_ld, base, std::true_type{});
     }
   };
   // "this wave's pieces of every tile but the newest one (NEWEST) / of every tile (!NEWEST) have landed"
@@ -372,7 +383,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
         return;
       }
     }
-    __builtin_amdgcn_s_setprio(1);
+    if (TF_PP_PRIO == 0) __builtin_amdgcn_s_setprio(1);
     if constexpr (F8) {
       typedef int v8i __attribute__((ext_vector_type(8)));
       typedef int v4i __attribute__((ext_vector_type(4)));
@@ -398,8 +409,43 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
 #pragma unroll
           for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[f][i], xf[f][j], acc[i][j], 0, 0, 0);
     }
-    __builtin_amdgcn_s_setprio(0);
+    if (TF_PP_PRIO == 0) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
+  };
+  // chunk c of the MFMA block of a K tile (the experiment's form): the MJ instructions of (k-step c / NI, channel tile c % NI)
+  auto mma_chunk = [&](int c) {
+    const int f = c / NI, i = c % NI;
+    if constexpr (F8) {
+      typedef int v8i __attribute__((ext_vector_type(8)));
+      typedef int v4i __attribute__((ext_vector_type(4)));
+      v4i lo = __builtin_bit_cast(v4i, wf[0][i]), hi = __builtin_bit_cast(v4i, wf[KF - 1][i]);
+      const v8i wv = (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (f == 0) {
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+          v4i xl = __builtin_bit_cast(v4i, xf[0][j]), xh = __builtin_bit_cast(v4i, xf[KF - 1][j]);
+          const v8i xv = (v8i){xl[0], xl[1], xl[2], xl[3], xh[0], xh[1], xh[2], xh[3]};
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, xv, acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, sx[j]);
+        }
+      }
+    } else {
+      if constexpr (LNF) {
+        if (i == 0) {
+          typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+          const hh2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+          for (int j = 0; j < MJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              hh2 v = {xf[f][j][2 * e], xf[f][j][2 * e + 1]};
+              ls[j] = __builtin_amdgcn_fdot2(v, one2, ls[j], false);
+              lq[j] = __builtin_amdgcn_fdot2(v, v, lq[j], false);
+            }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[f][i], xf[f][j], acc[i][j], 0, 0, 0);
+    }
   };
   auto barrier = [&]() {
     __builtin_amdgcn_s_barrier();
@@ -424,7 +470,8 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
   if (D < nt) prep_tile();                                 // the scalars of tile D: its pieces ride on tile 0
   if (D >= 2 && nt >= 2) wait_landed(std::true_type{}); else wait_landed(std::false_type{});     // tile 0 landed
   barrier();                                               // P: tile 0 is visible to every wave
-  if (grp == 1) barrier();                                 // the second half falls one barrier behind
+  if (grp == 1 && !(NP == 1 && TF_PP_V2 != 0)) barrier();  // the second half falls one barrier behind
+  if (TF_PP_PRIO == 1 && grp == 1) __builtin_amdgcn_s_setprio(1);      // (experiment: static priority for the later-dispatched half, no per-segment flips)
   int rs = 0, ws = D % NS;                                 // ring slot of tile t / of tile t + D
   int ktw = kt_begin + D;                                  // K tile whose weight pieces are staged next
   // one K tile.  MORE: tile t + D exists (its pieces are issued during this tile, and the wait for tile t + 1 leaves them in flight);
@@ -434,7 +481,32 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
     const char* sb = smem + rs * STAGE;
     bool more = MORE;
     if constexpr (DBG) { if (p.dbg & 4) more = false; }
-    if constexpr (NP == 1) {
+    if constexpr (NP == 1 && TF_PP_V2 != 0) {
+      // EXPERIMENT (tagged build -DTF_PP_V2=1): no ping-pong -- every wave runs the same phase, ONE barrier per K tile; a wave's loads of tile
+      // t + D are issued piece by piece between the chunks of its MFMA block (an LDS-DMA issue costs ~60 cycles among bare MFMAs against
+      // 100-185 inside a load segment that also carries the fragment reads: MI355X_MICROARCH.md), the partner wave of the SIMD covers the stalls
+      read_k(sb, 0, 0);
+      read_k(sb, 1, 1);
+      read_sc(rs);
+      constexpr int CH = F8 ? NI : KF * NI, PT = APL + WPW + SCL;      // MFMA chunks (MJ instructions each) and load instructions of a tile
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        mma_chunk(c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+          const int q0 = c * PT / CH, q1 = (c + 1) * PT / CH;                 // pieces issued behind this chunk
+          stage_act(ws, q0, q1 < APL ? q1 : APL);
+          stage_w(ws, ktw, q0 - APL, q1 - APL);
+          stage_sc(ws, q0 - APL - WPW, q1 - APL - WPW);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (MORE) prep_tile();
+      if constexpr (NEXT) wait_landed(more_c);
+      wait_lds_reads();
+      barrier();
+    } else if constexpr (NP == 1) {
       read_k(sb, 0, 0);
       read_k(sb, 1, 1);
       read_sc(rs);
@@ -473,7 +545,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
     for (; t + 1 < nt; ++t) tile(std::false_type{}, std::true_type{});         // drain: nothing left to stage
     tile(std::false_type{}, std::false_type{});                                // last tile
   }
-  if (grp == 0) barrier();                                 // the first half waits for the second: every wave is done with the ring
+  if (grp == 0 && !(NP == 1 && TF_PP_V2 != 0)) barrier();  // the first half waits for the second: every wave is done with the ring
 
   if constexpr (DBG) {
     if (p.dbg & 1) {

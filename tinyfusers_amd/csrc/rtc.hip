@@ -82,13 +82,21 @@ int tf_rtc_load(tfFunction_t* out_fn, const char* source, const char* func_name)
   if (!r) { code.resize(n); r = g_rtc.get_code(prog, code.data()); }
   g_rtc.destroy(&prog);
   if (r || code.empty()) { tf_set_error("hiprtcGetCode failed with status %d", r); return TF_E_STATE; }
-  hipModule_t mod;
-  TF_HIP(hipModuleLoadData(&mod, code.data()));
+  // the code object stays alive with its module (one entry per loaded kernel: the loader may keep pointers into the image), and the
+  // modules are unloaded when the library goes away -- a Device that recompiles many sources no longer leaks them silently
+  struct Loaded { hipModule_t mod; std::vector<char> image; };
+  static std::vector<Loaded*> g_loaded;
+  Loaded* L = new Loaded{nullptr, std::move(code)};
+  hipError_t le = hipModuleLoadData(&L->mod, L->image.data());
+  if (le != hipSuccess) { tf_set_error("hipModuleLoadData failed: %s", hipGetErrorString(le)); delete L; return (int)le; }
+  g_loaded.push_back(L);
+  hipModule_t mod = L->mod;
   hipFunction_t fn;
   hipError_t e = hipModuleGetFunction(&fn, mod, func_name);
   if (e != hipSuccess) {
     tf_set_error("hipModuleGetFunction(%s) failed: %s", func_name, hipGetErrorString(e));
     (void)hipModuleUnload(mod); (void)hipGetLastError();
+    g_loaded.pop_back(); delete L;
     return TF_E_ARG;
   }
   *out_fn = (tfFunction_t)fn;
@@ -100,6 +108,10 @@ int tf_rtc_launch(tfFunction_t fn, unsigned gx, unsigned gy, unsigned gz, unsign
                   tfStream_t s, void** params) {
   TF_REQUIRE(fn, "tf_rtc_launch: null function");
   TF_REQUIRE(gx && gy && gz && bx && by && bz && (unsigned long long)bx * by * bz <= 1024, "tf_rtc_launch: bad launch geometry (%u,%u,%u)x(%u,%u,%u)", gx, gy, gz, bx, by, bz);
+  if (shared_bytes > 64 * 1024) {                            // more dynamic LDS than the default limit: raise the kernel's attribute (160 KiB per CU on gfx950)
+    TF_REQUIRE(shared_bytes <= 160 * 1024, "tf_rtc_launch: %u bytes of dynamic LDS exceed the 160 KiB of a CU", shared_bytes);
+    TF_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shared_bytes));
+  }
   TF_HIP(hipModuleLaunchKernel((hipFunction_t)fn, gx, gy, gz, bx, by, bz, shared_bytes, tf_hs(s), params, nullptr));
   return TF_OK;
 }

@@ -96,6 +96,8 @@ if _TUNE and os.path.exists(_TUNE):
 # One process per GPU: with several ranks every rank must pick the same kernels (bit-identical results across ranks, the same kernels in
 # every rank's timed region), so nothing is tuned at run time -- a shape without a row in the table is an error naming the shape
 # (TF_GEMM_AUTOTUNE=0/1/2 overrides: see tf_gemm_autotune in include/tinyfusers_hip.h)
+if os.environ.get("TF_SPLITK_PARTIALS"):          # A/B: 32 = the fp32 split-K partial slabs of rounds 1-3 (default 16: fp16 slabs, fp32 accumulation)
+    check(lib.tf_gemm_splitk_partials(int(os.environ["TF_SPLITK_PARTIALS"])), "tf_gemm_splitk_partials")
 _mode = os.environ.get("TF_GEMM_AUTOTUNE", "2" if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 else "")
 if _mode:
     check(lib.tf_gemm_autotune(int(_mode)), "tf_gemm_autotune")

@@ -47,10 +47,21 @@ class Device:
                 a = ctypes.c_void_p(a.ptr)
             elif hasattr(a, "dt_ptr"):
                 a = ctypes.c_void_p(_p(a.dt_ptr))
-            elif isinstance(a, int):
-                a = ctypes.c_int(a)
-            elif isinstance(a, float):
-                a = ctypes.c_float(a)
+            elif isinstance(a, (bool, np.bool_)):
+                a = ctypes.c_int(int(a))
+            elif isinstance(a, (int, np.integer)):
+                # a C int, as in the reference's wrappers; a value that does not fit is a 64-bit size or a pointer the caller must type
+                # itself (ctypes.c_longlong / c_void_p): truncating it silently would corrupt the launch
+                if isinstance(a, (np.int64, np.uint64)) and not -2 ** 31 <= int(a) < 2 ** 31:
+                    a = ctypes.c_longlong(int(a))
+                elif not -2 ** 31 <= int(a) < 2 ** 32:
+                    raise OverflowError(f"launch_func: integer argument {a} does not fit a C int; pass ctypes.c_longlong / ctypes.c_void_p")
+                else:
+                    a = ctypes.c_int(int(a) if int(a) < 2 ** 31 else int(a) - 2 ** 32)
+            elif isinstance(a, (float, np.floating)):
+                a = ctypes.c_double(float(a)) if isinstance(a, np.float64) else ctypes.c_float(float(a))
+            elif not isinstance(a, ctypes._SimpleCData) and not isinstance(a, (ctypes.Structure, ctypes.Array, ctypes._Pointer)):
+                raise TypeError(f"launch_func: cannot pass {type(a).__name__} to a kernel; use ctypes scalars / pointers, numbers or device arrays")
             keep.append(a)
         params = (ctypes.c_void_p * len(keep))(*[ctypes.cast(ctypes.byref(a), ctypes.c_void_p) for a in keep])
         hip.tf_rtc_launch(func, *g, *b, int(shared_mem), stream, params)

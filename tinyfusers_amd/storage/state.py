@@ -32,8 +32,12 @@ def _slots(root, prefix=""):
     attributes (``_x``), scalars and arrays that are not such leaves are not descended into; ``module`` is the object the slot
     belongs to (``param_shapes`` reads the shape off it)."""
     stack = [(prefix, root)]
-    while stack:
+    seen = set()                                           # ids of the containers / objects already walked: a public back-reference (a module holding
+    while stack:                                           # its parent, a compiled graph reachable from the root) must not make the walk spin
         pre, node = stack.pop()
+        if id(node) in seen:
+            continue
+        seen.add(id(node))
         below = []
         for name, child, owner in _children(node):
             dotted = f"{pre}.{name}" if pre else name

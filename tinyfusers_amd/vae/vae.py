@@ -10,8 +10,10 @@ from .encoder import Encoder
 
 
 class AutoencoderKL:
-    def __init__(self, init=True):
-        self.encoder = Encoder(init=init)
+    def __init__(self, init=True, init_encoder=None):
+        """init_encoder: draw random weights for the encoder side too (default: as ``init``).  The sampler never uses the encoder, so
+        StableDiffusion builds it empty (init_encoder=False: the module tree update_state walks, no 34 M parameters drawn and uploaded)."""
+        self.encoder = Encoder(init=init if init_encoder is None else bool(init_encoder))
         self.decoder = Decoder(init=init)
         self.quant_conv = Conv2d(8, 8, kernel_size=[1, 1], init=init)
         self.post_quant_conv = Conv2d(4, 4, kernel_size=[1, 1], init=init)

@@ -37,7 +37,7 @@ class StableDiffusion:
         self.alphas_cumprod = get_alphas_cumprod()
         self.model = namedtuple("DiffusionModel", ["diffusion_model"])(diffusion_model=UNetModel(cfg, init=init))
         from ..vae.vae import AutoencoderKL
-        self.first_stage_model = AutoencoderKL(init=init) if cfg is SD15 else None   # decode side only
+        self.first_stage_model = AutoencoderKL(init=init, init_encoder=False) if cfg is SD15 else None   # the sampler uses the decode side only: the encoder stays an empty tree until update_state fills it
         self.cond_stage_model = None
         if cfg is SD15:                  # variants/sd.py:12: cond_stage_model.transformer.text_model
             from ..vae.encoder import CLIPTextTransformer
