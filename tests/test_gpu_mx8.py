@@ -179,8 +179,13 @@ def test_conv2d_mx8_exact_integers_and_random_operands(tf, n, c, hw, cout, r, fo
     x8 = upload_mx(tf, _e4m3_codes(vals), sc, (n, c, hw, hw), "nhwc")
     w8 = tf.DeviceArray.from_numpy(_e4m3_codes(w).view(np.uint8).reshape(cout, -1), np.uint8, "row")
     one = tf.DeviceArray.from_numpy(np.ones(cout, np.float32), np.float32, "row")
-    with forced(*force):
-        y = fp8.conv2d_mx(x8, w8, one, None, (cout, c, r, r), [pad, pad]).numpy()
+    from tinyfusers_amd.native import hip
+    hip.tf_gemm_splitk_partials(32)                        # (exactness: an fp16 partial slab would round the halves of a split sum before they are added)
+    try:
+        with forced(*force):
+            y = fp8.conv2d_mx(x8, w8, one, None, (cout, c, r, r), [pad, pad]).numpy()
+    finally:
+        hip.tf_gemm_splitk_partials(16)
     xdeq = (vals.reshape(n, hw, hw, c // 32, 32) * np.exp2(sc.astype(np.float32) - 127.0)[..., None]).reshape(n, hw, hw, c).transpose(0, 3, 1, 2)
     wk = w.reshape(cout, r, r, c).transpose(0, 3, 1, 2)                        # KRSC storage -> KCRS
     want = O.conv_2d(xdeq, wk, (pad, pad), (1, 1), (1, 1)).numpy()
@@ -266,9 +271,14 @@ def test_linear_mx8_exact_integers(tf):
     w8 = tf.DeviceArray.from_numpy(_e4m3_codes(w).reshape(n, k), np.uint8, "row")
     one = tf.DeviceArray.from_numpy(np.ones(n, np.float32), np.float32, "row")
     want = (vals.reshape(m, k // 32, 32) * np.exp2(sc.astype(np.float32) - 127.0)[..., None]).reshape(m, k) @ w.T
+    from tinyfusers_amd.native import hip
     for cfg in ((192, 128, 1), (256, 160, 1), (192, 160, 2)):
-        with forced(*cfg):
-            y = fp8.linear_mx(x8, w8, one, None).numpy()
+        hip.tf_gemm_splitk_partials(32)                    # (exactness across the split: see the conv test)
+        try:
+            with forced(*cfg):
+                y = fp8.linear_mx(x8, w8, one, None).numpy()
+        finally:
+            hip.tf_gemm_splitk_partials(16)
         np.testing.assert_array_equal(y, want.astype(np.float16).astype(np.float32))
 
 

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma16(rs, am[i] >= 0 ? (unsigned)(am[i] * ld + cc) * 2u : TF_OOB, base + (unsigned)i * 4096u);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma16(rs_w, gw[i] != TF_OOB ? gw[i] + (unsigned)kt * 128u : TF_OOB, base + 16384u + (unsigned)i * 4096u);
+    for (int i = 0; i < 4; ++i) dma16_w(rs_w, gw[i] != TF_OOB ? gw[i] + (unsigned)kt * 128u : TF_OOB, base + 16384u + (unsigned)i * 4096u);
   };
   auto barrier = [&]() {
     __builtin_amdgcn_s_barrier();

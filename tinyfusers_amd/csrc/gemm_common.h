@@ -106,6 +106,13 @@ __device__ __forceinline__ void bload_lds16(rsrc_t rsrc, unsigned voffset_bytes,
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset_bytes, 0, 0, 0);
 }
 
+// the once-read WEIGHT stream of a launch: default cache policy (shipped) or, in the tagged experiment build -DTF_W_NT=1, non-temporal (aux = 2)
+#ifndef TF_W_NT
+#define TF_W_NT 0
+#endif
+__device__ __forceinline__ void bload_lds16_w(rsrc_t rsrc, unsigned voffset_bytes, char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset_bytes, 0, 0, TF_W_NT ? 2 : 0);
+}
 // s_waitcnt lgkmcnt(0) of the consumers' K loop as the BUILTIN (simm16 0xC07F: vmcnt 63, expcnt 7, lgkmcnt 0), not inline asm: the
 // compiler's own wait-count pass cannot see inside an asm string, so with the asm form it assumed the fragments read one tile earlier
 // could still be in flight and put s_waitcnt lgkmcnt(8 / 1 / 0) INSIDE the MFMA block -- which waits for the ds_reads of the NEXT tile
@@ -522,6 +529,15 @@ __device__ __forceinline__ i4v raw_rsrc(const void* base, unsigned bytes) {
   r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
   r[3] = 0x00020000;
   return r;
+}
+__device__ __forceinline__ void dma16_w(i4v rsrc, unsigned voffset_bytes, unsigned lds_base) {      // (weights: see TF_W_NT)
+#if TF_W_NT
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds"
+               :: "s"(__builtin_amdgcn_readfirstlane((int)lds_base)), "v"(voffset_bytes), "s"(rsrc) : "memory");
+#else
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(__builtin_amdgcn_readfirstlane((int)lds_base)), "v"(voffset_bytes), "s"(rsrc) : "memory");
+#endif
 }
 __device__ __forceinline__ void dma16(i4v rsrc, unsigned voffset_bytes, unsigned lds_base) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"

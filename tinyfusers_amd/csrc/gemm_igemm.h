@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
         } else {
           unsigned wo = (unsigned)g_c[i];
           unsigned off = (kvalid && wo != TF_OOB) ? wo + kb : TF_OOB;
-          bload_lds16(rs_w, off, dst);
+          bload_lds16_w(rs_w, off, dst);
         }
       }
     };
@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
       char* base = smem + buf * STAGE;
 #pragma unroll
       for (int i = 0; i < LPC; ++i)
-        bload_lds16(rs_cw, cw[i] != TF_OOB ? cw[i] + (unsigned)kt * 128u : TF_OOB, base + (NG - 4 * LPC + w4 + 4 * i) * 1024);
+        bload_lds16_w(rs_cw, cw[i] != TF_OOB ? cw[i] + (unsigned)kt * 128u : TF_OOB, base + (NG - 4 * LPC + w4 + 4 * i) * 1024);
     }
   };
   if constexpr (BM == 256) {

@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
 #pragma unroll
       for (int i = 0; i < BNP; ++i) {
         unsigned off = gw[i] != TF_OOB ? gw[i] + koff * 2u : TF_OOB;
-        bload_lds16(rs_w, off, base + (w4 + 4 * i) * 1024);
+        bload_lds16_w(rs_w, off, base + (w4 + 4 * i) * 1024);
       }
       const int n = count(sg, stap);
       if (extra) {

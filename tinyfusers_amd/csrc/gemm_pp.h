@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
     const unsigned kb = (unsigned)kt * 128u;
 #pragma unroll
     for (int i = 0; i < WPW; ++i)
-      if (i >= i0 && i < i1 && (WREM == 0 || i < WPW - 1 || wid < WREM)) dma16(rs_w, (gw[i] != TF_OOB && (!F8 || (int)kb < klim)) ? gw[i] + kb : TF_OOB, base + (unsigned)i * 8192u);
+      if (i >= i0 && i < i1 && (WREM == 0 || i < WPW - 1 || wid < WREM)) dma16_w(rs_w, (gw[i] != TF_OOB && (!F8 || (int)kb < klim)) ? gw[i] + kb : TF_OOB, base + (unsigned)i * 8192u);
   };
   // F8: the E8M0 bytes of the tile's activation rows (waves 4-7; every one of them issues SCL loads so that the counts stay uniform -- the
   // rows beyond BM of the 192-row tile fetch out of range).  A source tensor holds its scale bytes behind its codes (offset = the codes'
