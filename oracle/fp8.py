@@ -107,8 +107,8 @@ class policy:
     mx_gemm_supported says the kernel takes the shape (``assume_supported=True``: at every shape -- the precision budget of the policy as such,
     for a CPU study at a small batch).  Restores the fp32 functions on exit."""
 
-    def __init__(self, assume_supported=False):
-        self.assume_supported = assume_supported
+    def __init__(self, assume_supported=False, attention=False):
+        self.assume_supported, self.attention = assume_supported, attention      # attention: tinyfusers_amd/ff/fp8.py::ATTENTION (off by default)
 
     def __enter__(self):
         mx_ok = (lambda *a, **k: True) if self.assume_supported else mx_gemm_supported
@@ -149,7 +149,7 @@ class policy:
             b, t, c = x_.shape
             self_attn = context is None
             n_q = 3 * c if self_attn else c                   # the device fuses q | k | v of self-attention into one GEMM
-            if c < MIN_K or not mx_ok(b * t, n_q, c):
+            if not self.attention or c < MIN_K or not mx_ok(b * t, n_q, c):
                 return ca0(x, context, W, p, n_heads, head_merge)
             x8 = quant_act_mx(x_)
             q = lin0(x8, quant_weight(W[p + ".to_q.weight"])[0])

@@ -321,12 +321,16 @@ def test_transformer_block_fp8_policy_against_the_oracle(tf):
     Wt = {"p." + k: torch.from_numpy(v.astype(np.float16).astype(np.float32)) for k, v in W.items()}
     torch.set_num_threads(16)
     ref32 = oracle.basic_transformer_block(torch.from_numpy(x), torch.from_numpy(ctx), Wt, "p", nh).numpy()
-    with O8.policy():
+    from tinyfusers_amd.ff import fp8
+    with O8.policy(attention=True):
         ref8 = oracle.basic_transformer_block(torch.from_numpy(x), torch.from_numpy(ctx), Wt, "p", nh).numpy()
     config.set_dtype("fp8")
+    saved = fp8.ATTENTION
+    fp8.ATTENTION = True                                   # (off by default: measured slower; the path stays covered here)
     try:
         got = blk(tf.DeviceArray.from_numpy(x, np.float16, "row"), context=tf.DeviceArray.from_numpy(ctx, np.float16, "row")).numpy()
     finally:
+        fp8.ATTENTION = saved
         config.set_dtype("fp16")
     rl = lambda a, r: float(np.linalg.norm(a - r) / np.linalg.norm(r))
     assert np.isfinite(got).all()

@@ -106,7 +106,7 @@ class CrossAttention:
         from ..ff import fp8
         # config 5: the projections on block-scaled e4m3 operands where the kernel takes the shape (ff/fp8.py: K >= 640 levels) -- LayerNorm written
         # as an mx8 tensor instead of folded, the attention output quantised in one pass in front of to_out
-        mx_in = ln is not None and fp8.linear_ok(b * t, 3 * c if (context is None and kv is None) else c, x.shape[-1])
+        mx_in = fp8.ATTENTION and ln is not None and fp8.linear_ok(b * t, 3 * c if (context is None and kv is None) else c, x.shape[-1])
         if mx_in:
             if getattr(self, "_cache8", None) is None:
                 self._cache8 = {"qkv": {}, "q": {}, "out": {}}
@@ -144,7 +144,7 @@ class CrossAttention:
             os_ = (t * c, hs, c)                 # LDM-intended merge
         sdpa_strided(o, q, k, v, b, nh, t, tk, hs, qs, ks, ks, os_)
         lo = self.to_out[0]
-        if fp8.linear_ok(b * t, lo.weight.shape[0], c):
+        if fp8.ATTENTION and fp8.linear_ok(b * t, lo.weight.shape[0], c):
             if getattr(self, "_cache8", None) is None:
                 self._cache8 = {"qkv": {}, "q": {}, "out": {}}
             w8, wsc = fp8.pack_weight(lo.weight, self._cache8["out"])

@@ -10,8 +10,8 @@ GEGLU epilogue) or by one quantise pass (``quantize_mx``); the GEMM (k_igemm_pp<
 Which layers (measured on the CPU oracle with the same quantisers, tests/fp8_policy_study.py; BASELINE.md section 4 gate: UNet rel-L2 <= 0.1):
 e4m3 rounding noise adds up in quadrature whatever the scales -- every conv and linear in e4m3 gives 0.15 with block scales and with a
 fixed scale alike -- so the policy is a precision budget, spent where the FLOPs are: the two 3x3 convs of every ResBlock (0.048), the
-FeedForward pair (0.042 + 0.029), the attention projections q|k|v / q / to_out (0.018 + 0.010 + 0.022): 0.076 together at 32 x 32, 0.09 at
-64 x 64.  The 1x1 convs on the residual path (proj_in 0.060, proj_out 0.055, skip 0.092) and the up / down-sampling convs (0.056) stay fp16,
+FeedForward pair (0.042 + 0.029) -- 0.068 together -- and, optionally (``ATTENTION``, off: slower, see below), the attention projections
+q|k|v / q / to_out (0.018 + 0.010 + 0.022): 0.076 for all of them at 32 x 32, 0.094 at 64 x 64.  The 1x1 convs on the residual path (proj_in 0.060, proj_out 0.055, skip 0.092) and the up / down-sampling convs (0.056) stay fp16,
 as do conv_in / conv_out, the time-embedding GEMVs and everything outside the UNet.  A layer also stays fp16 where the block-scaled kernel
 cannot take its shape (tf_mx8_*_supported: it is the 192- / 256-row ping-pong kernel, i.e. launches that fill the chip -- config 5's
 regime) or where the fp16 kernels are faster (K = 320: ``MIN_K``).
@@ -138,7 +138,12 @@ def layer_norm_fp8(x, ln):
 
 
 # ---- block-scaled e4m3 ("mx8") -------------------------------------------------------------------------------------------------------
-MIN_K = 640        # below this the fp16 kernels win (LayerNorm folded into the persistent short-K kernel: 215 + 90 us against 293 + 74 us for the
+import os
+# The attention projections (q|k|v, q, to_out at K >= MIN_K) on e4m3 operands as well: within the precision budget and built (tests/test_gpu_mx8.py),
+# but MEASURED SLOWER at config 5 (profiles/r04_ab.txt: 23.78 against 23.59 ms per step): the LayerNorm can no longer be folded into the
+# projection (one launch and one pass more per block) and to_out needs a quantise pass, which costs more than the shorter GEMMs give back.  Off.
+ATTENTION = os.environ.get("TF_FP8_ATTN", "0") not in ("0", "")
+MIN_K = int(os.environ.get("TF_FP8_MIN_K", "640"))        # below this the fp16 kernels win (LayerNorm folded into the persistent short-K kernel: 215 + 90 us against 293 + 74 us for the
                    # e4m3 FeedForward pair at config 5's first level) -- K = 320 layers stay fp16
 _supported = {}
 
