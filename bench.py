@@ -39,8 +39,8 @@ sys.path.insert(0, ROOT)
 FLOP_PER_STEP = 1.6088e12          # algorithmic FLOPs of one step (conv 887.89 G + linear 466.49 G + SDPA 252.10 G + 2.28 G)
 PEAK_MFMA_TFLOPS = {"fp16": 2500.0, "fp8": 5000.0}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_PROFILE = os.path.join("profiles", "r03_pmc_traffic.json")
-FAMILY_PROFILE = os.path.join("profiles", "r03_kernel_family.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r04_pmc_traffic.json")
+FAMILY_PROFILE = os.path.join("profiles", "r04_kernel_family.json")
 
 
 def parse(argv=None):

@@ -22,21 +22,12 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_C
 python3 $R/tools/pmc_sq_summary.py $O/prof_sq $O/pmc_sq.json
 rm -rf $O/prof_stats $O/prof_fetch $O/prof_write $O/prof_sq
 [ -n "$QUICK" ] && { ls -la $O; exit 0; }      # QUICK=1: the bench line, kernel stats and PMC passes only
-# same-box A/B of the launch-floor fusions (ms per step, 60 graph-replayed steps each, two rounds), and of the round-1 library where a
-# worktree of it sits next to the repo (git worktree add _r01 <round-1 commit>; python -m tinyfusers_amd.build inside it)
+# same-box A/B of the switches that change the step (ms per step, 60 graph-replayed steps each, two rounds)
 : > $O/ab_fusions.txt
-if [ -d $R/_r01 ]; then
-  for i in 1 2 3; do
-    v=$(cd $R/_r01 && python3 bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])")
-    echo "round $i  round-1 library (_r01): $v ms/step" >> $O/ab_fusions.txt
-    v=$(python3 $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-roofline --no-e2e 2>/dev/null | tail -1 | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])")
-    echo "round $i  this round, default: $v ms/step" >> $O/ab_fusions.txt
-  done
-fi
 for i in 1 2; do
-  for cfg in "" "TF_FUSE_GROUP_NORM=0" "TF_FUSE_REDUCE_NORM=0" "TF_FUSE_GROUP_NORM_3X3=1" "TF_CFG_PARALLEL=1"; do
-    v=$(env $cfg python3 $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-roofline --no-e2e 2>/dev/null | tail -1 | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])")
-    echo "round $i  ${cfg:-default (GroupNorm inside the 1x1 convs only)}: $v ms/step" >> $O/ab_fusions.txt
+  for cfg in "" "TF_FUSE_GROUP_NORM=0" "TF_FUSE_REDUCE_NORM=0" "TF_HOIST_STEP_INVARIANTS=0" "TF_SPLITK_PARTIALS=32"; do
+    v=$(env $cfg python3 $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-roofline --no-e2e --no-config5 2>/dev/null | tail -1 | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])")
+    echo "round $i  ${cfg:-default}: $v ms/step" >> $O/ab_fusions.txt
   done
 done
 # BASELINE config 5's per-GPU shape (4 images, 96 x 96 latents), fp16 and fp8: bench line, per-shape GEMM table, rocprofv3 kernel statistics
