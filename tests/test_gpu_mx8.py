@@ -290,10 +290,24 @@ def test_unsupported_shapes_are_refused_and_the_policy_keeps_them_in_fp16(tf):
     assert lib.tf_mx8_gemm_supported(512, 3840, 1280, 0, 0) == 0              # batch 1, 16 x 16 level: 3 x 30 tiles of 192 x 128 cannot fill the chip
     assert lib.tf_mx8_conv_supported(8, 96, 96, 320, 0, 320, 3, 3, 1, 1, 0) == 1
     assert lib.tf_mx8_conv_supported(8, 96, 96, 320, 0, 320, 3, 3, 2, 1, 0) == 0 and lib.tf_mx8_conv_supported(8, 12, 12, 1280, 0, 1280, 3, 3, 1, 1, 0) == 0
-    x8 = fp8.quantize_mx(tf.DeviceArray.from_numpy(rnd("u.x", (64, 64)), np.float16, "row"))
-    w8, sc = fp8.pack_weight(tf.DeviceArray.from_numpy(rnd("u.w", (64, 64), 0.1), np.float16, "row"), {})
-    with pytest.raises(RuntimeError, match="tf_linear_mx8 failed with status 10002"):
-        fp8.linear_mx(x8, w8, sc, None)
+    # "supported" is about filling the chip: a small launch still RUNS on the kernel (one tile) when a caller insists ...
+    xs, ws_ = rnd("u.x", (64, 64)), rnd("u.w", (64, 64), 0.1)
+    x8 = fp8.quantize_mx(tf.DeviceArray.from_numpy(xs, np.float16, "row"))
+    w8, sc = fp8.pack_weight(tf.DeviceArray.from_numpy(ws_, np.float16, "row"), {})
+    from oracle import fp8 as O8
+    y = fp8.linear_mx(x8, w8, sc, None).numpy()
+    np.testing.assert_allclose(y, (O8.quant_act_mx(xs) @ O8.quant_weight(ws_)[0].t()).numpy(), **TOL)
+    # ... and what the kernel cannot do is refused with a status, never run on something else: a time-embedding bias on tiles that span more than
+    # two images (12 x 12 pixels per image against 192-row tiles), a stride-2 convolution
+    xc = fp8.quantize_mx(tf.DeviceArray.from_numpy(rnd("u.xc", (8, 128, 12, 12)), np.float16, "nhwc"))
+    wc8, wcs = fp8.pack_weight(tf.DeviceArray.from_numpy(rnd("u.wc", (128, 128, 3, 3), 0.05), np.float16, "nhwc"), {})
+    emb = tf.DeviceArray.from_numpy(rnd("u.e", (8, 128)), np.float16, "row")
+    with pytest.raises(RuntimeError, match="tf_conv2d_mx8 failed with status 10002"):
+        fp8.conv2d_mx(xc, wc8, wcs, None, (128, 128, 3, 3), [1, 1], bias_nc=emb)
+    assert np.isfinite(fp8.conv2d_mx(xc, wc8, wcs, None, (128, 128, 3, 3), [1, 1]).numpy()).all()      # (without the time embedding it runs)
+    from tinyfusers_amd.native import hip
+    with pytest.raises(RuntimeError, match="tf_conv2d_mx8 failed with status 10001"):
+        hip.tf_conv2d_mx8(xc.ptr, xc.ptr, None, wc8.ptr, wcs.ptr, None, None, 0, None, 8, 12, 12, 128, 0, 128, 3, 3, 2, 1, None, 0, None, 0, 0, None, None)
     config.set_dtype("fp8")
     try:
         assert not fp8.linear_ok(8 * 9216, 960, 320) and fp8.linear_ok(8 * 9216, 1920, 640)     # K = 320 stays fp16 (MIN_K)

@@ -677,7 +677,7 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
   for (int ci = 0; ci < 3; ++ci) {
     const int bm = ppbm[bi], bn = ppbn[ci];
     if (!pp_ok(p, bn, bm) || p.M <= 256) continue;
-    for (int sk = 1; sk <= 8; sk *= 2) {
+    for (int sk = 1; sk <= 32; sk *= 2) {        // (round 4: up to 32 -- at the 16 x 16 level a 256-row tile halves the weight re-reads per CU, and only a deep split fills the chip with it)
       if (sk > 1 && (p.act == 1 || p.out32 || p.ln_colsum || ktiles_for(p, 4) / sk < 4 || !workspace || (size_t)sk * p.M * p.N * 4 > workspace_bytes)) break;
       long long blocks = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * sk;
       if (blocks < 128) continue;
