@@ -53,6 +53,9 @@
 #ifndef TF_PP_V2
 #define TF_PP_V2 0        // experiment switch (tagged build): 1 = one barrier per K tile, loads issued between MFMA chunks (see the tile loop)
 #endif
+#ifndef TF_PP_H2_MERGE
+#define TF_PP_H2_MERGE 1  // e4m3, channel counts off the 128 grid: one full-width load where the two slabs of a K tile are contiguous (0: always two half-masked loads)
+#endif
 #ifndef TF_PP_PRIO
 #define TF_PP_PRIO 0      // experiment switch of tools' tagged builds: 0 = s_setprio 1 around every MFMA block (shipped), 1 = static priority for waves 4-7, 2 = none
 #endif
@@ -268,8 +271,15 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
     const auto lim = [](int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; };
     if constexpr (!F8) one(a_lo, a_hi, a_nb, a_r, a_s, a_c0, a_ld, cs, -1, i0, i1);
     else if constexpr (H2) {
-      one(b_lo, b_hi, b_nb, b_r, b_s, b_c0, b_ld, cs & 3, 0, lim(i0, 0, APW), lim(i1, 0, APW));
-      one(a_lo, a_hi, a_nb, a_r, a_s, a_c0, a_ld, cs & 3, 1, lim(i0 - APW, 0, APW), lim(i1 - APW, 0, APW));
+      // the two 64-channel slabs of this K tile are usually 128 CONTIGUOUS bytes of one (tap, tensor) -- with 320 channels 4 tiles of 5 -- and then
+      // one full-width load does it: the load instructions of the load half, not bytes, set this kernel's pace (13 per wave and tile against 9).
+      // (wave-uniform test on the prepared scalars; the counted waits assume the smaller number of loads: see wait_landed)
+      const bool contig = TF_PP_H2_MERGE && FASTA && __builtin_amdgcn_readfirstlane((b_lo == a_lo) & (b_hi == a_hi) & (b_nb == a_nb) & (a_r == b_r) & (a_c0 == b_c0 + 64) & (a_ld == b_ld));
+      if (contig) one(b_lo, b_hi, b_nb, b_r, b_s, b_c0, b_ld, cs, -1, lim(i0, 0, APW), lim(i1, 0, APW));
+      else {
+        one(b_lo, b_hi, b_nb, b_r, b_s, b_c0, b_ld, cs & 3, 0, lim(i0, 0, APW), lim(i1, 0, APW));
+        one(a_lo, a_hi, a_nb, a_r, a_s, a_c0, a_ld, cs & 3, 1, lim(i0 - APW, 0, APW), lim(i1 - APW, 0, APW));
+      }
     } else one(b_lo, b_hi, b_nb, b_r, b_s, b_c0, b_ld, cs, -1, i0, i1);       // channel counts on the 128 grid: the two slabs of a tile are 128 contiguous bytes
   };
   auto stage_w = [&](int slot, int kt, int i0 = 0, int i1 = 64) {
@@ -309,7 +319,10 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
     if constexpr (decltype(newest)::value && D >= 2) {
       // loads of one tile by this wave: APL activation pieces, WPW (or one fewer from wave WREM on) weight pieces, SCL scale loads on waves 4-7
       static_assert(WREM == 0 || WREM == 4, "the wave classes below");
-      if (wid < 4) wait_vm<APL + WPW>(); else wait_vm<APL + WPW - (WREM ? 1 : 0) + SCL>();
+      // (H2 with merging: a tile issues APW or 2 APW activation loads; the wait assumes APW -- with the newest tile's loads at least that many in
+      // flight, "at most that many outstanding" still means every older load has landed; a split tile's extra loads are waited for a little early)
+      constexpr int APLW = (F8 && H2 && TF_PP_H2_MERGE) ? APW : APL;
+      if (wid < 4) wait_vm<APLW + WPW>(); else wait_vm<APLW + WPW - (WREM ? 1 : 0) + SCL>();
     } else wait_vm<0>();
   };
 
