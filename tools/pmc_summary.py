@@ -24,12 +24,9 @@ for fam in sorted(ft):
     out[fam] = {"launches": fn[fam], "fetch_bytes_per_launch": fetch_b / fn[fam], "write_bytes_per_launch": write_b / max(1, wn.get(fam, 1)),
                 "hbm_bytes_per_launch": fetch_b / fn[fam] + write_b / max(1, wn.get(fam, 1))}
 # stamp: hash of the kernel sources this profile was taken on (bench.py reports `traffic` only while it still matches)
-_d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tinyfusers_amd", "csrc")
-_h = hashlib.sha256()
-for _f in sorted(os.listdir(_d)):
-    if _f.endswith((".hip", ".h")):
-        _h.update(_f.encode()); _h.update(open(os.path.join(_d, _f), "rb").read())
-out["csrc_sha16"] = _h.hexdigest()[:16]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_hash          # ONE definition of the stamp (it covers csrc/*.hip, *.h and *.inc)
+out["csrc_sha16"] = csrc_hash()
 print(json.dumps(out, indent=1))
 if len(sys.argv) > 3:
     json.dump(out, open(sys.argv[3], "w"), indent=1)
