@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_STEP = 1.6088e12          # algorithmic FLOPs of one step (conv 887.89 G + linear 466.49 G + SDPA 252.10 G + 2.28 G)
-PEAK_MFMA_TFLOPS = {"fp16": 2500.0, "fp8": 5000.0}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_MFMA_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp8": 5000.0}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 TRAFFIC_PROFILE = os.path.join("profiles", "r04_pmc_traffic.json")
 FAMILY_PROFILE = os.path.join("profiles", "r04_kernel_family.json")
@@ -59,7 +59,8 @@ def parse(argv=None):
     ap.add_argument("--tune-cache", default="", help="file to load/save the GEMM autotuner's per-shape choices (optional)")
     ap.add_argument("--images", type=int, default=1, help="images per GPU (UNet batch = 2x); default 1 = BASELINE config 2")
     ap.add_argument("--latent", type=int, default=64, help="latent height = width; default 64 (512x512 images); 96 = 768x768 (config 5)")
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp8"], help="conv/linear operand type (fp8 = config 5: OCP e4m3 weights + activations, fp32 accumulate, fp16 residual stream)")
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp8"], help="fp16 (the metric's configuration); bf16 = every 16-bit tensor bfloat16 (a correct step on the plain per-op structure, not a tuned one); "
+                    "fp8 = config 5: block-scaled e4m3 conv / linear operands, fp32 accumulate, fp16 residual stream")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank plumbing (gloo): no GPU, no kernels")
     ap.add_argument("--comm", default="torch", choices=["torch", "tf"], help="who carries the one weight-arena broadcast: torch.distributed (nccl = RCCL), or the C-ABI's own "
                     "tf_comm_unique_id / tf_comm_init_rank / tf_bcast (csrc/comm.hip; the id travels through a file, tinyfusers_amd.dist.TfComm)")
@@ -184,6 +185,9 @@ def build_weight_arena(unet, rank, world, device_index, comm="torch"):
     from tinyfusers_amd.dist import broadcast_arena, pack_tensor, plan_arena
     shapes = unet_param_shapes(unet)
     offs, off = plan_arena(shapes)
+    from tinyfusers_amd import config as _cfg
+    from tinyfusers_amd.storage.tensor import bfloat16 as _bf16, f32_to_bf16_bits
+    wdtype = _bf16 if _cfg.is_bf16() else np.float16
     arena = torch.empty(off, dtype=torch.uint8, device=f"cuda:{device_index}")
     base = arena.data_ptr()
     t0 = time.time()
@@ -191,6 +195,9 @@ def build_weight_arena(unet, rank, world, device_index, comm="torch"):
         from concurrent.futures import ThreadPoolExecutor
 
         def gen(k):
+            if _cfg.is_bf16():                      # bfloat16 bit patterns in the same packed layout (conv weights KRSC)
+                w = np.asarray(synth_tensor(0, k, shapes[k]), dtype=np.float32)
+                return k, np.ascontiguousarray(f32_to_bf16_bits(w.transpose(0, 2, 3, 1) if w.ndim == 4 else w))
             return k, pack_tensor(synth_tensor(0, k, shapes[k]))
         with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
             for k, w in ex.map(gen, list(shapes)):
@@ -212,7 +219,7 @@ def build_weight_arena(unet, rank, world, device_index, comm="torch"):
             broadcast_arena(arena, src=0)      # the ONLY collective of the path (RCCL over xGMI)
         torch.cuda.synchronize()
         t_bcast = time.time() - t1
-    state = {k: DeviceArray(base + offs[k], shapes[k], np.float16, None, base=arena) for k in shapes}
+    state = {k: DeviceArray(base + offs[k], shapes[k], wdtype, None, base=arena) for k in shapes}
     update_state(unet, state, "")
     return arena, off, t_gen, t_bcast, state
 
@@ -540,7 +547,7 @@ def main(argv=None):
         if use_dist:
             import torch.distributed as dist
             rccl_ranks = dist.get_world_size()
-        dt = {"fp16": "f16", "fp8": "f8e4m3"}[args.dtype]
+        dt = {"fp16": "f16", "bf16": "bf16", "fp8": "f8e4m3"}[args.dtype]
         out = {
             "metric": "unet_denoise_steps_per_sec", "value": round(steps_per_s, 2), "unit": "steps/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 4), "higher_is_better": True,

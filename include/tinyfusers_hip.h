@@ -361,6 +361,17 @@ int tf_layer_norm_bf16(void* y, const void* x, const void* gamma, const void* be
 /* y(M,N) = x(M,K) . w(N,K)^T + bias(N) + residual(M,N)   (ff/linear.py:112-121) */
 int tf_linear_bf16(void* y, const void* x, const void* w, const void* bias, const void* residual, int M, int N, int K, tfStream_t s);
 /* tf_conv2d_f16's arguments without the workspace (vision/conv2d.py:9-28): NHWC x (+ concat x2), w (Cout, R, S, C1 + C2) */
+/* the bfloat16 STEP (round 4: config.set_dtype("bf16"), bench.py --dtype bf16): the sampler on bfloat16 tensors throughout -- conv / linear /
+ * GEGLU on the bf16 MFMA (tf_conv2d_bf16, tf_linear_act_bf16), GroupNorm / LayerNorm / SiLU in bfloat16, the time-embedding chain, CFG duplicate
+ * and the CFG + DDIM update reading bfloat16 (vision/unet.py:51-97, variants/sd.py:14-46); the attention core stays the fp16 kernel behind one
+ * conversion in and one out (tf_convert_*) */
+int tf_linear_act_bf16(void* y, const void* x, const void* w, const void* bias, const void* residual, int M, int N, int K, int act, tfStream_t s);
+int tf_silu_bf16(void* y, const void* x, long long n, tfStream_t s);
+int tf_convert_f16_to_bf16(void* y_bf16, const void* x_f16, long long n, tfStream_t s);
+int tf_convert_bf16_to_f16(void* y_f16, const void* x_bf16, long long n, tfStream_t s);
+int tf_timestep_embedding_bf16(void* out, const void* step_params, int dim, float max_period, tfStream_t s);
+int tf_cfg_duplicate_bf16(void* x2b, const void* latent, int B, int C, int H, int W, tfStream_t s);
+int tf_cfg_ddim_step_bf16(void* latent, const void* eps2, const void* params, int B, int C, int H, int W, tfStream_t s);
 int tf_conv2d_bf16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
                    const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
                    tfStream_t s);

@@ -66,6 +66,9 @@ cfg_parallel = _flag("TF_CFG_PARALLEL", False)
 # that sets the step scalars).  Bit-identical results; 5 launches (~55 us) fewer per step.  False = the reference's per-step recomputation.
 hoist_step_invariants = _flag("TF_HOIST_STEP_INVARIANTS", True)
 
+# "bf16" (round 4): every 16-bit tensor of the step holds bfloat16 -- install the weights AFTER set_dtype("bf16") (update_state then makes bfloat16 leaves);
+# conv / linear / GEGLU on the bf16 MFMA, norms and the sampler's small kernels in bfloat16, the attention core on the fp16 kernel behind a conversion;
+# the plain per-op structure (no LayerNorm fold, no split-K, no statistics riding on the convs): a correct bfloat16 step, not a tuned one.
 # Operand type of the conv / linear GEMMs: "fp16" (default; BASELINE configs 2-4) or "fp8" (config 5: OCP e4m3 weights with
 # per-output-channel scales packed once, e4m3 activations with a per-tensor scale quantised by the loader side, fp32 accumulate,
 # fp16 residual stream).  Set through set_dtype() before the first forward.
@@ -74,6 +77,10 @@ dtype = "fp16"
 
 def set_dtype(name):
     global dtype
-    if name not in ("fp16", "fp8"):
+    if name not in ("fp16", "fp8", "bf16"):
         raise ValueError(f"config.set_dtype: unknown dtype {name!r}")
     dtype = name
+
+
+def is_bf16():
+    return dtype == "bf16"

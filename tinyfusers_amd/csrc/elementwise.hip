@@ -22,20 +22,36 @@ __device__ __forceinline__ float act(float x) {
   return x * sigmoid_f(1.702f * x);
 }
 
-template <int OP>
-__global__ void __launch_bounds__(EW_BLOCK) k_unary(half_t* __restrict__ y, const half_t* __restrict__ x, long long n) {
+template <int OP, typename T = half_t>      // T: half_t, or bf16_t for the bfloat16 step (config.set_dtype("bf16"))
+__global__ void __launch_bounds__(EW_BLOCK) k_unary(T* __restrict__ y, const T* __restrict__ x, long long n) {
+  typedef T T8 __attribute__((ext_vector_type(8)));
   long long nvec = n >> 3;
   long long stride = (long long)gridDim.x * EW_BLOCK;
   for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < nvec; i += stride) {
-    h8 v = *reinterpret_cast<const h8*>(x + i * 8), o;
+    T8 v = *reinterpret_cast<const T8*>(x + i * 8), o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (half_t)act<OP>((float)v[j]);
-    *reinterpret_cast<h8*>(y + i * 8) = o;
+    for (int j = 0; j < 8; ++j) o[j] = (T)act<OP>((float)v[j]);
+    *reinterpret_cast<T8*>(y + i * 8) = o;
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
     long long i = (nvec << 3) + threadIdx.x;
-    y[i] = (half_t)act<OP>((float)x[i]);
+    y[i] = (T)act<OP>((float)x[i]);
   }
+}
+// fp16 <-> bfloat16 (the bfloat16 step runs its attention core on the fp16 kernel: one conversion in, one out)
+template <typename TO, typename TI>
+__global__ void __launch_bounds__(EW_BLOCK) k_convert16(TO* __restrict__ y, const TI* __restrict__ x, long long n) {
+  typedef TO O8 __attribute__((ext_vector_type(8)));
+  typedef TI I8 __attribute__((ext_vector_type(8)));
+  long long nvec = n >> 3, stride = (long long)gridDim.x * EW_BLOCK;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < nvec; i += stride) {
+    I8 v = *reinterpret_cast<const I8*>(x + i * 8);
+    O8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (TO)(float)v[j];
+    *reinterpret_cast<O8*>(y + i * 8) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) { long long i = (nvec << 3) + threadIdx.x; y[i] = (TO)(float)x[i]; }
 }
 
 __global__ void __launch_bounds__(EW_BLOCK) k_add(half_t* __restrict__ y, const half_t* __restrict__ a, const half_t* __restrict__ b, long long n) {
@@ -287,30 +303,33 @@ __global__ void __launch_bounds__(256) k_set_params_copy(float* p, float t, floa
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) dst[i] = src[i];
 }
 // out (1, dim) f16 = [cos(t f_i), sin(t f_i)], f_i = exp(-ln(max_period) i / half)   (vision/unet.py:92-97)
-__global__ void k_timestep_embedding(half_t* out, const float* params, int dim, float max_period) {
+template <typename T = half_t>
+__global__ void k_timestep_embedding(T* out, const float* params, int dim, float max_period) {
   int half_dim = dim / 2;
   float t = params[0];
   for (int i = threadIdx.x; i < half_dim; i += blockDim.x) {
     float f = expf(-logf(max_period) * (float)i / (float)half_dim);
     float a = t * f;
-    out[i] = (half_t)cosf(a);
-    out[half_dim + i] = (half_t)sinf(a);
+    out[i] = (T)cosf(a);
+    out[half_dim + i] = (T)sinf(a);
   }
 }
 // latent (B,C,H,W) f32 -> x (2B,H,W,C) f16, both CFG halves the same latent (variants/sd.py:31)
-__global__ void __launch_bounds__(EW_BLOCK) k_cfg_duplicate(half_t* __restrict__ x, const float* __restrict__ lat, int B, int C, int HW) {
+template <typename T = half_t>
+__global__ void __launch_bounds__(EW_BLOCK) k_cfg_duplicate(T* __restrict__ x, const float* __restrict__ lat, int B, int C, int HW) {
   long long n = (long long)B * C * HW, gs = (long long)gridDim.x * EW_BLOCK;
   for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += gs) {
     int c = (int)(i % C);
     long long p = i / C;
     int hw = (int)(p % HW), b = (int)(p / HW);
-    half_t v = (half_t)lat[((long long)b * C + c) * HW + hw];
+    T v = (T)lat[((long long)b * C + c) * HW + hw];
     x[i] = v;
     x[n + i] = v;
   }
 }
 // e = e_u + g (e_c - e_u); pred_x0 = (x - sqrt(1-a_t) e)/sqrt(a_t); x' = sqrt(a_prev) pred_x0 + sqrt(1-a_prev) e
-__global__ void __launch_bounds__(EW_BLOCK) k_cfg_ddim(float* __restrict__ lat, const half_t* __restrict__ eps2, const half_t* __restrict__ eps_c,
+template <typename T = half_t>
+__global__ void __launch_bounds__(EW_BLOCK) k_cfg_ddim(float* __restrict__ lat, const T* __restrict__ eps2, const T* __restrict__ eps_c,
                                                        const float* __restrict__ params, int B, int C, int HW) {
   float a_t = params[1], a_prev = params[2], g = params[3];
   float s1 = sqrtf(1.0f - a_t), r = sqrtf(a_t), sp = sqrtf(a_prev), dp = sqrtf(1.0f - a_prev);
@@ -369,6 +388,49 @@ int tf_add_f16(void* y, const void* a, const void* b, long long n, tfStream_t s)
   TF_REQUIRE(y && a && b && n >= 0, "tf_add_f16: bad arguments");
   if (n == 0) return TF_OK;
   hipLaunchKernelGGL(k_add, dim3(ew_grid(n >> 3)), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)y, (const half_t*)a, (const half_t*)b, n);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+// ---- the bfloat16 step (config.set_dtype("bf16")): the small kernels of the sampler and the time-embedding chain on bfloat16 tensors, and the
+// fp16 <-> bfloat16 conversion around the attention core (tf_sdpa_f16 stays the fp16 kernel)
+int tf_silu_bf16(void* y, const void* x, long long n, tfStream_t s) {
+  TF_REQUIRE(y && x && n >= 0, "tf_silu_bf16: bad arguments");
+  if (n == 0) return TF_OK;
+  hipLaunchKernelGGL((k_unary<OP_SILU, bf16_t>), dim3(ew_grid(n >> 3)), dim3(EW_BLOCK), 0, tf_hs(s), (bf16_t*)y, (const bf16_t*)x, n);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_convert_f16_to_bf16(void* y_bf16, const void* x_f16, long long n, tfStream_t s) {
+  TF_REQUIRE(y_bf16 && x_f16 && n >= 0, "tf_convert_f16_to_bf16: bad arguments");
+  if (n == 0) return TF_OK;
+  hipLaunchKernelGGL((k_convert16<bf16_t, half_t>), dim3(ew_grid(n >> 3)), dim3(EW_BLOCK), 0, tf_hs(s), (bf16_t*)y_bf16, (const half_t*)x_f16, n);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_convert_bf16_to_f16(void* y_f16, const void* x_bf16, long long n, tfStream_t s) {
+  TF_REQUIRE(y_f16 && x_bf16 && n >= 0, "tf_convert_bf16_to_f16: bad arguments");
+  if (n == 0) return TF_OK;
+  hipLaunchKernelGGL((k_convert16<half_t, bf16_t>), dim3(ew_grid(n >> 3)), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)y_f16, (const bf16_t*)x_bf16, n);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_timestep_embedding_bf16(void* out, const void* step_params, int dim, float max_period, tfStream_t s) {
+  TF_REQUIRE(out && step_params && dim > 0 && dim % 2 == 0, "tf_timestep_embedding_bf16: dim=%d must be even", dim);
+  hipLaunchKernelGGL(k_timestep_embedding<bf16_t>, dim3(1), dim3(256), 0, tf_hs(s), (bf16_t*)out, (const float*)step_params, dim, max_period);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_cfg_duplicate_bf16(void* x2b, const void* latent, int B, int C, int H, int W, tfStream_t s) {
+  TF_REQUIRE(x2b && latent && B > 0 && C > 0, "tf_cfg_duplicate_bf16: bad arguments");
+  long long n = (long long)B * C * H * W;
+  hipLaunchKernelGGL(k_cfg_duplicate<bf16_t>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (bf16_t*)x2b, (const float*)latent, B, C, H * W);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_cfg_ddim_step_bf16(void* latent, const void* eps2, const void* params, int B, int C, int H, int W, tfStream_t s) {
+  TF_REQUIRE(latent && eps2 && params && B > 0 && C > 0, "tf_cfg_ddim_step_bf16: bad arguments");
+  long long n = (long long)B * C * H * W;
+  hipLaunchKernelGGL(k_cfg_ddim<bf16_t>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (float*)latent, (const bf16_t*)eps2, (const bf16_t*)nullptr, (const float*)params, B, C, H * W);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
@@ -606,28 +668,28 @@ int tf_set_step_params_copy(void* step_params, float timestep, float a_t, float 
 }
 int tf_timestep_embedding_f16(void* out, const void* step_params, int dim, float max_period, tfStream_t s) {
   TF_REQUIRE(out && step_params && dim > 0 && dim % 2 == 0, "tf_timestep_embedding_f16: dim=%d must be even", dim);
-  hipLaunchKernelGGL(k_timestep_embedding, dim3(1), dim3(256), 0, tf_hs(s), (half_t*)out, (const float*)step_params, dim, max_period);
+  hipLaunchKernelGGL(k_timestep_embedding<half_t>, dim3(1), dim3(256), 0, tf_hs(s), (half_t*)out, (const float*)step_params, dim, max_period);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
 int tf_cfg_duplicate_f16(void* x2b, const void* latent, int B, int C, int H, int W, tfStream_t s) {
   TF_REQUIRE(x2b && latent && B > 0 && C > 0, "tf_cfg_duplicate_f16: bad arguments");
   long long n = (long long)B * C * H * W;
-  hipLaunchKernelGGL(k_cfg_duplicate, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)x2b, (const float*)latent, B, C, H * W);
+  hipLaunchKernelGGL(k_cfg_duplicate<half_t>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)x2b, (const float*)latent, B, C, H * W);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
 int tf_cfg_ddim_step_f32(void* latent, const void* eps2, const void* params, int B, int C, int H, int W, tfStream_t s) {
   TF_REQUIRE(latent && eps2 && params && B > 0 && C > 0, "tf_cfg_ddim_step_f32: bad arguments");
   long long n = (long long)B * C * H * W;
-  hipLaunchKernelGGL(k_cfg_ddim, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (float*)latent, (const half_t*)eps2, (const half_t*)nullptr, (const float*)params, B, C, H * W);
+  hipLaunchKernelGGL(k_cfg_ddim<half_t>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (float*)latent, (const half_t*)eps2, (const half_t*)nullptr, (const float*)params, B, C, H * W);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
 int tf_cfg_ddim_step2_f32(void* latent, const void* eps_uncond, const void* eps_cond, const void* params, int B, int C, int H, int W, tfStream_t s) {
   TF_REQUIRE(latent && eps_uncond && eps_cond && params && B > 0 && C > 0, "tf_cfg_ddim_step2_f32: bad arguments");
   long long n = (long long)B * C * H * W;
-  hipLaunchKernelGGL(k_cfg_ddim, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (float*)latent, (const half_t*)eps_uncond, (const half_t*)eps_cond, (const float*)params, B, C, H * W);
+  hipLaunchKernelGGL(k_cfg_ddim<half_t>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, tf_hs(s), (float*)latent, (const half_t*)eps_uncond, (const half_t*)eps_cond, (const float*)params, B, C, H * W);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }

@@ -1248,6 +1248,23 @@ int tf_linear_bf16(void* y, const void* x, const void* w, const void* bias, cons
   }
   return run_gemm(p, nullptr, 0, 0, 0, 0, tf_hs(s));
 }
+// ... with the GEGLU epilogue (act = 1: w / bias packed in 16-row value | gate blocks as for tf_linear_f16; N = the output width): ff/nn.py:5-12 on bfloat16
+int tf_linear_act_bf16(void* y, const void* x, const void* w, const void* bias, const void* residual, int M, int N, int K, int act, tfStream_t s) {
+  TF_REQUIRE(y && x && w, "tf_linear_act_bf16: null tensor");
+  TF_REQUIRE(M >= 0 && N >= 1 && K >= 8 && K % 8 == 0, "tf_linear_act_bf16: K=%d must be a positive multiple of 8", K);
+  TF_REQUIRE(act == 0 || (act == 1 && bias && N % 16 == 0), "tf_linear_act_bf16: act=%d (GEGLU needs a bias and N %% 16 == 0, N=%d)", act, N);
+  if (M == 0) return TF_OK;
+  GemmP p = {};
+  p.x = (const half_t*)x; p.w = (const half_t*)w; p.y = (half_t*)y; p.bias = (const half_t*)bias; p.residual = (const half_t*)residual;
+  p.M = M; p.N = act == 1 ? 2 * N : N; p.K = K; p.Kc = K; p.C1 = K; p.C2 = 0; p.C = K;
+  p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.HoWo = M; p.S = 1; p.stride = 1; p.pad = 0; p.ups = 0; p.act = act; p.bf16 = 1;
+  {
+    long long xb = (long long)M * K * 2, wb = (long long)p.N * K * 2;
+    TF_REQUIRE(xb < (1LL << 31) && wb < (1LL << 31), "tf_linear_act_bf16: tensors must be < 2 GiB each");
+    p.x_bytes = (unsigned)xb; p.x2_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+  }
+  return run_gemm(p, nullptr, 0, 0, 0, 0, tf_hs(s));
+}
 int tf_conv2d_bf16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
                    const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample, tfStream_t s) {
   GemmP ex = {};

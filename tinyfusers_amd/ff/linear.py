@@ -35,6 +35,41 @@ def linear_bf16(x, w, b=None, residual=None):
     return y
 
 
+def linear_act_bf16(x, w, b=None, residual=None, act=0, out_features=None):
+    """bfloat16 form of linear_f16 (act = 1: GEGLU, w / b packed as for the fp16 kernel)."""
+    K = x.shape[-1]
+    rows = x.size // K
+    n_out = out_features if out_features is not None else w.shape[0]
+    y = DeviceArray.empty(x.shape[:-1] + (n_out,), x.dtype, "row")
+    hip.tf_linear_act_bf16(y.ptr, x.ptr, w.ptr, b.ptr if b is not None else None, residual.ptr if residual is not None else None, rows, n_out, K, act, _sh())
+    return y
+
+
+def linear_any(x, w, b=None, residual=None, act=0, out_features=None):
+    """linear_f16 or its bfloat16 form, by the element type of x."""
+    if is_bfloat16(x.dtype):
+        return linear_act_bf16(x, w, b, residual, act, out_features)
+    return linear_f16(x, w, b, residual, act, out_features)
+
+
+def to_f16(x):
+    """bfloat16 DeviceArray -> fp16 copy (same shape / layout); fp16 arrays pass through."""
+    if not is_bfloat16(x.dtype):
+        return x
+    y = DeviceArray.empty(x.shape, np.float16, x.layout)
+    hip.tf_convert_bf16_to_f16(y.ptr, x.ptr, x.size, _sh())
+    return y
+
+
+def to_bf16(x):
+    from ..storage.tensor import bfloat16
+    if is_bfloat16(x.dtype):
+        return x
+    y = DeviceArray.empty(x.shape, bfloat16, x.layout)
+    hip.tf_convert_f16_to_bf16(y.ptr, x.ptr, x.size, _sh())
+    return y
+
+
 def gemv_f16(x, w, b=None, silu_input=False):
     K = x.shape[-1]
     rows = x.size // K
@@ -156,7 +191,10 @@ class Linear:
         assert x.layout == "row" and x.shape[-1] == self.weight.shape[1], (x.shape, self.weight.shape)
         rows = x.size // x.shape[-1]
         if is_bfloat16(x.dtype):
-            assert not silu_input
+            if silu_input:
+                xs = DeviceArray.empty(x.shape, x.dtype, x.layout)
+                hip.tf_silu_bf16(xs.ptr, x.ptr, x.size, _sh())
+                x = xs
             return linear_bf16(x, self.weight, self.bias, residual)
         if rows <= 8 and residual is None:
             return gemv_f16(x, self.weight, self.bias, silu_input)

@@ -5,7 +5,7 @@ import numpy as np
 
 from ..native import hip
 from ..storage.tensor import DeviceArray, Tensor, _sh
-from .linear import Linear, fold_layer_norm, linear_f16, linear_ln_f16
+from .linear import Linear, fold_layer_norm, linear_any, linear_f16, linear_ln_f16
 
 
 def pack_geglu(weight, bias):
@@ -13,11 +13,11 @@ def pack_geglu(weight, bias):
     two_n, k = weight.shape
     n = two_n // 2
     assert n % 16 == 0, "GEGLU width must be a multiple of 16"
-    wp = DeviceArray.empty((two_n, k), np.float16, "row")
+    wp = DeviceArray.empty((two_n, k), weight.dtype, "row")     # (2-byte copies: fp16 and bfloat16 alike)
     blk = 16 * k * 2
     hip.tf_memcpy_2d_async(wp.ptr, 2 * blk, weight.ptr, blk, blk, n // 16, _sh())
     hip.tf_memcpy_2d_async(wp.ptr + blk, 2 * blk, weight.ptr + n * k * 2, blk, blk, n // 16, _sh())
-    bp = DeviceArray.empty((two_n,), np.float16, "row")
+    bp = DeviceArray.empty((two_n,), bias.dtype, "row")
     hip.tf_memcpy_2d_async(bp.ptr, 64, bias.ptr, 32, 32, n // 16, _sh())
     hip.tf_memcpy_2d_async(bp.ptr + 32, 64, bias.ptr + n * 2, 32, 32, n // 16, _sh())
     return wp, bp
@@ -53,7 +53,7 @@ class GEGLU:
             return linear_ln_f16(x, self._pack_ln(ln), ln.eps, act=1, out_features=self.dim_out)
         if self.dim_out % 16 == 0 and self.proj.bias is not None:
             wp, bp = self._pack()
-            return linear_f16(x, wp, bp, None, act=1, out_features=self.dim_out)
+            return linear_any(x, wp, bp, None, act=1, out_features=self.dim_out)
         h = self.proj(x)                                   # unfused fallback shape (still HIP): split + a*gelu(gate)
         y = DeviceArray.empty(x.shape[:-1] + (self.dim_out,), np.float16, "row")
         hip.tf_geglu_f16(y.ptr, h.ptr, h.size // h.shape[-1], self.dim_out, _sh())

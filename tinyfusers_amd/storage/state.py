@@ -65,7 +65,9 @@ def update_state(obj, state_dict, prefix=''):
             if cur is not None or not name.endswith((".to_q.bias", ".to_k.bias", ".to_v.bias")):
                 print(f"skipped: {name}")
             continue
-        owner[key] = asarray(_to_numpy(state_dict[name]), np.float16)
+        from .. import config
+        from .tensor import bfloat16
+        owner[key] = asarray(_to_numpy(state_dict[name]), bfloat16 if config.is_bf16() else np.float16)
 
 
 def _leaf_shape(module, key):

@@ -17,7 +17,7 @@ import numpy as np
 
 from .. import config
 from ..native import hip
-from ..storage.tensor import Branch, DeviceArray, Stream, _sh, asarray, pool, use_stream
+from ..storage.tensor import Branch, DeviceArray, Stream, _sh, asarray, bfloat16, pool, use_stream
 from ..vision.unet import SD15, StepParams, UNetModel
 
 
@@ -51,8 +51,7 @@ class StableDiffusion:
         """variants/sd.py:27-46.  Returns the raw UNet output for [uncond x B ; cond x B] (2B,4,H,W) -- the CFG
         combine is fused with the DDIM update in __call__ (use cfg_combine() to get e_t on its own)."""
         b, c, h, w = latent.shape
-        x2 = DeviceArray.empty((2 * b, c, h, w), np.float16, "nhwc")
-        hip.tf_cfg_duplicate_f16(x2.ptr, latent.ptr, b, c, h, w, _sh())
+        x2 = self._cfg_duplicate(latent)
         ctx = self._stack_context(unconditional_context, context)
         sp = params if params is not None else self._step_params().set(_scalar(timestep), 1.0, 1.0, _scalar(unconditional_guidance_scale))
         return self.model.diffusion_model(x2, sp, ctx)
@@ -73,7 +72,7 @@ class StableDiffusion:
         b, c, h, w = latent.shape
         x_prev = DeviceArray.empty(latent.shape, np.float32, "row")
         hip.tf_memcpy_async(x_prev.ptr, latent.ptr, latent.nbytes, 3, _sh())
-        hip.tf_cfg_ddim_step_f32(x_prev.ptr, out.ptr, sp.dev.ptr, b, c, h, w, _sh())
+        (hip.tf_cfg_ddim_step_bf16 if config.is_bf16() else hip.tf_cfg_ddim_step_f32)(x_prev.ptr, out.ptr, sp.dev.ptr, b, c, h, w, _sh())
         return x_prev
 
     def decode(self, x):
@@ -101,11 +100,22 @@ class StableDiffusion:
         return self._params
 
     @staticmethod
+    def _cfg_duplicate(latent):
+        """variants/sd.py:31: the latent for both halves of the CFG pair, in the step's 16-bit type (NHWC)."""
+        b, c, h, w = latent.shape
+        x2 = DeviceArray.empty((2 * b, c, h, w), bfloat16 if config.is_bf16() else np.float16, "nhwc")
+        (hip.tf_cfg_duplicate_bf16 if config.is_bf16() else hip.tf_cfg_duplicate_f16)(x2.ptr, latent.ptr, b, c, h, w, _sh())
+        return x2
+
+    @staticmethod
     def _stack_context(unconditional_context, context):
         b, t, d = context.shape
-        ctx = DeviceArray.empty((2 * b, t, d), np.float16, "row")
+        ctx = DeviceArray.empty((2 * b, t, d), context.dtype, "row")
         hip.tf_memcpy_async(ctx.ptr, unconditional_context.ptr, context.nbytes, 3, _sh())
         hip.tf_memcpy_async(ctx.ptr + context.nbytes, context.ptr, context.nbytes, 3, _sh())
+        if config.is_bf16():
+            from ..ff.linear import to_bf16
+            ctx = to_bf16(ctx)                                 # (the bfloat16 step takes fp16 or bfloat16 contexts)
         return ctx
 
     @staticmethod
@@ -176,8 +186,7 @@ class StableDiffusion:
 
     def _eager_step(self, sp):
         b, c, h, w = self._latent.shape
-        x2 = DeviceArray.empty((2 * b, c, h, w), np.float16, "nhwc")
-        hip.tf_cfg_duplicate_f16(x2.ptr, self._latent.ptr, b, c, h, w, _sh())
+        x2 = self._cfg_duplicate(self._latent)
         unet = self.model.diffusion_model
         if config.cfg_parallel:
             # the unconditional and the conditional half of the CFG pair (variants/sd.py:31-32) as two independent UNet chains: one runs
@@ -197,7 +206,7 @@ class StableDiffusion:
             out = unet(x2, sp, self._ctx2, shared=(None, self._emb_cur, self._kv_all))     # (step() has put this timestep's row into _emb_cur)
         else:
             out = unet(x2, sp, self._ctx2)
-        hip.tf_cfg_ddim_step_f32(self._latent.ptr, out.ptr, sp.dev.ptr, b, c, h, w, _sh())
+        (hip.tf_cfg_ddim_step_bf16 if config.is_bf16() else hip.tf_cfg_ddim_step_f32)(self._latent.ptr, out.ptr, sp.dev.ptr, b, c, h, w, _sh())
         self._keep = (x2, out)      # graph nodes reference these blocks: keep them out of the pool
 
     def step(self, timestep, a_t, a_prev, guidance, eager=False):
@@ -234,10 +243,11 @@ class StableDiffusion:
     def set_context(self, unconditional_context, context):
         """New prompts for the compiled step: refresh the stacked context in place (the captured graph reads these buffers) and the
         cross-attention K|V projection that was hoisted out of the step.  Ordered on the sampler stream."""
-        nb = context.nbytes
         with use_stream(self._stream):
-            hip.tf_memcpy_async(self._ctx2.ptr, unconditional_context.ptr, nb, 3, _sh())
-            hip.tf_memcpy_async(self._ctx2.ptr + nb, context.ptr, nb, 3, _sh())
+            new = self._stack_context(unconditional_context, context)       # (in the step's 16-bit type)
+            assert new.nbytes == self._ctx2.nbytes, "set_context: the contexts must have the shape the step was compiled for"
+            hip.tf_memcpy_async(self._ctx2.ptr, new.ptr, new.nbytes, 3, _sh())
+            self._ctx_tmp = new                                    # (referenced until the copy has run)
             if getattr(self, "_kv_all", None) is not None:
                 kv = self.model.diffusion_model.context_kv(self._ctx2)
                 hip.tf_memcpy_async(self._kv_all.ptr, kv.ptr, kv.nbytes, 3, _sh())

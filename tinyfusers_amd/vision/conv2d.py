@@ -183,18 +183,47 @@ def conv_2d(X_gpu, W_gpu, padding, stride, dilation):
     return _conv(X_gpu, W_gpu, None, padding, stride, dilation)
 
 
-def conv2d_bf16(x, w, bias, padding, stride, dilation, residual=None):
-    """The same operator on bfloat16 tensors (x NHWC, w (K, R, S, C) stored): tf_conv2d_bf16, channels a multiple of 8."""
+def conv2d_bf16(x, w, bias, padding, stride, dilation, residual=None, bias_nc=None, upsample=False):
+    """The same operator on bfloat16 tensors (x NHWC -- or the concat pair (x, x2) --, w (K, R, S, C) stored): tf_conv2d_bf16, channel counts
+    multiples of 8; bias, the time-embedding bias (bias_nc), the residual and the nearest-2x up-sampling folded in as for the fp16 conv."""
+    x2 = None
+    if isinstance(x, (tuple, list)):
+        x, x2 = x
     n, c, h, wd = x.shape
+    c2 = x2.shape[1] if x2 is not None else 0
     k, cw, r, s_ = w.shape
-    assert c == cw and c % 8 == 0 and is_bfloat16(w.dtype), (x.shape, w.shape)
+    assert c + c2 == cw and c % 8 == 0 and c2 % 8 == 0 and is_bfloat16(w.dtype), (x.shape, w.shape)
     assert list(dilation) == [1, 1] and stride[0] == stride[1] and padding[0] == padding[1]
-    ho = (h + 2 * padding[0] - r) // stride[0] + 1
-    wo = (wd + 2 * padding[1] - s_) // stride[1] + 1
+    up = 1 if upsample else 0
+    ho = ((h << up) + 2 * padding[0] - r) // stride[0] + 1
+    wo = ((wd << up) + 2 * padding[1] - s_) // stride[1] + 1
     y = DeviceArray.empty((n, k, ho, wo), x.dtype, "nhwc")
-    hip.tf_conv2d_bf16(y.ptr, x.ptr, None, w.ptr, bias.ptr if bias is not None else None, None, 0,
-                       residual.ptr if residual is not None else None, n, h, wd, c, 0, k, r, s_, stride[0], padding[0], 0, _sh())
+    bnc_stride = 0
+    if bias_nc is not None:
+        bnc_stride = k if bias_nc.size // k > 1 else 0
+    hip.tf_conv2d_bf16(y.ptr, x.ptr, x2.ptr if x2 is not None else None, w.ptr, bias.ptr if bias is not None else None,
+                       bias_nc.ptr if bias_nc is not None else None, bnc_stride,
+                       residual.ptr if residual is not None else None, n, h, wd, c, c2, k, r, s_, stride[0], padding[0], up, _sh())
     return y
+
+
+def _conv_small_c_bf16(x, w, bias, padding, stride, cache):
+    """Cin % 8 != 0 on bfloat16 (the 4-channel conv_in of the bfloat16 step): im2col (a 2-byte copy: the same kernel) to K padded to 64, then a
+    1x1 bfloat16 conv over the patch image."""
+    n, c, h, wd = x.shape
+    k, _, r, s = w.shape
+    kk = r * s * c
+    kpad = (kk + 63) // 64 * 64
+    ho = (h + 2 * padding[0] - r) // stride[0] + 1
+    wo = (wd + 2 * padding[1] - s) // stride[1] + 1
+    key = (w.wkey, kpad, "bf16")
+    if cache.get("key") != key:
+        wp = DeviceArray.zeros((k, kpad), w.dtype, "row")
+        hip.tf_memcpy_2d_async(wp.ptr, kpad * 2, w.ptr, kk * 2, kk * 2, k, _sh())
+        cache["key"], cache["w"] = key, wp
+    col = DeviceArray.empty((n * ho * wo, kpad), x.dtype, "row")
+    hip.tf_im2col_nhwc_f16(col.ptr, x.ptr, n, h, wd, c, r, s, stride[0], padding[0], kpad, _sh())
+    return conv2d_bf16(col.view((n, kpad, ho, wo), "nhwc"), cache["w"].view((k, kpad, 1, 1), "nhwc"), bias, [0, 0], [1, 1], [1, 1])
 
 
 def pad_image(x, left, right, top, bottom):
@@ -248,6 +277,17 @@ class Conv2d:
         """gn = G: also emit the statistics of the output for the GroupNorm(G) that reads it next (y.gn).
         extra = (proj, x3): add ``proj(x3)`` (a Conv2d 1x1; x3 a tensor or a concat pair) inside this conv's GEMM.
         gn_in = (GroupNorm, silu): this conv reads GroupNorm(x) [-> SiLU] (x is the RAW tensor): one launch where possible."""
+        x0 = x[0] if isinstance(x, (tuple, list)) else x
+        if is_bfloat16(x0.dtype):
+            # the bfloat16 step: the plain per-op structure -- GroupNorm (+ SiLU) as its own launch, one bf16-MFMA conv with bias / time embedding /
+            # residual / up-sampling / concat folded in; no statistics ride along, nothing is split along K
+            assert extra is None and len(self.padding) == 2
+            if gn_in is not None:
+                x = gn_in[0](x, silu=gn_in[1])
+            if (x[0].shape[1] + x[1].shape[1] if isinstance(x, (tuple, list)) else x.shape[1]) % 8 != 0:
+                assert bias_nc is None and residual is None and not upsample and not isinstance(x, (tuple, list))
+                return _conv_small_c_bf16(x, self.weight, self.bias, self.padding, self.stride, self._cache)
+            return conv2d_bf16(x, self.weight, self.bias, self.padding, self.stride, self.dilation, residual, bias_nc, upsample)
         if len(self.padding) == 4:                         # [left, right, top, bottom]: pad explicitly, then an unpadded conv
             assert extra is None and gn_in is None and not upsample and not isinstance(x, (tuple, list))
             x = pad_image(x, *self.padding)

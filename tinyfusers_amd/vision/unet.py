@@ -19,10 +19,10 @@ import numpy as np
 
 from ..attention.attention import SpatialTransformer, _concat_rows
 from ..ff.group_norm import GroupNorm
-from ..ff.linear import Linear, gemv_f16, linear_f16
+from ..ff.linear import Linear, gemv_f16, linear_any, linear_bf16, linear_f16, to_f16
 from ..native import hip
 from .. import config
-from ..storage.tensor import Branch, DeviceArray, Tensor, _sh, asarray
+from ..storage.tensor import Branch, DeviceArray, Tensor, _sh, asarray, bfloat16, is_bfloat16
 from .conv2d import Conv2d
 from .resnet import ResBlock
 
@@ -87,6 +87,11 @@ def timestep_embedding(timesteps, dim, max_period=10000):
     """unet.py:92-97: (1, dim) = [cos(t f), sin(t f)].  timesteps: host scalar/array, or StepParams / a device
     fp32 array whose element 0 is the timestep."""
     sp = _as_params(timesteps)
+    if config.is_bf16():
+        out = DeviceArray.empty((1, dim), bfloat16, "row")
+        hip.tf_timestep_embedding_bf16(out.ptr, sp.dev.ptr, dim, float(max_period), _sh())
+        out._base = sp
+        return out
     out = DeviceArray.empty((1, dim), np.float16, "row")
     hip.tf_timestep_embedding_f16(out.ptr, sp.dev.ptr, dim, float(max_period), _sh())
     out._base = sp
@@ -163,13 +168,17 @@ class UNetModel:
         bt = self._prepare()
         t_emb = timestep_embedding(timesteps, self.cfg.model_channels)
         emb = self.time_embed[2](self.time_embed[0](t_emb), silu_input=True)          # Linear -> SiLU -> Linear
+        if is_bfloat16(emb.dtype):                                                    # the bfloat16 step: SiLU launch + one bf16-MFMA GEMM with M = 1
+            se = DeviceArray.empty(emb.shape, emb.dtype, emb.layout)
+            hip.tf_silu_bf16(se.ptr, emb.ptr, emb.size, _sh())
+            return emb, linear_bf16(se, bt["emb_w"], bt["emb_b"])
         return emb, gemv_f16(emb, bt["emb_w"], bt["emb_b"], silu_input=True)          # every ResBlock's Linear(SiLU(emb))
 
     def context_kv(self, context):
         """Every cross-attention's K|V projection of the (stacked) context as ONE GEMM (attention/attention.py:35-36 for all 16 blocks):
         depends on the context alone, so a sampler computes it when the context changes, not once per step."""
         bt = self._prepare()
-        return linear_f16(context, bt["kv_w"]) if bt["kv_w"] is not None else None
+        return to_f16(linear_any(context, bt["kv_w"])) if bt["kv_w"] is not None else None     # (bfloat16 step: the attention core reads fp16 K|V)
 
     def weights_key(self):
         """Identity of everything time_embedding_all / context_kv depend on: a cached row is stale once any of these weights is replaced."""
@@ -192,11 +201,9 @@ class UNetModel:
                 br = Branch()                          # the context projection is independent of the time-embedding chain
                 with br:
                     kv_all = linear_f16(context, bt["kv_w"])
-            t_emb = timestep_embedding(timesteps, cfg.model_channels)
-            emb = self.time_embed[2](self.time_embed[0](t_emb), silu_input=True)          # Linear -> SiLU -> Linear
-            emb_all = gemv_f16(emb, bt["emb_w"], bt["emb_b"], silu_input=True)            # every ResBlock's Linear(SiLU(emb))
+            emb, emb_all = self.time_embedding_all(timesteps)                            # Linear -> SiLU -> Linear, then every ResBlock's Linear(SiLU(emb))
             if br is None:
-                kv_all = linear_f16(context, bt["kv_w"]) if bt["kv_w"] is not None else None  # every attn2's K|V of the context
+                kv_all = self.context_kv(context)                                         # every attn2's K|V of the context
 
         def run(x, bb, nxt, force_gn=0):
             # nxt = the module that reads this one's output as a single tensor (None across a concat): when it opens
