@@ -161,10 +161,10 @@ def _sd_fp8(tf, images, latent, seed):
     return sd, W, lat, ctx, unc
 
 
-@pytest.mark.parametrize("images,latent", [(4, 64), (4, 96)])
+@pytest.mark.parametrize("images,latent", [(2, 64), (4, 96)])
 def test_unet_fp8_policy_within_the_config5_gate(tf, images, latent):
-    """The SD-1.x UNet forward with the fp8 layer policy vs the fp32 oracle: rel-L2 <= 0.1 -- at 4 images of
-    config 2's latent size and at config 5's per-GPU shape (96 x 96 latents, 4 images = UNet batch 8); at one image per GPU no layer fills the
+    """The SD-1.x UNet forward with the fp8 layer policy vs the fp32 oracle: rel-L2 <= 0.1 -- at 2 images of
+    config 2's latent size (only the first level fills the chip there) and at config 5's per-GPU shape (96 x 96 latents, 4 images = UNet batch 8); at one image per GPU no layer fills the
     chip with the block-scaled kernel's tiles and the policy keeps everything in fp16.  EVERY image of the batch is compared: the images
     carry distinct latents and contexts, and image i's pair sits at rows (i, B + i) of the [uncond x B ; cond x B] batch (the D8
     generalisation of variants/sd.py:31-44), so an indexing slip at B > 1 shows; the oracle runs one CFG pair at a time.  The fp16 path
