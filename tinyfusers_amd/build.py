@@ -15,7 +15,7 @@ LIB = os.path.join(LIBDIR, "libtinyfusers_hip.so")
 LIB_ABLATION = os.path.join(LIBDIR, "libtinyfusers_hip_ablation.so")
 # the GEMM family is one translation unit per kernel family (gemm_k_*.hip) so that its instances compile in parallel; the largest first
 SOURCES = ["gemm_k_pp16.hip", "gemm_k_pp8.hip", "gemm_k_igemm_128.hip", "gemm_k_igemm_64.hip", "gemm_k_igemm_160.hip", "gemm_k_patch.hip", "sdpa.hip",
-           "gemm_k_igemm8.hip", "gemm_k_c4.hip", "gemm.hip", "norm.hip", "elementwise.hip", "runtime.hip", "sgemm.hip", "comm.hip", "rtc.hip"]
+           "gemm_k_igemm8.hip", "gemm_k_c4.hip", "gemm_k_pp3.hip", "gemm.hip", "norm.hip", "elementwise.hip", "runtime.hip", "sgemm.hip", "comm.hip", "rtc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-ffp-contract=fast"]
 # sdpa.hip: keep the MFMA accumulators in VGPRs (the softmax reads every score: no v_accvgpr_read traffic) and drop
 # the NaN-canonicalising v_max in front of every fmaxf on MFMA outputs (scores are never NaN; -inf masks still work)

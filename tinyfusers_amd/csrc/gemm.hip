@@ -445,7 +445,21 @@ static bool pp_ok(const GemmP& p, int bn, int bm = 256) {
 }
 static int g_pp_np = 0;                                    // test / tuning hook: 0 = default phases per K tile, 2 = one phase per k-step where the tile has both forms
 // rows of a tile as the GroupNorm-statistics code sees them: the ping-pong kernel's epilogue works in 128-row sub-blocks
-static int stats_bm(int bm, int variant) { return variant == 4 ? bm / 2 : bm; }
+static int stats_bm(int bm, int variant) { return (variant == 4 || variant == 6) ? bm / 2 : bm; }
+// k_igemm_pp3 (variant 6): the PATCH form of the ping-pong kernel -- 3x3 / stride 1 / pad 1 convolutions of fp16 operands, every channel count on
+// the 64 grid, a 192-row tile that is a whole number of image rows inside one image (W | 192, 192 | H W: the 96 / 48 / 24-pixel levels of
+// BASELINE config 5), no extra 1x1 segment, no split-K; two patch buffers + three weight slots in LDS
+static bool pp3_setup(GemmP& p, int bm, int bn) {
+  if (bm != 192 || (bn != 160 && bn != 128)) return false;
+  if (p.bf16 || p.fp8 || p.mx || p.gi_part || p.ln_colsum || p.act || p.out8 || p.out32 || gemm_generic(p)) return false;
+  if (p.S != 3 || p.Kc != 9 * p.C || p.K != p.Kc || p.stride != 1 || p.pad != 1 || p.ups || p.C3 || p.C4) return false;
+  if ((p.C1 % 64) || (p.C2 % 64) || p.H != p.Ho || p.W != p.Wo) return false;
+  if (p.W < 8 || (192 % p.W) || (p.HoWo % 192) || (p.M % p.HoWo)) return false;
+  const int ppix = (192 / p.W + 2) * (p.W + 2), ppc = (ppix + 7) / 8;
+  if (ppc > 56 || 2 * ppc * 1024 + 3 * bn * 128 > 163840) return false;      // 7 pieces per wave; the LDS budget
+  p.pt_ppc = ppc; p.pt_ppix = ppix; p.pt_stage = ppc * 1024; p.pt_ns = 3; p.pt_log2w = 0;
+  return true;
+}
 // k_gemm_c4 (variant 5): the persistent short-K kernel -- linears / 1x1 stride-1 convolutions of fp16 operands whose channel counts sit on
 // the 64 grid, one launch (no split-K), no statistics, no time-embedding bias; bias, residual, GEGLU and the LayerNorm fold ride along
 static bool c4_ok(const GemmP& p) {
@@ -519,6 +533,10 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
   else if (variant == 5) {
     if (!c4_ok(p) || c.bm != 128 || c.bn != 128 || p.splitk != 1) { tf_set_error("run_gemm: the persistent short-K kernel cannot run this launch (tile %dx%d, split %d)", c.bm, c.bn, p.splitk); return TF_E_UNSUPPORTED; }
     rc = tfk_launch_c4(p, st);
+  }
+  else if (variant == 6) {
+    if (p.splitk != 1 || !pp3_setup(p, c.bm, c.bn)) { tf_set_error("run_gemm: the patch form of the ping-pong kernel cannot run this launch (tile %dx%d, split %d)", c.bm, c.bn, p.splitk); return TF_E_UNSUPPORTED; }
+    rc = tfk_launch_pp3(p, st, c.bn);
   }
   else if (variant == 2 && patch_setup(p, c.bm, c.bn)) rc = tfk_launch_patch(p, st, c.bm, c.bn);
   else if (c.bm == 256 && c.bn == 128) rc = tfk_launch_igemm_256x128(p, st);
@@ -703,6 +721,32 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
       }
     }
   }
+  // the patch form of the ping-pong kernel (variant 6): 192 x {160, 128} tiles, one launch
+  for (int ci = 0; ci < 2; ++ci) {
+    const int bn = ppbn[ci];
+    GemmP probe = p;
+    if (!pp3_setup(probe, 192, bn)) continue;
+    if ((long long)(p.M / 192) * ((p.N + bn - 1) / bn) < 128) continue;
+    TileCfg c = {192, bn, 1};
+    for (int order = 0; order < 2; ++order) {
+      GemmP q = p;
+      if (q.gn_part && !gn_tile_ok(q, 96, bn)) q.gn_part = nullptr;
+      int rc = launch_one(q, c, 6, order, workspace, st);   // warm-up
+      if (rc) return rc;
+      float tv[5];
+      for (int r = 0; r < 5; ++r) {
+        TF_HIP(hipMemsetAsync(g_flush, r, TF_FLUSH_BYTES, st));
+        TF_HIP(hipEventRecord(a, st));
+        rc = launch_one(q, c, 6, order, workspace, st);
+        if (rc) return rc;
+        TF_HIP(hipEventRecord(b, st));
+        TF_HIP(hipEventSynchronize(b));
+        TF_HIP(hipEventElapsedTime(&tv[r], a, b));
+      }
+      for (int i = 0; i < 5; ++i) for (int j = i + 1; j < 5; ++j) if (tv[j] < tv[i]) { float t = tv[i]; tv[i] = tv[j]; tv[j] = t; }
+      if (tv[2] < best) { best = tv[2]; bc = {c, 6, order}; }
+    }
+  }
   // the persistent short-K kernel (variant 5): a candidate once its 128 x 128 tiles occupy a good part of the CUs (with fewer tiles than
   // blocks it is simply a 4-wave kernel with a register epilogue: 8192 x 320 x 320 8.2 vs 9.0 us, 2048 x 1920 x 640 12.0 vs 13.6)
   if (c4_ok(p) && (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) >= 96) {
@@ -807,6 +851,14 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     wide = 0;
     if (t.c.bm >= 192) t.c = choose_tiles(p.M, p.N, p.K, p.act, workspace != nullptr);
   }
+  if (wide == 6) {
+    // the tile is the kernel's own: a forced tile keeps its width where the kernel has it; a table row this launch cannot take falls back
+    GemmP q = p;
+    const int bn6 = (t.c.bn == 128 || t.c.bn == 160) ? t.c.bn : 160;
+    if (pp3_setup(q, 192, bn6)) t.c = {192, bn6, 1};
+    else if (g_force_wide == 6) { tf_set_error("run_gemm: the patch form of the ping-pong kernel cannot run this launch"); return TF_E_UNSUPPORTED; }
+    else { wide = 0; if (t.c.bm >= 192) t.c = choose_tiles(p.M, p.N, p.K, p.act, workspace != nullptr); }
+  }
   if (wide == 5) {
     GemmP q = p;
     if (!gn_chunks) q.gn_part = nullptr;                  // (statistics the caller did not ask to hear about are never requested)
@@ -867,7 +919,7 @@ int tf_gemm_debug(int flags) {
   TF_REQUIRE(!(flags & (7 | 4096)), "tf_gemm_debug: the ablation bits (1, 2, 4, 4096) exist only in the library built with -DTF_ABLATION (python -m tinyfusers_amd.build --ablation)");
 #endif
   g_pp_np = (flags & 8192) ? 2 : 0;                       // 8192: k_igemm_pp with one phase per k-step even where the 3-slot ring allows one per K tile
-  g_force_wide = (flags & 1024) ? 5 : (flags & 512) ? 4 : (flags & 256) ? 3 : (flags & 128) ? 2 : (flags & 16) ? 1 : (flags & 8) ? 0 : -1;   // 128 / 256 / 512 / 1024: the PATCH / ALL8 / ping-pong / persistent short-K variants where eligible
+  g_force_wide = (flags & 2048) ? 6 : (flags & 1024) ? 5 : (flags & 512) ? 4 : (flags & 256) ? 3 : (flags & 128) ? 2 : (flags & 16) ? 1 : (flags & 8) ? 0 : -1;   // 128 / 256 / 512 / 1024 / 2048: the PATCH / ALL8 / ping-pong / persistent short-K / ping-pong PATCH variants where eligible
   g_force_order = (flags & 64) ? 1 : (flags & 32) ? 0 : -1;
   return TF_OK;
 }
@@ -944,7 +996,7 @@ int tf_gemm_tune_load(const char* path) {
     if (act == 1 && (bn % 64) != 0) ok = false;
     if ((act == 1 || ln || (k[9] & 256)) && sk > 1) ok = false;
     if (wide == 5) ok = bm == 128 && bn == 128 && sk == 1 && !f8;
-    if (ok) g_tuned[k] = {{bm, bn, sk}, wide < 0 || wide > 5 ? 0 : wide, order != 0 ? 1 : 0};
+    if (ok) g_tuned[k] = {{bm, bn, sk}, wide < 0 || wide > 6 ? 0 : wide, order != 0 ? 1 : 0};
   }
   fclose(f);
   return TF_OK;
@@ -1035,7 +1087,7 @@ int tf_prof_dump(const char* path) {
   if (rc) return rc;
   FILE* f = fopen(path, "w");
   TF_REQUIRE(f, "tf_prof_dump: cannot open %s", path);
-  fprintf(f, "M,N,K,taps,bm,bn,splitk,variant,launches,total_ms,avg_us,tflops\n");   // variant: 0 deep ring, 1 wide, 2 patch, 3 all8, 4 ping-pong; times include the split-K reduce
+  fprintf(f, "M,N,K,taps,bm,bn,splitk,variant,launches,total_ms,avg_us,tflops\n");   // variant: 0 deep ring, 1 wide, 2 patch, 3 all8, 4 ping-pong, 5 persistent short-K, 6 ping-pong patch; times include the split-K reduce
   for (auto& kv : g_prof_shapes) {
     const auto& k = kv.first;
     double ms = kv.second.second; long long n = kv.second.first;

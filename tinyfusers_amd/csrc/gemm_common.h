@@ -137,6 +137,86 @@ __device__ __forceinline__ void wait_stages(int k) {
   }
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n in [0, 63]: computed jump into a table of (s_waitcnt, s_branch) pairs
+// (8 bytes each) -- the counter is an immediate field, and a compare chain costs more than the K tile it guards.
+__device__ __forceinline__ void wait_vm_dyn(int n) {
+  n = __builtin_amdgcn_readfirstlane(n < 0 ? 0 : n > 63 ? 63 : n);
+  asm volatile(
+      "s_getpc_b64 s[96:97]\n"                 // address of the next instruction
+      "s_lshl_b32 s98, %0, 3\n"                // 4 bytes each from here to the table: 6 instructions = 24 bytes
+      "s_add_u32 s96, s96, s98\n"
+      "s_addc_u32 s97, s97, 0\n"
+      "s_add_u32 s96, s96, 24\n"
+      "s_addc_u32 s97, s97, 0\n"
+      "s_setpc_b64 s[96:97]\n"
+      "s_waitcnt vmcnt(0)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(1)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(2)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(3)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(4)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(5)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(6)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(7)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(8)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(9)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(10)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(11)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(12)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(13)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(14)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(15)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(16)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(17)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(18)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(19)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(20)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(21)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(22)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(23)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(24)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(25)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(26)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(27)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(28)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(29)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(30)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(31)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(32)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(33)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(34)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(35)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(36)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(37)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(38)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(39)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(40)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(41)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(42)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(43)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(44)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(45)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(46)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(47)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(48)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(49)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(50)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(51)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(52)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(53)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(54)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(55)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(56)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(57)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(58)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(59)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(60)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(61)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(62)\n s_branch 1f\n"
+      "s_waitcnt vmcnt(63)\n s_branch 1f\n"
+      "1:\n"
+      :: "s"(n) : "s96", "s97", "s98", "scc", "memory");
+}
+
 // ---- GroupNorm of the input inside the GEMM (GemmP::gi_*) ----------------------------------------------------------------
 // LDS accesses that touch (or sit next to) LDS-DMA landing zones go through inline asm: for an LDS access the compiler cannot
 // disambiguate from an outstanding LDS-DMA it inserts s_waitcnt vmcnt(0), which would drain the whole ring.
@@ -571,3 +651,4 @@ int tfk_launch_pp16(const GemmP& p, hipStream_t st, int bm, int bn, int np_force
 int tfk_launch_pp8(const GemmP& p, hipStream_t st, int bm, int bn);
 //   k_gemm_c4 (gemm_k_c4.hip)
 int tfk_launch_c4(const GemmP& p, hipStream_t st);
+int tfk_launch_pp3(const GemmP& p, hipStream_t st, int bn);

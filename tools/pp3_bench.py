@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""k_igemm_pp3 (the patch form of the ping-pong kernel, tf_gemm_debug(2048)) against k_igemm_pp (512) and the deep-ring kernels on the 3x3
+convolutions of BASELINE config 5 (4 images, 96 x 96 latents: UNet batch 8).  GPU box only.
+usage: tools/pp3_bench.py"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pp_bench import T, hip, lib, st, time_call
+
+
+def bench(n, hw, cin, cout):
+    rng = np.random.default_rng(0)
+    x = T.DeviceArray.from_numpy((rng.standard_normal((n, cin, hw, hw)) * 0.5).astype(np.float16))
+    wt = T.DeviceArray.from_numpy((rng.standard_normal((cout, cin, 3, 3)) * (cin * 9) ** -0.5).astype(np.float16))
+    b = T.DeviceArray.from_numpy(rng.standard_normal(cout).astype(np.float16))
+    y = T.DeviceArray.empty((n, cout, hw, hw))
+    M, K = n * hw * hw, 9 * cin
+    ws = T.DeviceArray.empty((min(4 * M * cout * 4, 1 << 30) + 16,), np.uint8, "row")
+    flops = 2.0 * M * cout * K
+
+    def fn():
+        hip.tf_conv2d_f16(y.ptr, x.ptr, None, wt.ptr, b.ptr, None, 0, None, n, hw, hw, cin, 0, cout, 3, 3, 1, 1, 0, ws.ptr, ws.nbytes, st.handle)
+    out = []
+    cfgs = [(128, 160, 1, 8, 0), (128, 160, 1, 128, 0), (256, 160, 1, 512, 0), (192, 160, 1, 512, 0), (192, 128, 1, 512, 0), (192, 160, 2, 512, 0), (256, 160, 2, 512, 0),
+            (192, 160, 1, 2048, 0), (192, 160, 1, 2048, 1), (192, 128, 1, 2048, 0), (192, 128, 1, 2048, 1)]
+    for bm, bn, sk, flags, order in cfgs:
+        lib.tf_gemm_force_config(bm, bn, sk); lib.tf_gemm_debug(flags | (64 if order else 32))
+        try:
+            us = time_call(fn)
+        except RuntimeError:
+            us = float("inf")
+        finally:
+            lib.tf_gemm_force_config(0, 0, 0); lib.tf_gemm_debug(0)
+        out.append(f"{ {8: 'deep', 128: 'patch', 512: 'pp', 2048: 'PP3'}[flags]}{bm}x{bn}/{sk}o{order}: {us:7.1f} us {flops / us / 1e6:5.0f} TF")
+    print(f"conv3x3 {cin}->{cout} @{hw} (M={M} K={K})\n   " + "\n   ".join(out), flush=True)
+
+
+if __name__ == "__main__":
+    bench(8, 96, 320, 320)
+    bench(8, 96, 640, 320)
+    bench(8, 48, 640, 640)
+    bench(8, 48, 1280, 640)
+    bench(8, 24, 1280, 1280)
+    bench(8, 24, 2560, 1280)
