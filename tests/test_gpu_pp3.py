@@ -17,9 +17,9 @@ def conv_nchw(x, w, pad=1):
     return torch.nn.functional.conv2d(torch.from_numpy(x), torch.from_numpy(w), padding=pad).numpy()
 
 
-@pytest.mark.parametrize("bn", [160, 128])
-@pytest.mark.parametrize("n,c1,c2,hw,cout", [(1, 64, 0, 24, 64), (2, 64, 0, 24, 200), (3, 128, 64, 24, 320), (2, 64, 64, 48, 136), (1, 192, 0, 96, 160), (2, 320, 0, 48, 320)])
-def test_pp3_conv_exact_integers(tf, bn, n, c1, c2, hw, cout):
+@pytest.mark.parametrize("n,c1,c2,hw,cout", [(1, 64, 0, 24, 64), (2, 64, 0, 24, 200), (3, 128, 64, 24, 320), (2, 64, 64, 48, 136), (1, 192, 0, 96, 160), (2, 320, 0, 48, 320),
+                                             (1, 64, 64, 96, 200), (1, 128, 0, 48, 64), (2, 256, 64, 24, 136)])
+def test_pp3_conv_exact_integers(tf, n, c1, c2, hw, cout):
     """1 ... 5 channel slabs (prologue-only patch, the double buffer's both parities), image borders on every side of a tile, ragged channel tiles,
     the concat pair, several images; bias + time embedding + residual in the shared epilogue.  Integers small enough that every partial sum is
     exact in fp16 / fp32: bit-exact against a float32 convolution."""
@@ -34,7 +34,7 @@ def test_pp3_conv_exact_integers(tf, bn, n, c1, c2, hw, cout):
     m = Conv2d(cin, cout, [3, 3], padding=[1, 1], init=False); m.weight = dev(tf, wt); m.bias = dev(tf, b)
     x = (dev(tf, xa), dev(tf, xb)) if c2 else dev(tf, xa)
     ed, rd = dev(tf, e), dev(tf, r)
-    with forced(bn, 1, 2048, 192):
+    with forced(160, 1, 2048, 192):        # (the tile width is the instance's own: 160 on 96-pixel rows, 128 on 48 / 24)
         got = m(x, bias_nc=ed, residual=rd).numpy()
     want = conv_nchw(np.concatenate((xa, xb), 1) if c2 else xa, wt) + b[None, :, None, None] + e[:, :, None, None] + r
     assert np.abs(want).max() < 2048

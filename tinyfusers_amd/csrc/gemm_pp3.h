@@ -10,23 +10,43 @@
 // pixels fetched nine times -- every filter tap stages its own shifted copy of the tile's activation rows.  Here the K loop runs channel-slab major
 // (for each 64-channel slab its nine taps) and the slab's activation PATCH -- the (192 / W + 2) x (W + 2) pixels the nine taps touch, zero where
 // the image ends -- is brought into LDS ONCE, double buffered; a tap's fragments are read straight out of the patch at pixel offset
-// dy (W + 2) + dx.  Per K tile a block then ingests the weight tile (BN x 128 B) plus a ninth of a patch instead of weight tile + 192 x 128 B:
+// dy PW + dx (PW = W + 4: the patch's row pitch).  Per K tile a block then ingests the weight tile (BN x 128 B) plus a ninth of a patch instead of weight tile + 192 x 128 B:
 // 25.6 KB instead of 44.6 KB at 192 x 160 and W = 96, and 3.2 LDS-DMA instructions per wave instead of 5.5.
 //
-// Everything else is k_igemm_pp's one-phase form: all eight waves load and compute, two wave groups one barrier apart, a three-slot LDS-DMA ring
-// (weights only) two tiles ahead, counted vmcnt waits (run-time counts through a computed jump: the tiles of a slab carry different numbers of
-// loads), LDS image rows XOR-swizzled on the source side and again on the read, the shared epilogue in two passes of 96 rows.
-//   LDS: patch buffer 0 | patch buffer 1 | weight slots 0 .. 2.  patch(g) lives in buffer g & 1; its pieces ride on the tiles of slab g - 1, one per wave
-//   and tap (the buffer was last read for slab g - 2: behind every barrier those tiles are issued after); slab 0's patch is issued whole in the prologue.
-//   Patch row pr = py (W + 2) + px holds pixel (y0 - 1 + py, px - 1) of the tile's image (y0 = its first image row); output row m of the tile
-//   (image row yl = m / W, column x) reads tap (dy, dx) at patch row (yl + dy)(W + 2) + x + dx.
-// Channel counts on the 64 grid (the concat pair: a slab lies in one source), no extra 1x1 segment, no split-K, fp16.
-template <int BN>
+// Everything else is k_igemm_pp's one-phase form: all eight waves load and compute, two wave groups one barrier apart, an LDS-DMA ring of three
+// slots (weights only) two tiles ahead -- nine taps = three turns of the ring, so a tap's slot is a compile-time constant; a fourth slot where the
+// patches leave room for it measured 3-5 % SLOWER (profiles/r04_pp3.txt): latency is not what this loop waits for -- counted vmcnt waits (run-time counts through a computed jump: the tiles of a slab carry different numbers
+// of loads), LDS image rows XOR-swizzled on the source side and again on the read, the shared epilogue in two passes of 96 rows.
+//   LDS: patch buffer 0 | patch buffer 1 | weight slots 0 .. 2.  patch(g) lives in buffer g & 1; its pieces ride on the first tiles of slab g - 1, one
+//   per wave and tap (the buffer was last read for slab g - 2: behind every barrier those tiles are issued after); slab 0's patch is issued whole in the
+//   prologue.  Patch row pr = py PW + px holds pixel (y0 - 1 + py, px - 1) of the tile's image (y0 = its first image row; px > W + 1 is padding);
+//   output row m of the tile (image row yl = m / W, column x) reads tap (dy, dx) at patch row (yl + dy) PW + x + dx.
+// Channel counts on the 64 grid (the concat pair: a slab lies in one source), no extra 1x1 segment, no split-K, fp16.  W is a template parameter:
+// every patch offset is then an instruction immediate.
+// The patch image's swizzle: a tap reads 16 consecutive patch rows starting ANYWHERE, so the XOR term of the aligned tiles ((row >> 1) & 7) would put two
+// rows of a ds_read_b128 lane group on the same banks for every shift but 0.  chunk ^ (row & 6) is conflict-free for every start row: the hardware
+// serves lanes {0-3, 12-15} of one k-chunk together with lanes {4-11} of the next chunk, i.e. per row parity four rows of one cyclic window of (row >> 1)
+// with chunk c and the other four with chunk c ^ 1, and 2 ((row >> 1) & 3) separates them for all eight windows (brute force over all 8^8 maps).
+// With PW = 4 mod 8 the swizzle term of row pr + PW is that of pr with bit 2 flipped -- the other 64-byte half of the row -- and that of pr + 2 PW
+// is the same: the addresses of tap (dy, dx) are those of tap (0, dx) plus the immediate dy PW 128, with the two k-steps' registers swapped for dy = 1.
+// So a wave keeps 3 (dx) x 3 (pixel tiles) x 2 (k-steps) fragment addresses and the K loop has no address arithmetic besides the buffer flip per slab.
+#ifndef TF_PP3_STAMP
+#define TF_PP3_STAMP 0    // diagnostic builds (tools/pp3_stamp.py), stamps into the workspace: 1 = s_memtime of waves 0 and 4 of block 0 around the phases of the tiles of slab 1 + the clock pair; 2 = only the (s_memtime, s_memrealtime) pair around block 0's K loop
+#endif
+#ifndef TF_PP3_WB
+#define TF_PP3_WB 0       // experiment switches (tagged builds): the last WB weight pieces of a wave and (PB = 1) its patch piece are issued between the
+#define TF_PP3_PB 0       // MFMAs of the tile instead of in front of the barrier (balancing the two phases of the ping-pong)
+#endif
+template <int BN, int W>
 __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
-  constexpr int BM = 192, TN = BN / 2, MJ = 3, NI = TN / 16, NS = 3;
+  constexpr int BM = 192, TN = BN / 2, MJ = 3, NI = TN / 16, NS = 3, D = NS - 1;
   constexpr int WST = BN * 128;                            // bytes of a weight ring slot
   constexpr int NWG = BN / 8, WPW = (NWG + 7) / 8, WREM = NWG % 8;
-  constexpr int PPW = 7;                                   // patch pieces per wave at most (56 pieces = 448 patch rows)
+  constexpr int PW = W + 4, PROWS = (BM / W + 2) * PW, NPP = (PROWS + 7) / 8, PB = NPP * 1024;     // patch: row pitch, rows, 8-row pieces, bytes of a buffer
+  constexpr int PPW = (NPP + 7) / 8;                       // patch pieces per wave at most: they ride on taps 0 .. PPW - 1 and are waited for D - 1 tiles later
+  static_assert(W % 8 == 0 && BM % W == 0, "the tile is whole image rows; PW = 4 mod 8");
+  static_assert(PPW - 1 + D - 1 <= 8, "a slab's patch must have landed when its first tile is read");
+  static_assert(2 * PB + NS * WST <= 163840, "LDS budget");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -42,25 +62,22 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
   if (p.order == 0) { tile_m = bid / p.ntn; tile_n = bid - tile_m * p.ntn; }
   else { tile_n = bid / p.ntm; tile_m = bid - tile_n * p.ntm; }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int PW = p.W + 2, PR = p.pt_ppix, NPP = p.pt_ppc, PB = p.pt_stage;
-  const int img = m0 / p.HoWo, y0 = fast_div(m0 - img * p.HoWo, p.dv_wo_mul, p.dv_wo_shr);
+  const int img = m0 / p.HoWo, y0 = (m0 - img * p.HoWo) / W;
   const int G = p.C >> 6, nt = G * 9;                      // 64-channel slabs, K tiles
   const unsigned lds0 = lds_off(smem);
   const unsigned lds_w = lds0 + 2u * (unsigned)PB;
 
-  // ---- staging geometry.  Patch piece q = wid + 8 i covers patch rows 8 q .. 8 q + 7; lane -> row 8 q + sub, source chunk cs (swizzled)
+  // ---- staging geometry.  Patch piece q = wid + 8 i covers patch rows 8 q .. 8 q + 7; lane -> row 8 q + sub, source chunk swizzled
   const int sub = lane >> 3;
-  const int cs = (lane & 7) ^ ((4 * (wid & 1) + (sub >> 1)) & 7);
+  const int cs = (lane & 7) ^ ((4 * (wid & 1) + (sub >> 1)) & 7);      // weight rows: the aligned tiles' swizzle
+  const int csp = (lane & 7) ^ (sub & 6);                                // patch rows
   int pp_pix[PPW];
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
-    const int q = wid + 8 * i, pr = 8 * q + sub;
-    pp_pix[i] = -1;
-    if (q < NPP && pr < PR) {
-      const int py = pr / PW, px = pr - py * PW;
-      const int y = y0 - 1 + py, x = px - 1;
-      if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) pp_pix[i] = (img * p.H + y) * p.W + x;
-    }
+    const int pr = 8 * (wid + 8 * i) + sub;
+    const int py = pr / PW, px = pr - py * PW;
+    const int y = y0 - 1 + py, x = px - 1;
+    pp_pix[i] = (pr < PROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)W) ? (img * p.H + y) * W + x : -1;
   }
   const i4v rs_w = raw_rsrc(p.w, p.w_bytes);
   unsigned gw[WPW];
@@ -72,8 +89,9 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
   const int C1_ = p.C1, C2_ = p.C2, Cc_ = p.C;
   const unsigned long long px1 = (unsigned long long)p.x, px2 = (unsigned long long)(p.x2 ? p.x2 : p.x);
   const int nb1 = (int)p.x_bytes, nb2 = (int)p.x2_bytes;
-  // pieces [i0, i1) of this wave's share of patch(g) into buffer g & 1; returns the number of loads issued
-  auto stage_patch = [&](int g, int i0, int i1) -> int {
+  // piece `i` of this wave's share of patch(g) into buffer g & 1; returns the number of loads issued
+  auto stage_patch = [&](int g, int i) -> int {
+    if (wid + 8 * i >= NPP) return 0;
     const int c = g * 64;
     const bool second = c >= C1_;
     const unsigned long long px = second ? px2 : px1;
@@ -81,70 +99,67 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
     rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)px); rs[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(px >> 32) & 0xffffu));
     rs[2] = __builtin_amdgcn_readfirstlane(second ? nb2 : nb1); rs[3] = 0x00020000;
     const int ld2 = __builtin_amdgcn_readfirstlane((second ? C2_ : C1_) * 2);
-    const int cb = __builtin_amdgcn_readfirstlane((second ? c - C1_ : c) * 2) + cs * 16;
-    const unsigned base = lds0 + (unsigned)(g & 1) * (unsigned)PB + (unsigned)wid * 1024u;
-    int n = 0;
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      if (i < i0 || i >= i1 || wid + 8 * i >= NPP) continue;
-      dma16(rs, pp_pix[i] >= 0 ? (unsigned)(pp_pix[i] * ld2 + cb) : TF_OOB, base + (unsigned)i * 8192u);
-      ++n;
-    }
-    return n;
+    const int cb = __builtin_amdgcn_readfirstlane((second ? c - C1_ : c) * 2) + csp * 16;
+    dma16(rs, pp_pix[i] >= 0 ? (unsigned)(pp_pix[i] * ld2 + cb) : TF_OOB, lds0 + (unsigned)(g & 1) * (unsigned)PB + (unsigned)wid * 1024u + (unsigned)i * 8192u);
+    return 1;
   };
   // the weight tile of (slab g, tap) into ring slot `slot`; returns the number of loads issued
-  auto stage_w = [&](int slot, int g, int tap) -> int {
+  auto stage_w = [&](int slot, int g, int tap, int i0 = 0, int i1 = 64) -> int {
     const unsigned base = lds_w + (unsigned)slot * WST + (unsigned)wid * 1024u;
     const unsigned kb = (unsigned)(tap * Cc_ + g * 64) * 2u;
     int n = 0;
 #pragma unroll
     for (int i = 0; i < WPW; ++i)
-      if (WREM == 0 || i < WPW - 1 || wid < WREM) { dma16_w(rs_w, gw[i] != TF_OOB ? gw[i] + kb : TF_OOB, base + (unsigned)i * 8192u); ++n; }
+      if (i >= i0 && i < i1 && (WREM == 0 || i < WPW - 1 || wid < WREM)) { dma16_w(rs_w, gw[i] != TF_OOB ? gw[i] + kb : TF_OOB, base + (unsigned)i * 8192u); ++n; }
     return n;
   };
 
   // ---- fragment addressing
   const int lr = lane & 15, lg = lane >> 4;
-  int pp0[MJ];                                             // patch row of tap (0, 0) for row lr of pixel tile j
+  int ax[2][3][MJ];                                        // [k-step][dx][pixel tile]: byte address in the CURRENT patch buffer of tap (0, dx)
 #pragma unroll
   for (int j = 0; j < MJ; ++j) {
     const int ml = wm * (BM / 4) + j * 16 + lr;
-    const int yl = fast_div(ml, p.dv_wo_mul, p.dv_wo_shr);
-    pp0[j] = yl * PW + (ml - yl * p.W);
+    const int yl = ml / W;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int pr = yl * PW + (ml - yl * W) + dx;
+      ax[0][dx][j] = pr * 128 + ((lg ^ (pr & 6)) << 4);
+      ax[1][dx][j] = ax[0][dx][j] ^ 64;
+    }
   }
-  const int wo_ = (wn * TN) * 128 + lr * 128 + ((lg ^ ((lr >> 1) & 7)) << 4);      // + i * 2048
+  const int wo0 = 2 * PB + (wn * TN) * 128 + lr * 128 + ((lg ^ ((lr >> 1) & 7)) << 4);      // + slot * WST + i * 2048
+  const int wo1 = wo0 ^ 64;
   f4 acc[NI][MJ];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < MJ; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
   h8 wf[2][NI], xf[2][MJ];
-  auto read_frags = [&](int buf, int slot, int tap) {
-    const char* pb = smem + buf * PB;
-    const char* wb = smem + 2 * PB + slot * WST;
-    const int dlt = (tap / 3) * PW + (tap % 3);
+  auto read_frags = [&](int slot, int tap) {
+    const int dy = tap / 3, dx = tap - 3 * dy, sw = dy & 1;      // (compile-time after unrolling)
 #pragma unroll
     for (int j = 0; j < MJ; ++j) {
-      const int pr = pp0[j] + dlt;
-      const int a = pr * 128 + ((lg ^ ((pr >> 1) & 7)) << 4);
-      xf[0][j] = *reinterpret_cast<const h8*>(pb + a);
-      xf[1][j] = *reinterpret_cast<const h8*>(pb + (a ^ 64));
+      xf[0][j] = *reinterpret_cast<const h8*>(smem + ax[sw][dx][j] + dy * PW * 128);
+      xf[1][j] = *reinterpret_cast<const h8*>(smem + ax[sw ^ 1][dx][j] + dy * PW * 128);
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      wf[0][i] = *reinterpret_cast<const h8*>(wb + (wo_ + i * 2048));
-      wf[1][i] = *reinterpret_cast<const h8*>(wb + ((wo_ + i * 2048) ^ 64));
+      wf[0][i] = *reinterpret_cast<const h8*>(smem + wo0 + (slot * WST + i * 2048));
+      wf[1][i] = *reinterpret_cast<const h8*>(smem + wo1 + (slot * WST + i * 2048));
     }
   };
-  auto mma = [&]() {
+  auto mma = [&](int c0 = 0, int c1 = 64) {          // chunks [c0, c1) of the tile's 2 NI chunks of MJ MFMAs
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int i = 0; i < NI; ++i)
+        if (f * NI + i >= c0 && f * NI + i < c1) {
 #pragma unroll
-        for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[f][i], xf[f][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[f][i], xf[f][j], acc[i][j], 0, 0, 0);
+        }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -153,45 +168,85 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
     asm volatile("" ::: "memory");
   };
 
-  // bias and time-embedding values of this tile's columns (as in k_igemm_pp)
-  const int lb_img0 = img;
-  float lb_b = 0.f, lb_c0 = 0.f, lb_c1 = 0.f;
+  // bias and time-embedding values of this tile's columns (as in k_igemm_pp; a tile lies inside one image)
+  float lb_b = 0.f, lb_c0 = 0.f;
   if (tid < BN && n0 + tid < p.N) {
     if (p.bias) lb_b = (float)p.bias[n0 + tid];
-    if (p.bias_nc) {
-      lb_c0 = (float)p.bias_nc[(long long)lb_img0 * p.bias_nc_stride + n0 + tid];
-      if ((lb_img0 + 1) * p.HoWo < p.M) lb_c1 = (float)p.bias_nc[(long long)(lb_img0 + 1) * p.bias_nc_stride + n0 + tid];
-    }
+    if (p.bias_nc) lb_c0 = (float)p.bias_nc[(long long)img * p.bias_nc_stride + n0 + tid];
   }
 
-  // ---- prologue: patch(0) whole, weight tiles 0 and 1; tile 0's loads landed, tile 1's in flight
-  stage_patch(0, 0, PPW);
-  stage_w(0, 0, 0);
-  const int n1 = stage_w(1, 0, 1);                         // (nt >= 9)
-  wait_vm_dyn(n1);
+  // ---- prologue: patch(0) whole, weight tiles 0 .. D - 1; tile 0's loads landed, the others in flight
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) stage_patch(0, i);
+  int nw = 0;
+#pragma unroll
+  for (int s_ = 0; s_ < D; ++s_) nw = stage_w(s_, 0, s_);  // (nt >= 9 > D; every tile of a wave carries the same number of weight loads)
+  wait_vm_dyn(nw * (D - 1));
   barrier();                                               // P: patch(0) and weight tile 0 are visible to every wave
   if (grp == 1) barrier();                                 // the second half falls one barrier behind
 
-  int rs = 0, ws = 2;                                      // ring slot of tile t / of tile t + 2
+#if TF_PP3_STAMP
+  unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(p.partial) + (wid >> 2) * 64;
+  const bool stamping = blockIdx.x == 0 && (wid & 3) == 0 && p.partial;
+#define PP3_STAMP(k) do { if (TF_PP3_STAMP != 1) break; __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); if (stamping && g == 1 && lane == 0) stamps[tap * 6 + (k)] = t_; } while (0)
+  if (stamping && wid == 0 && lane == 0) {                  // in-kernel clock: core-clock and 100 MHz counters around the K loop (MI355X_MICROARCH.md, DVFS give-back item 6)
+    unsigned long long a_, b_;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(a_), "=s"(b_) :: "memory");
+    stamps[56] = a_; stamps[57] = b_;
+  }
+#else
+#define PP3_STAMP(k) do { } while (0)
+#endif
   for (int g = 0; g < G; ++g) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int t = g * 9 + tap;
-      read_frags(g & 1, rs, tap);
-      int nl = 0;                                          // loads this wave issues during this tile (the newest ones: they stay in flight)
-      if (t + 2 < nt) nl += tap < 7 ? stage_w(ws, g, tap + 2) : stage_w(ws, g + 1, tap - 7);
-      if (g + 1 < G && tap < PPW) nl += stage_patch(g + 1, tap, tap + 1);
+      PP3_STAMP(0);
+      read_frags(tap % NS, tap);                           // (tile t = 9 g + tap lives in slot t % 3 = tap % 3)
+      int nl = 0;                                          // loads this wave issues during this tile: the newest ones, they stay in flight
+      constexpr int WA = WPW - TF_PP3_WB;                  // weight pieces issued in front of the barrier
+      const int wg = tap + D < 9 ? g : g + 1, wt = tap + D < 9 ? tap + D : tap + D - 9;
+      const bool wmore = tap + D < 9 || g + 1 < G, pmore = tap < PPW && g + 1 < G;
+      if (wmore) nl += stage_w((tap + D) % NS, wg, wt, 0, WA);
+      if (!TF_PP3_PB && pmore) nl += stage_patch(g + 1, tap);
       const bool next = t + 1 < nt;
-      if (next && grp == 1) wait_vm_dyn(nl);               // tile t + 1 (and every patch piece issued so far) landed; what this tile issued stays in flight
+      PP3_STAMP(1);
+      if (next && grp == 1) wait_vm_dyn(nl);               // tile t + 1 (and every patch piece of an earlier tile) landed
       wait_lds_reads();
+      PP3_STAMP(2);
       barrier();
-      mma();
+      PP3_STAMP(3);
+      if (TF_PP3_WB || TF_PP3_PB) {
+        mma(0, NI / 2);
+        if (TF_PP3_WB && wmore) nl += stage_w((tap + D) % NS, wg, wt, WA, WA + (TF_PP3_WB + 1) / 2);
+        mma(NI / 2, NI);
+        if (TF_PP3_WB > 1 && wmore) nl += stage_w((tap + D) % NS, wg, wt, WA + (TF_PP3_WB + 1) / 2, WPW);
+        mma(NI, NI + NI / 2);
+        if (TF_PP3_PB && pmore) nl += stage_patch(g + 1, tap);
+        mma(NI + NI / 2, 2 * NI);
+      } else mma();
+      PP3_STAMP(4);
       if (next && grp == 0) wait_vm_dyn(nl);
+      PP3_STAMP(5);
       barrier();
-      if (++rs == NS) rs = 0;
-      if (++ws == NS) ws = 0;
     }
+    // the next slab's patch is the other buffer
+    const int flip = (g & 1) ? -PB : PB;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) ax[f][dx][j] += flip;
   }
+#if TF_PP3_STAMP
+  if (stamping && wid == 0 && lane == 0) {
+    unsigned long long a_, b_;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(a_), "=s"(b_) :: "memory");
+    stamps[58] = a_; stamps[59] = b_;
+  }
+#endif
   if (grp == 0) barrier();                                 // the first half waits for the second: every wave is done with the ring and the patches
 
   // ---- epilogue: two passes of 96 rows through the shared scratch (as k_igemm_pp)
@@ -200,15 +255,15 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
   for (int i = 0; i < NI; ++i) csum[i] = (f4){0.f, 0.f, 0.f, 0.f};
   constexpr int BS = BM / 2;
   float* const lbt = reinterpret_cast<float*>(smem + 4 * (BS / 2) * (TN + 4) * 4 + BS * 8 + 4 * BN * 8);
-  if (tid < BN) { lbt[tid] = lb_b; lbt[BN + tid] = lb_c0; lbt[2 * BN + tid] = lb_c1; }
-  const int lb_m1 = (lb_img0 + 1) * p.HoWo;
+  if (tid < BN) { lbt[tid] = lb_b; lbt[BN + tid] = lb_c0; lbt[2 * BN + tid] = 0.f; }
+  const int lb_m1 = (img + 1) * p.HoWo;
 #pragma unroll
   for (int sm = 0; sm < 2; ++sm) {
     if ((wm >> 1) == sm) igemm_scratch_write<BS, BN>(p, acc, csum, smem, (wm & 1) | (wn << 1), lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     barrier();
     igemm_epilogue<BS, BN, 0, false, 2, true>(p, smem, m0 + sm * BS, n0, 0, wid & 3, wid >> 2, lane, lbt, n0, lb_m1);
-    if (p.gn_part && m0 + sm * BS < p.M) igemm_gn_stats<BS, BN>(p, smem, m0 + sm * BS, n0, wid & 3, wid >> 2, lane);
+    if (p.gn_part) igemm_gn_stats<BS, BN>(p, smem, m0 + sm * BS, n0, wid & 3, wid >> 2, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     barrier();
   }

@@ -22,7 +22,7 @@ def bench(n, hw, cin, cout):
         hip.tf_conv2d_f16(y.ptr, x.ptr, None, wt.ptr, b.ptr, None, 0, None, n, hw, hw, cin, 0, cout, 3, 3, 1, 1, 0, ws.ptr, ws.nbytes, st.handle)
     out = []
     cfgs = [(128, 160, 1, 8, 0), (128, 160, 1, 128, 0), (256, 160, 1, 512, 0), (192, 160, 1, 512, 0), (192, 128, 1, 512, 0), (192, 160, 2, 512, 0), (256, 160, 2, 512, 0),
-            (192, 160, 1, 2048, 0), (192, 160, 1, 2048, 1), (192, 128, 1, 2048, 0), (192, 128, 1, 2048, 1)]
+            (192, 160, 1, 2048, 0), (192, 160, 1, 2048, 1)]      # (variant 6 takes its own tile width: 160 on 96-pixel rows, 128 on 48 / 24)
     for bm, bn, sk, flags, order in cfgs:
         lib.tf_gemm_force_config(bm, bn, sk); lib.tf_gemm_debug(flags | (64 if order else 32))
         try:
