@@ -55,12 +55,12 @@ def upload_mx(tf, codes, scales, shape, layout):
 
 
 class forced:
-    def __init__(self, bm, bn, sk=1):
-        self.cfg = (bm, bn, sk)
+    def __init__(self, bm, bn, sk=1, flags=512):     # 512: k_igemm_pp<F8>; 2048: k_igemm_pp3<F8> (the patch form: 3x3 convs on 48 / 24-pixel rows)
+        self.cfg, self.flags = (bm, bn, sk), flags
 
     def __enter__(self):
         from tinyfusers_amd.native import lib
-        lib.tf_gemm_force_config(*self.cfg); lib.tf_gemm_debug(512)
+        lib.tf_gemm_force_config(*self.cfg); lib.tf_gemm_debug(self.flags)
 
     def __exit__(self, *a):
         from tinyfusers_amd.native import lib
@@ -165,6 +165,10 @@ CONV_MX = [   # n, c, hw, cout, r, (bm, bn, splitk)
     (2, 256, 16, 256, 1, (192, 128, 1)),     # 1x1
     (8, 320, 96, 320, 3, (192, 160, 1)),     # config 5's most frequent conv, its tile
     (2, 1280, 12, 1280, 3, (256, 160, 1)),   # 256 x 160 exists on the 128 grid only; a tile spans two images (HoWo = 144 < 256: no time embedding)
+    (2, 128, 24, 128, 3, (192, 128, 1, 2048)),   # the patch form (k_igemm_pp3<F8>): one 128-channel slab -- patch and scale patch from the prologue only
+    (1, 384, 48, 256, 3, (192, 128, 1, 2048)),   # three slabs: both parities of the double buffers, scale loads on tap 7
+    (3, 256, 24, 200, 3, (192, 128, 1, 2048)),   # ragged channel tile, several images
+    (2, 640, 48, 640, 3, (192, 128, 1, 2048)),   # config 5's level-1 conv
 ]
 
 

@@ -451,7 +451,8 @@ static int stats_bm(int bm, int variant) { return (variant == 4 || variant == 6)
 // BASELINE config 5, the row length a template parameter), no extra 1x1 segment, no split-K; two patch buffers + 3 or 4 weight slots in LDS
 static bool pp3_setup(GemmP& p, int bm, int bn) {
   if (bm != 192 || bn != (p.W == 96 ? 160 : 128)) return false;                                       // the instantiated (row length, tile width) pairs
-  if (p.bf16 || p.fp8 || p.mx || p.gi_part || p.ln_colsum || p.act || p.out8 || p.out32 || gemm_generic(p)) return false;
+  if (p.bf16 || p.gi_part || p.ln_colsum || p.act || p.out8 || p.out32 || gemm_generic(p)) return false;
+  if (p.fp8 && (!p.mx || p.W == 96 || (p.C1 % 128) || (p.C2 % 128))) return false;                  // e4m3: block-scaled, 128-channel slabs, the 48 / 24-pixel instances
   if (p.S != 3 || p.Kc != 9 * p.C || p.K != p.Kc || p.stride != 1 || p.pad != 1 || p.ups || p.C3 || p.C4) return false;
   if ((p.C1 % 64) || (p.C2 % 64) || p.H != p.Ho || p.W != p.Wo) return false;
   if ((p.W != 96 && p.W != 48 && p.W != 24) || (p.HoWo % 192) || (p.M % p.HoWo)) return false;      // the instantiated row lengths; a tile = whole rows of one image
@@ -489,7 +490,7 @@ static bool gi_any_ok(const GemmP& p) {
 
 // K tiles of a launch: 64 elements, except the e4m3 ping-pong kernel's 128 (128 BYTES of a row either way).  Everything that reasons about
 // split-K -- the effective split count, whether a reduce launch follows, the tuner's "at least 4 K tiles per split" -- goes through this
-static int ktiles_for(const GemmP& p, int variant) { return (variant == 4 && p.fp8) ? (p.K + 127) / 128 : (p.K + 63) / 64; }
+static int ktiles_for(const GemmP& p, int variant) { return ((variant == 4 || variant == 6) && p.fp8) ? (p.K + 127) / 128 : (p.K + 63) / 64; }
 // the split count a launch really runs with (launch_one rounds the requested one to whole K tiles)
 static int eff_splitk(const GemmP& p, int variant, int splitk) {
   const int kt = ktiles_for(p, variant), kps = (kt + splitk - 1) / splitk;
@@ -521,8 +522,8 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
     else p.gn_chunks = gn_pieces(p, c.bn) * (p.HoWo / stats_bm(c.bm, variant));
   }
   if (p.bf16) rc = tfk_launch_igemm_bf16(p, st, c.bm, c.bn);
-  else if (p.mx && variant != 4) { tf_set_error("run_gemm: block-scaled e4m3 operands run on the ping-pong kernel only (variant %d, tile %dx%d)", variant, c.bm, c.bn); return TF_E_UNSUPPORTED; }
-  else if (p.fp8 && variant != 4) rc = tfk_launch_igemm8(p, st, c.bm, c.bn);
+  else if (p.mx && variant != 4 && variant != 6) { tf_set_error("run_gemm: block-scaled e4m3 operands run on the ping-pong kernel only (variant %d, tile %dx%d)", variant, c.bm, c.bn); return TF_E_UNSUPPORTED; }
+  else if (p.fp8 && variant != 4 && variant != 6) rc = tfk_launch_igemm8(p, st, c.bm, c.bn);
   else if (variant == 4) {
     if (!pp_ok(p, c.bn, c.bm)) { tf_set_error("run_gemm: the ping-pong kernel cannot run tile %dx%d of this launch", c.bm, c.bn); return TF_E_UNSUPPORTED; }
     rc = p.fp8 ? tfk_launch_pp8(p, st, c.bm, c.bn) : tfk_launch_pp16(p, st, c.bm, c.bn, g_pp_np);
@@ -617,6 +618,10 @@ static TunedCfg gi_default(const GemmP& p) {
 static TunedCfg mx_default(const GemmP& p) {
   static const int cand[][2] = {{192, 160}, {192, 128}, {256, 128}, {256, 160}};
   TunedCfg best = {{0, 0, 1}, 4, 0};
+  {                                                        // the patch form where it applies: 2.0-2.4 against 1.2-1.45 PFLOP/s on config 5's 3x3 convs (tools/mx_bench.py)
+    GemmP probe = p;
+    if (pp3_setup(probe, 192, 128) && (long long)(p.M / 192) * ((p.N + 127) / 128) >= 128) return {{192, 128, 1}, 6, 1};
+  }
   long long best_blocks = -1;
   for (int ci = 0; ci < 4; ++ci) {
     const int bm = cand[ci][0], bn = cand[ci][1];
@@ -812,7 +817,11 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
       if (p.gi_part && !gi_tile_ok(p, t.c.bm, t.c.bn, t.variant)) t = gi_default(p);
       // e4m3 rows: a fixed-scale launch has k_igemm8 only, a block-scaled one the ping-pong kernel only -- a row that says otherwise (an
       // older table, a user's file) falls back to the default instead of failing the forward
-      if (p.fp8 && ((t.variant == 4) != (p.mx != 0) || (p.mx && !pp_ok(p, t.c.bn, t.c.bm)))) t = fp8_default;
+      if (p.fp8) {
+        GemmP probe = p;
+        const bool blk = t.variant == 4 || t.variant == 6;
+        if (blk != (p.mx != 0) || (t.variant == 4 && !pp_ok(p, t.c.bn, t.c.bm)) || (t.variant == 6 && !pp3_setup(probe, t.c.bm, t.c.bn))) t = fp8_default;
+      }
     }
     else if (g_autotune == 2) {
       tf_set_error("run_gemm: shape M=%d N=%d K=%d C1=%d C2=%d S=%d stride=%d ups=%d act=%d flags=%d is not in the tuning table and tuning is off "

@@ -33,20 +33,29 @@
 #ifndef TF_PP3_STAMP
 #define TF_PP3_STAMP 0    // diagnostic builds (tools/pp3_stamp.py), stamps into the workspace: 1 = s_memtime of waves 0 and 4 of block 0 around the phases of the tiles of slab 1 + the clock pair; 2 = only the (s_memtime, s_memrealtime) pair around block 0's K loop
 #endif
-#ifndef TF_PP3_WB
-#define TF_PP3_WB 0       // experiment switches (tagged builds): the last WB weight pieces of a wave and (PB = 1) its patch piece are issued between the
-#define TF_PP3_PB 0       // MFMAs of the tile instead of in front of the barrier (balancing the two phases of the ping-pong)
-#endif
-template <int BN, int W>
+// (Issuing part of a tile's loads between its MFMAs instead of in front of the barrier -- balancing the two phases of the ping-pong -- measured
+// 0 ... -5 %, the more the more loads moved: profiles/r04_pp3.txt.  The loop runs at 1.83-1.94 GHz with the matrix pipe busy in ~72 % of its
+// cycles: the chip holds its clock down under this load, and what raises throughput from here is less energy per MFMA, not a tighter issue stream.)
+// F8 = OCP e4m3 operands on the block-scaled MFMA, as k_igemm_pp<F8>: a slab is 128 channels (the 128 bytes of a patch row), the fragment
+//   reads and their addresses are the fp16 kernel's, one v_mfma_scale_f32_16x16x128_f8f6f4 takes both 64-byte halves.  The E8M0 bytes of a patch row's
+//   four 32-channel blocks travel as a second, small patch (one dword per patch row, double buffered behind the weight ring): waves 0 .. 6 fetch it with
+//   one buffer_load_dword ... lds each, on tap 7 of the previous slab (the patch pieces ride on taps 0 .. PPW - 1 <= 6), and a lane reads the byte of (its
+//   patch row, block lg) with one ds_read_u8 per pixel tile at an immediate offset per tap.  Channel counts on the 128 grid; weights carry one fp32 scale
+//   per output channel, applied to the accumulators in front of the epilogue.
+template <int BN, int W, bool F8 = false>
 __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
   constexpr int BM = 192, TN = BN / 2, MJ = 3, NI = TN / 16, NS = 3, D = NS - 1;
+  constexpr int ES = F8 ? 1 : 2, SLAB = 128 / ES;          // bytes per element; channels of a slab (128 bytes of a patch row)
   constexpr int WST = BN * 128;                            // bytes of a weight ring slot
   constexpr int NWG = BN / 8, WPW = (NWG + 7) / 8, WREM = NWG % 8;
   constexpr int PW = W + 4, PROWS = (BM / W + 2) * PW, NPP = (PROWS + 7) / 8, PB = NPP * 1024;     // patch: row pitch, rows, 8-row pieces, bytes of a buffer
   constexpr int PPW = (NPP + 7) / 8;                       // patch pieces per wave at most: they ride on taps 0 .. PPW - 1 and are waited for D - 1 tiles later
   static_assert(W % 8 == 0 && BM % W == 0, "the tile is whole image rows; PW = 4 mod 8");
   static_assert(PPW - 1 + D - 1 <= 8, "a slab's patch must have landed when its first tile is read");
-  static_assert(2 * PB + NS * WST <= 163840, "LDS budget");
+  constexpr int SCB = F8 ? ((PROWS + 63) / 64) * 256 : 0;  // bytes of a scale patch: one dword per patch row, whole 64-row wave loads
+  constexpr int NSW = (PROWS + 63) / 64;                   // waves that fetch scales
+  static_assert(2 * PB + NS * WST + 2 * SCB <= 163840, "LDS budget");
+  static_assert(!F8 || (PPW <= 7 && NSW <= 8), "the scale loads ride on tap 7");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -63,7 +72,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
   else { tile_n = bid / p.ntm; tile_m = bid - tile_n * p.ntm; }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int img = m0 / p.HoWo, y0 = (m0 - img * p.HoWo) / W;
-  const int G = p.C >> 6, nt = G * 9;                      // 64-channel slabs, K tiles
+  const int G = p.C / SLAB, nt = G * 9;                    // channel slabs, K tiles
   const unsigned lds0 = lds_off(smem);
   const unsigned lds_w = lds0 + 2u * (unsigned)PB;
 
@@ -84,7 +93,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
 #pragma unroll
   for (int i = 0; i < WPW; ++i) {
     const int g = wid + 8 * i, n = n0 + 8 * g + sub;
-    gw[i] = (g < NWG && n < p.N) ? (unsigned)(n * p.K) * 2u + cs * 16u : TF_OOB;
+    gw[i] = (g < NWG && n < p.N) ? (unsigned)(n * p.K) * ES + cs * 16u : TF_OOB;
   }
   const int C1_ = p.C1, C2_ = p.C2, Cc_ = p.C;
   const unsigned long long px1 = (unsigned long long)p.x, px2 = (unsigned long long)(p.x2 ? p.x2 : p.x);
@@ -92,35 +101,62 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
   // piece `i` of this wave's share of patch(g) into buffer g & 1; returns the number of loads issued
   auto stage_patch = [&](int g, int i) -> int {
     if (wid + 8 * i >= NPP) return 0;
-    const int c = g * 64;
+    const int c = g * SLAB;
     const bool second = c >= C1_;
     const unsigned long long px = second ? px2 : px1;
     i4v rs;
     rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)px); rs[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(px >> 32) & 0xffffu));
     rs[2] = __builtin_amdgcn_readfirstlane(second ? nb2 : nb1); rs[3] = 0x00020000;
-    const int ld2 = __builtin_amdgcn_readfirstlane((second ? C2_ : C1_) * 2);
-    const int cb = __builtin_amdgcn_readfirstlane((second ? c - C1_ : c) * 2) + csp * 16;
+    const int ld2 = __builtin_amdgcn_readfirstlane((second ? C2_ : C1_) * ES);
+    const int cb = __builtin_amdgcn_readfirstlane((second ? c - C1_ : c) * ES) + csp * 16;
     dma16(rs, pp_pix[i] >= 0 ? (unsigned)(pp_pix[i] * ld2 + cb) : TF_OOB, lds0 + (unsigned)(g & 1) * (unsigned)PB + (unsigned)wid * 1024u + (unsigned)i * 8192u);
     return 1;
   };
+  // F8: the scale dwords of patch(g): lane L of wave w < NSW fetches those of patch row 64 w + L.  A source tensor holds its E8M0 bytes behind its
+  // codes (offset = the codes' byte count), C / 32 per pixel; the slab starting at channel c has its four at c / 32.
+  int sc_pix = -1;
+  if constexpr (F8) {
+    const int pr = 64 * wid + lane;
+    const int py = pr / PW, px = pr - py * PW;
+    const int y = y0 - 1 + py, x = px - 1;
+    if (pr < PROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)W) sc_pix = (img * p.H + y) * W + x;
+  }
+  auto stage_sc = [&](int g) -> int {
+    if constexpr (!F8) return 0;
+    if (wid >= NSW) return 0;
+    const int c = g * SLAB;
+    const bool second = c >= C1_;
+    const unsigned long long px = second ? px2 : px1;
+    const int s_nb = __builtin_amdgcn_readfirstlane(second ? nb2 : nb1);
+    i4v rs;
+    rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)px); rs[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(px >> 32) & 0xffffu));
+    rs[2] = s_nb + (s_nb >> 5); rs[3] = 0x00020000;
+    const int ld32 = __builtin_amdgcn_readfirstlane((second ? C2_ : C1_) >> 5), c32 = __builtin_amdgcn_readfirstlane((second ? c - C1_ : c) >> 5);
+    const unsigned off = sc_pix >= 0 ? (unsigned)s_nb + (unsigned)(sc_pix * ld32 + c32) : TF_OOB;
+    const unsigned ldsb = lds_w + (unsigned)NS * WST + (unsigned)(g & 1) * SCB + (unsigned)wid * 256u;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" :: "s"(__builtin_amdgcn_readfirstlane((int)ldsb)), "v"(off), "s"(rs) : "memory");
+    return 1;
+  };
   // the weight tile of (slab g, tap) into ring slot `slot`; returns the number of loads issued
-  auto stage_w = [&](int slot, int g, int tap, int i0 = 0, int i1 = 64) -> int {
+  auto stage_w = [&](int slot, int g, int tap) -> int {
     const unsigned base = lds_w + (unsigned)slot * WST + (unsigned)wid * 1024u;
-    const unsigned kb = (unsigned)(tap * Cc_ + g * 64) * 2u;
+    const unsigned kb = (unsigned)(tap * Cc_ + g * SLAB) * ES;
     int n = 0;
 #pragma unroll
     for (int i = 0; i < WPW; ++i)
-      if (i >= i0 && i < i1 && (WREM == 0 || i < WPW - 1 || wid < WREM)) { dma16_w(rs_w, gw[i] != TF_OOB ? gw[i] + kb : TF_OOB, base + (unsigned)i * 8192u); ++n; }
+      if (WREM == 0 || i < WPW - 1 || wid < WREM) { dma16_w(rs_w, gw[i] != TF_OOB ? gw[i] + kb : TF_OOB, base + (unsigned)i * 8192u); ++n; }
     return n;
   };
 
   // ---- fragment addressing
   const int lr = lane & 15, lg = lane >> 4;
   int ax[2][3][MJ];                                        // [k-step][dx][pixel tile]: byte address in the CURRENT patch buffer of tap (0, dx)
+  int asx[MJ];                                             // F8: byte address in the CURRENT scale patch of (tap (0, 0) of row lr of pixel tile j, block lg)
 #pragma unroll
   for (int j = 0; j < MJ; ++j) {
     const int ml = wm * (BM / 4) + j * 16 + lr;
     const int yl = ml / W;
+    asx[j] = 2 * PB + NS * WST + (yl * PW + (ml - yl * W)) * 4 + lg;
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       const int pr = yl * PW + (ml - yl * W) + dx;
@@ -136,8 +172,15 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
 #pragma unroll
     for (int j = 0; j < MJ; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
   h8 wf[2][NI], xf[2][MJ];
+  int sx[MJ];
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) sx[j] = 0x7F;
   auto read_frags = [&](int slot, int tap) {
     const int dy = tap / 3, dx = tap - 3 * dy, sw = dy & 1;      // (compile-time after unrolling)
+    if constexpr (F8) {
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) sx[j] = *(reinterpret_cast<const unsigned char*>(smem) + asx[j] + (dy * PW + dx) * 4);
+    }
 #pragma unroll
     for (int j = 0; j < MJ; ++j) {
       xf[0][j] = *reinterpret_cast<const h8*>(smem + ax[sw][dx][j] + dy * PW * 128);
@@ -149,17 +192,40 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
       wf[1][i] = *reinterpret_cast<const h8*>(smem + wo1 + (slot * WST + i * 2048));
     }
   };
-  auto mma = [&](int c0 = 0, int c1 = 64) {          // chunks [c0, c1) of the tile's 2 NI chunks of MJ MFMAs
+  auto mma = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
+    if constexpr (F8) {
+      typedef int v8i __attribute__((ext_vector_type(8)));
+      typedef int v4i __attribute__((ext_vector_type(4)));
+      v8i xv[MJ];
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+      for (int j = 0; j < MJ; ++j) {
+        v4i lo = __builtin_bit_cast(v4i, xf[0][j]), hi = __builtin_bit_cast(v4i, xf[1][j]);
+        xv[j] = (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        v4i lo = __builtin_bit_cast(v4i, wf[0][i]), hi = __builtin_bit_cast(v4i, wf[1][i]);
+        const v8i wv = (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)      // e4m3 x e4m3; weights at 2^0, activations with their block scales (block b's from lane group b)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, xv[j], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, sx[j]);
+      }
+      // (pin the results here: the intrinsic has no side effect, and without a use in this phase the compiler sinks a whole slab's MFMAs behind the
+      // last barrier of the slab and parks the fragments in scratch)
 #pragma unroll
       for (int i = 0; i < NI; ++i)
-        if (f * NI + i >= c0 && f * NI + i < c1) {
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) asm volatile("" :: "v"(acc[i][j]));
+    } else {
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[f][i], xf[f][j], acc[i][j], 0, 0, 0);
-        }
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -178,6 +244,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
   // ---- prologue: patch(0) whole, weight tiles 0 .. D - 1; tile 0's loads landed, the others in flight
 #pragma unroll
   for (int i = 0; i < PPW; ++i) stage_patch(0, i);
+  stage_sc(0);
   int nw = 0;
 #pragma unroll
   for (int s_ = 0; s_ < D; ++s_) nw = stage_w(s_, 0, s_);  // (nt >= 9 > D; every tile of a wave carries the same number of weight loads)
@@ -205,11 +272,10 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
       PP3_STAMP(0);
       read_frags(tap % NS, tap);                           // (tile t = 9 g + tap lives in slot t % 3 = tap % 3)
       int nl = 0;                                          // loads this wave issues during this tile: the newest ones, they stay in flight
-      constexpr int WA = WPW - TF_PP3_WB;                  // weight pieces issued in front of the barrier
-      const int wg = tap + D < 9 ? g : g + 1, wt = tap + D < 9 ? tap + D : tap + D - 9;
-      const bool wmore = tap + D < 9 || g + 1 < G, pmore = tap < PPW && g + 1 < G;
-      if (wmore) nl += stage_w((tap + D) % NS, wg, wt, 0, WA);
-      if (!TF_PP3_PB && pmore) nl += stage_patch(g + 1, tap);
+      if (tap + D < 9) nl += stage_w((tap + D) % NS, g, tap + D);
+      else if (g + 1 < G) nl += stage_w((tap + D) % NS, g + 1, tap + D - 9);
+      if (tap < PPW && g + 1 < G) nl += stage_patch(g + 1, tap);
+      if (F8 && tap == 7 && g + 1 < G) nl += stage_sc(g + 1);
       const bool next = t + 1 < nt;
       PP3_STAMP(1);
       if (next && grp == 1) wait_vm_dyn(nl);               // tile t + 1 (and every patch piece of an earlier tile) landed
@@ -217,15 +283,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
       PP3_STAMP(2);
       barrier();
       PP3_STAMP(3);
-      if (TF_PP3_WB || TF_PP3_PB) {
-        mma(0, NI / 2);
-        if (TF_PP3_WB && wmore) nl += stage_w((tap + D) % NS, wg, wt, WA, WA + (TF_PP3_WB + 1) / 2);
-        mma(NI / 2, NI);
-        if (TF_PP3_WB > 1 && wmore) nl += stage_w((tap + D) % NS, wg, wt, WA + (TF_PP3_WB + 1) / 2, WPW);
-        mma(NI, NI + NI / 2);
-        if (TF_PP3_PB && pmore) nl += stage_patch(g + 1, tap);
-        mma(NI + NI / 2, 2 * NI);
-      } else mma();
+      mma();
       PP3_STAMP(4);
       if (next && grp == 0) wait_vm_dyn(nl);
       PP3_STAMP(5);
@@ -239,6 +297,10 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
       for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
         for (int j = 0; j < MJ; ++j) ax[f][dx][j] += flip;
+    if constexpr (F8) {
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) asx[j] += (g & 1) ? -SCB : SCB;
+    }
   }
 #if TF_PP3_STAMP
   if (stamping && wid == 0 && lane == 0) {
@@ -249,6 +311,19 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
 #endif
   if (grp == 0) barrier();                                 // the first half waits for the second: every wave is done with the ring and the patches
 
+  if constexpr (F8) {                                      // per-output-channel weight scales (this lane's 4 consecutive channels of every n-tile)
+    if (p.wscale) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int n = n0 + wn * TN + i * 16 + lg * 4;
+        f4 w = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (n + e < p.N) w[e] = p.wscale[n + e];
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) acc[i][j] *= w;
+      }
+    }
+  }
   // ---- epilogue: two passes of 96 rows through the shared scratch (as k_igemm_pp)
   f4 csum[NI];
 #pragma unroll

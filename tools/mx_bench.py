@@ -20,11 +20,11 @@ def conv(n, hw, cin, cout, k, label):
     M, K = n * hw * hw, k * k * cin
     res = []
     with T.use_stream(st):
-        for bm, bn in ((192, 160), (192, 128), (256, 128), (256, 160)):
-            lib.tf_gemm_force_config(bm, bn, 1); lib.tf_gemm_debug(512)
+        for bm, bn, flags in ((192, 160, 512), (192, 128, 512), (256, 128, 512), (256, 160, 512), (192, 128, 2048)):      # 2048: the patch form, k_igemm_pp3<F8>
+            lib.tf_gemm_force_config(bm, bn, 1); lib.tf_gemm_debug(flags)
             try:
                 us = time_call(lambda: fp8.conv2d_mx(x, w8, sc, b, (cout, cin, k, k), [k // 2, k // 2]))
-                res.append((us, bm, bn))
+                res.append((us, "PP3-" + str(bm) if flags == 2048 else bm, bn))
             except RuntimeError:
                 pass
             finally:
@@ -39,4 +39,6 @@ if __name__ == "__main__":
     conv(8, 96, 640, 320, 3, "conv3x3 640->320@96")
     conv(8, 48, 640, 640, 3, "conv3x3 640@48")
     conv(8, 24, 1280, 1280, 3, "conv3x3 1280@24")
+    conv(8, 48, 1280, 640, 3, "conv3x3 1280->640@48")
+    conv(8, 24, 2560, 1280, 3, "conv3x3 2560->1280@24")
     conv(8, 48, 640, 5120, 1, "lin 640->5120 @18432")
