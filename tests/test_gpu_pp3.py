@@ -41,6 +41,22 @@ def test_pp3_conv_exact_integers(tf, n, c1, c2, hw, cout):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,c,hs,cout", [(2, 64, 12, 64), (1, 192, 24, 136), (1, 128, 48, 320), (3, 128, 12, 200)])
+def test_pp3_conv_with_folded_upsampling_exact_integers(tf, n, c, hs, cout):
+    """Upsample (vision/unet.py:79-86 of the reference: nearest 2x, then conv 3x3): the patch gather reads source pixel (y >> 1, x >> 1); output rows of
+    24 / 48 / 96 pixels from 12 / 24 / 48-pixel sources, image borders of the UP-SAMPLED image."""
+    from tinyfusers_amd.vision.conv2d import Conv2d
+    rs = np.random.RandomState(n * 100 + c + hs + cout)
+    x = rs.randint(-1, 2, (n, c, hs, hs)).astype(np.float32); wt = rs.randint(-1, 2, (cout, c, 3, 3)).astype(np.float32)
+    b = rs.randint(-4, 5, (cout,)).astype(np.float32)
+    m = Conv2d(c, cout, [3, 3], padding=[1, 1], init=False); m.weight = dev(tf, wt); m.bias = dev(tf, b)
+    with forced(160, 1, 2048, 192):
+        got = m(dev(tf, x), upsample=True).numpy()
+    want = conv_nchw(x.repeat(2, axis=2).repeat(2, axis=3), wt) + b[None, :, None, None]
+    assert np.abs(want).max() < 2048
+    np.testing.assert_array_equal(got, want)
+
+
 def test_pp3_refuses_what_it_cannot_run(tf):
     """32-pixel rows do not divide the 192-row tile, stride 2 and 1x1 are other kernels' work: an explicit request must fail, not run something else."""
     from tinyfusers_amd.vision.conv2d import Conv2d

@@ -450,12 +450,12 @@ static int stats_bm(int bm, int variant) { return (variant == 4 || variant == 6)
 // the 64 grid, a 192-row tile that is a whole number of image rows inside one image (W | 192, 192 | H W: the 96 / 48 / 24-pixel levels of
 // BASELINE config 5, the row length a template parameter), no extra 1x1 segment, no split-K; two patch buffers + 3 or 4 weight slots in LDS
 static bool pp3_setup(GemmP& p, int bm, int bn) {
-  if (bm != 192 || bn != (p.W == 96 ? 160 : 128)) return false;                                       // the instantiated (row length, tile width) pairs
+  if (bm != 192 || bn != (p.Wo == 96 ? 160 : 128)) return false;                                      // the instantiated (output row length, tile width) pairs
   if (p.bf16 || p.gi_part || p.ln_colsum || p.act || p.out8 || p.out32 || gemm_generic(p)) return false;
-  if (p.fp8 && (!p.mx || p.W == 96 || (p.C1 % 128) || (p.C2 % 128))) return false;                  // e4m3: block-scaled, 128-channel slabs, the 48 / 24-pixel instances
-  if (p.S != 3 || p.Kc != 9 * p.C || p.K != p.Kc || p.stride != 1 || p.pad != 1 || p.ups || p.C3 || p.C4) return false;
-  if ((p.C1 % 64) || (p.C2 % 64) || p.H != p.Ho || p.W != p.Wo) return false;
-  if ((p.W != 96 && p.W != 48 && p.W != 24) || (p.HoWo % 192) || (p.M % p.HoWo)) return false;      // the instantiated row lengths; a tile = whole rows of one image
+  if (p.fp8 && (!p.mx || p.Wo == 96 || (p.C1 % 128) || (p.C2 % 128))) return false;                 // e4m3: block-scaled, 128-channel slabs, the 48 / 24-pixel instances
+  if (p.S != 3 || p.Kc != 9 * p.C || p.K != p.Kc || p.stride != 1 || p.pad != 1 || p.C3 || p.C4) return false;
+  if ((p.C1 % 64) || (p.C2 % 64) || (p.H << p.ups) != p.Ho || (p.W << p.ups) != p.Wo) return false;   // (nearest-2x up-sampling folds into the patch gather)
+  if ((p.Wo != 96 && p.Wo != 48 && p.Wo != 24) || (p.HoWo % 192) || (p.M % p.HoWo)) return false;   // the instantiated row lengths; a tile = whole rows of one image
   return true;
 }
 // k_gemm_c4 (variant 5): the persistent short-K kernel -- linears / 1x1 stride-1 convolutions of fp16 operands whose channel counts sit on
@@ -860,7 +860,7 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
   if (wide == 6) {
     // the tile is the kernel's own: a forced tile keeps its width where the kernel has it; a table row this launch cannot take falls back
     GemmP q = p;
-    const int bn6 = p.W == 96 ? 160 : 128;
+    const int bn6 = p.Wo == 96 ? 160 : 128;
     if (pp3_setup(q, 192, bn6)) t.c = {192, bn6, 1};
     else if (g_force_wide == 6) { tf_set_error("run_gemm: the patch form of the ping-pong kernel cannot run this launch"); return TF_E_UNSUPPORTED; }
     else { wide = 0; if (t.c.bm >= 192) t.c = choose_tiles(p.M, p.N, p.K, p.act, workspace != nullptr); }

@@ -22,14 +22,14 @@ static int launch_pp3(const GemmP& p, hipStream_t st) {
 // 640 / 1280 channels on 48 / 24-pixel rows); pp3_setup (csrc/gemm.hip) admits exactly these
 int tfk_launch_pp3(const GemmP& p, hipStream_t st, int bn) {
   if (p.fp8) {                                             // block-scaled e4m3 (channel counts on the 128 grid: the 640 / 1280-channel levels)
-    if (p.mx && bn == 128 && p.W == 48) return launch_pp3<128, 48, true>(p, st);
-    if (p.mx && bn == 128 && p.W == 24) return launch_pp3<128, 24, true>(p, st);
-    tf_set_error("k_igemm_pp3: no e4m3 instance for a %d-wide tile on %d-pixel rows (mx=%d)", bn, p.W, p.mx);
+    if (p.mx && bn == 128 && p.Wo == 48) return launch_pp3<128, 48, true>(p, st);
+    if (p.mx && bn == 128 && p.Wo == 24) return launch_pp3<128, 24, true>(p, st);
+    tf_set_error("k_igemm_pp3: no e4m3 instance for a %d-wide tile on %d-pixel rows (mx=%d)", bn, p.Wo, p.mx);
     return TF_E_UNSUPPORTED;
   }
-  if (bn == 160 && p.W == 96) return launch_pp3<160, 96>(p, st);
-  if (bn == 128 && p.W == 48) return launch_pp3<128, 48>(p, st);
-  if (bn == 128 && p.W == 24) return launch_pp3<128, 24>(p, st);
-  tf_set_error("k_igemm_pp3: no instance for a %d-wide tile on %d-pixel rows", bn, p.W);
+  if (bn == 160 && p.Wo == 96) return launch_pp3<160, 96>(p, st);
+  if (bn == 128 && p.Wo == 48) return launch_pp3<128, 48>(p, st);
+  if (bn == 128 && p.Wo == 24) return launch_pp3<128, 24>(p, st);
+  tf_set_error("k_igemm_pp3: no instance for a %d-wide tile on %d-pixel rows", bn, p.Wo);
   return TF_E_UNSUPPORTED;
 }

@@ -21,8 +21,9 @@
 //   per wave and tap (the buffer was last read for slab g - 2: behind every barrier those tiles are issued after); slab 0's patch is issued whole in the
 //   prologue.  Patch row pr = py PW + px holds pixel (y0 - 1 + py, px - 1) of the tile's image (y0 = its first image row; px > W + 1 is padding);
 //   output row m of the tile (image row yl = m / W, column x) reads tap (dy, dx) at patch row (yl + dy) PW + x + dx.
-// Channel counts on the 64 grid (the concat pair: a slab lies in one source), no extra 1x1 segment, no split-K, fp16.  W is a template parameter:
-// every patch offset is then an instruction immediate.
+// Channel counts on the 64 grid (the concat pair: a slab lies in one source), no extra 1x1 segment, no split-K.  W -- the OUTPUT row length -- is a
+// template parameter: every patch offset is then an instruction immediate.  The nearest-2x up-sampling of the Upsample convs (vision/unet.py:79-86 of the
+// reference) folds into the patch gather: patch pixel (y, x) comes from source pixel (y >> 1, x >> 1), fetched once per slab instead of once per tap and 2 x 2 copy.
 // The patch image's swizzle: a tap reads 16 consecutive patch rows starting ANYWHERE, so the XOR term of the aligned tiles ((row >> 1) & 7) would put two
 // rows of a ds_read_b128 lane group on the same banks for every shift but 0.  chunk ^ (row & 6) is conflict-free for every start row: the hardware
 // serves lanes {0-3, 12-15} of one k-chunk together with lanes {4-11} of the next chunk, i.e. per row parity four rows of one cyclic window of (row >> 1)
@@ -76,6 +77,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
   const unsigned lds0 = lds_off(smem);
   const unsigned lds_w = lds0 + 2u * (unsigned)PB;
 
+  const int ups = p.ups;                                   // nearest-2x up-sampling folded into the gather: the patch holds the UP-SAMPLED pixels (p.H x p.W is the source)
   // ---- staging geometry.  Patch piece q = wid + 8 i covers patch rows 8 q .. 8 q + 7; lane -> row 8 q + sub, source chunk swizzled
   const int sub = lane >> 3;
   const int cs = (lane & 7) ^ ((4 * (wid & 1) + (sub >> 1)) & 7);      // weight rows: the aligned tiles' swizzle
@@ -86,7 +88,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
     const int pr = 8 * (wid + 8 * i) + sub;
     const int py = pr / PW, px = pr - py * PW;
     const int y = y0 - 1 + py, x = px - 1;
-    pp_pix[i] = (pr < PROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)W) ? (img * p.H + y) * W + x : -1;
+    pp_pix[i] = (pr < PROWS && (unsigned)y < (unsigned)p.Ho && (unsigned)x < (unsigned)W) ? (img * p.H + (y >> ups)) * p.W + (x >> ups) : -1;
   }
   const i4v rs_w = raw_rsrc(p.w, p.w_bytes);
   unsigned gw[WPW];
@@ -119,7 +121,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
     const int pr = 64 * wid + lane;
     const int py = pr / PW, px = pr - py * PW;
     const int y = y0 - 1 + py, x = px - 1;
-    if (pr < PROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)W) sc_pix = (img * p.H + y) * W + x;
+    if (pr < PROWS && (unsigned)y < (unsigned)p.Ho && (unsigned)x < (unsigned)W) sc_pix = (img * p.H + (y >> ups)) * p.W + (x >> ups);
   }
   auto stage_sc = [&](int g) -> int {
     if constexpr (!F8) return 0;
