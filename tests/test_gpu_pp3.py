@@ -57,6 +57,31 @@ def test_pp3_conv_with_folded_upsampling_exact_integers(tf, n, c, hs, cout):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,c1,c2,hw,cout,c3,c4", [(2, 64, 0, 24, 128, 64, 0), (1, 192, 0, 48, 200, 192, 0), (1, 64, 0, 96, 320, 128, 64), (2, 128, 0, 24, 136, 64, 320),
+                                                   (1, 192, 0, 48, 64, 448, 0)])
+def test_pp3_conv_with_folded_skip_projection_exact_integers(tf, n, c1, c2, hw, cout, c3, c4):
+    """ResBlock's conv2 with the 1x1 skip projection folded in (vision/resnet.py:23-31 of the reference: h + skip(x)): 1 ... 7 extra K tiles behind the nine
+    taps (the three activation slots over the patch buffers, both parities of the slab count, the concat pair as skip source; the conv's own input
+    is one tensor there: vision/conv2d.py's fold takes no concat pair)."""
+    from tinyfusers_amd.vision.conv2d import Conv2d
+    rs = np.random.RandomState(n + c1 + c2 + hw + cout + c3 + c4)
+    cin = c1 + c2
+    ri = lambda *sh: rs.randint(-1, 2, sh).astype(np.float32)
+    xa, xb = ri(n, c1, hw, hw), (ri(n, c2, hw, hw) if c2 else None)
+    x3, x4 = ri(n, c3, hw, hw), (ri(n, c4, hw, hw) if c4 else None)
+    wt, ws = ri(cout, cin, 3, 3), ri(cout, c3 + c4, 1, 1)
+    b, bs = rs.randint(-4, 5, (cout,)).astype(np.float32), rs.randint(-4, 5, (cout,)).astype(np.float32)
+    m = Conv2d(cin, cout, [3, 3], padding=[1, 1], init=False); m.weight = dev(tf, wt); m.bias = dev(tf, b)
+    proj = Conv2d(c3 + c4, cout, [1, 1], init=False); proj.weight = dev(tf, ws); proj.bias = dev(tf, bs)
+    x = (dev(tf, xa), dev(tf, xb)) if c2 else dev(tf, xa)
+    xs = (dev(tf, x3), dev(tf, x4)) if c4 else dev(tf, x3)
+    with forced(160, 1, 2048, 192):
+        got = m(x, extra=(proj, xs)).numpy()
+    want = conv_nchw(np.concatenate((xa, xb), 1) if c2 else xa, wt) + conv_nchw(np.concatenate((x3, x4), 1) if c4 else x3, ws, pad=0) + (b + bs)[None, :, None, None]
+    assert np.abs(want).max() < 2048
+    np.testing.assert_array_equal(got, want)
+
+
 def test_pp3_refuses_what_it_cannot_run(tf):
     """32-pixel rows do not divide the 192-row tile, stride 2 and 1x1 are other kernels' work: an explicit request must fail, not run something else."""
     from tinyfusers_amd.vision.conv2d import Conv2d

@@ -448,12 +448,14 @@ static int g_pp_np = 0;                                    // test / tuning hook
 static int stats_bm(int bm, int variant) { return (variant == 4 || variant == 6) ? bm / 2 : bm; }
 // k_igemm_pp3 (variant 6): the PATCH form of the ping-pong kernel -- 3x3 / stride 1 / pad 1 convolutions of fp16 operands, every channel count on
 // the 64 grid, a 192-row tile that is a whole number of image rows inside one image (W | 192, 192 | H W: the 96 / 48 / 24-pixel levels of
-// BASELINE config 5, the row length a template parameter), no extra 1x1 segment, no split-K; two patch buffers + 3 or 4 weight slots in LDS
+// BASELINE config 5, the OUTPUT row length a template parameter; nearest-2x up-sampling folds into the patch gather), no split-K; fp16, or block-scaled
+// e4m3 on the 128-channel grid; two patch buffers + three weight slots in LDS
 static bool pp3_setup(GemmP& p, int bm, int bn) {
   if (bm != 192 || bn != (p.Wo == 96 ? 160 : 128)) return false;                                      // the instantiated (output row length, tile width) pairs
   if (p.bf16 || p.gi_part || p.ln_colsum || p.act || p.out8 || p.out32 || gemm_generic(p)) return false;
   if (p.fp8 && (!p.mx || p.Wo == 96 || (p.C1 % 128) || (p.C2 % 128))) return false;                 // e4m3: block-scaled, 128-channel slabs, the 48 / 24-pixel instances
-  if (p.S != 3 || p.Kc != 9 * p.C || p.K != p.Kc || p.stride != 1 || p.pad != 1 || p.C3 || p.C4) return false;
+  if (p.S != 3 || p.Kc != 9 * p.C || p.K != p.Kc + p.C3 + p.C4 || p.stride != 1 || p.pad != 1) return false;
+  if ((p.C3 || p.C4) && (p.fp8 || p.ups || (p.C3 % 64) || (p.C4 % 64))) return false;               // the folded 1x1 skip projection: fp16, its sources at output resolution
   if ((p.C1 % 64) || (p.C2 % 64) || (p.H << p.ups) != p.Ho || (p.W << p.ups) != p.Wo) return false;   // (nearest-2x up-sampling folds into the patch gather)
   if ((p.Wo != 96 && p.Wo != 48 && p.Wo != 24) || (p.HoWo % 192) || (p.M % p.HoWo)) return false;   // the instantiated row lengths; a tile = whole rows of one image
   return true;

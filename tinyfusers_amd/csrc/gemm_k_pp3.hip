@@ -6,7 +6,7 @@ static int launch_pp3(const GemmP& p, hipStream_t st) {
   constexpr int PROWS = (192 / W + 2) * (W + 4), PB = ((PROWS + 7) / 8) * 1024;
   constexpr int NS = 3;
   constexpr int scratch = 4 * 48 * (BN / 2 + 4) * 4, tail = 96 * 8 + 4 * BN * 8 + 3 * BN * 4;      // the epilogue's share (as launch_pp2 with BM = 192)
-  constexpr int ring = 2 * PB + NS * BN * 128 + (F8 ? 2 * ((PROWS + 63) / 64) * 256 : 0);
+  constexpr int ring = 2 * PB + NS * BN * 128 + (F8 ? 2 * ((PROWS + 63) / 64) * 256 : (2 * 192 * 128 <= PB ? 0 : 192 * 128));   // (+ the scale patches / slot 1 of the extra segment)
   constexpr int smem = ring > scratch + tail ? ring : scratch + tail;
   static_assert(smem <= 163840, "LDS budget");
   static bool attr_set = false;

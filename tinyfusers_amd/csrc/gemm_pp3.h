@@ -21,7 +21,10 @@
 //   per wave and tap (the buffer was last read for slab g - 2: behind every barrier those tiles are issued after); slab 0's patch is issued whole in the
 //   prologue.  Patch row pr = py PW + px holds pixel (y0 - 1 + py, px - 1) of the tile's image (y0 = its first image row; px > W + 1 is padding);
 //   output row m of the tile (image row yl = m / W, column x) reads tap (dy, dx) at patch row (yl + dy) PW + x + dx.
-// Channel counts on the 64 grid (the concat pair: a slab lies in one source), no extra 1x1 segment, no split-K.  W -- the OUTPUT row length -- is a
+// Channel counts on the 64 grid (the concat pair: a slab lies in one source), no split-K.  The folded 1x1 skip projection of a ResBlock (extra K
+// columns behind the nine taps, their activations the output pixels of x3 | x4: vision/resnet.py:23-31 of the reference) follows as one K tile per
+// 64-channel slab in k_igemm_pp's form -- 192 activation rows per tile through a three-slot ring of its own, laid over the patch buffers (the one the
+// last slab does not read holds slots 0 and 1 -- slot 1 in the spare LDS behind the weight ring where a buffer is too small for two -- the other one slot 2).  W -- the OUTPUT row length -- is a
 // template parameter: every patch offset is then an instruction immediate.  The nearest-2x up-sampling of the Upsample convs (vision/unet.py:79-86 of the
 // reference) folds into the patch gather: patch pixel (y, x) comes from source pixel (y >> 1, x >> 1), fetched once per slab instead of once per tap and 2 x 2 copy.
 // The patch image's swizzle: a tap reads 16 consecutive patch rows starting ANYWHERE, so the XOR term of the aligned tiles ((row >> 1) & 7) would put two
@@ -57,6 +60,10 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
   constexpr int NSW = (PROWS + 63) / 64;                   // waves that fetch scales
   static_assert(2 * PB + NS * WST + 2 * SCB <= 163840, "LDS budget");
   static_assert(!F8 || (PPW <= 7 && NSW <= 8), "the scale loads ride on tap 7");
+  constexpr int AST = BM * 128;                            // bytes of an activation tile of the extra 1x1 segment
+  constexpr int XS1 = 2 * AST <= PB ? AST : -1;            // its slot 1: behind slot 0 in the free patch buffer, or (-1) in the spare LDS behind the weight ring
+  static_assert(F8 || XS1 > 0 || 2 * PB + NS * WST + AST <= 163840, "LDS budget of the extra segment");
+  static_assert(PPW <= 7, "taps 7 and 8 of the last slab carry the first two extra activation tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -73,7 +80,8 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
   else { tile_n = bid / p.ntm; tile_m = bid - tile_n * p.ntm; }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int img = m0 / p.HoWo, y0 = (m0 - img * p.HoWo) / W;
-  const int G = p.C / SLAB, nt = G * 9;                    // channel slabs, K tiles
+  const int G = p.C / SLAB, nt = G * 9;                    // channel slabs, K tiles of the nine taps
+  const int GE = F8 ? 0 : (p.C3 + p.C4) >> 6;              // K tiles of the extra 1x1 segment
   const unsigned lds0 = lds_off(smem);
   const unsigned lds_w = lds0 + 2u * (unsigned)PB;
 
@@ -139,15 +147,32 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" :: "s"(__builtin_amdgcn_readfirstlane((int)ldsb)), "v"(off), "s"(rs) : "memory");
     return 1;
   };
-  // the weight tile of (slab g, tap) into ring slot `slot`; returns the number of loads issued
-  auto stage_w = [&](int slot, int g, int tap) -> int {
+  // the weight tile at byte offset kb of every row into ring slot `slot`; returns the number of loads issued
+  auto stage_wk = [&](int slot, unsigned kb) -> int {
     const unsigned base = lds_w + (unsigned)slot * WST + (unsigned)wid * 1024u;
-    const unsigned kb = (unsigned)(tap * Cc_ + g * SLAB) * ES;
     int n = 0;
 #pragma unroll
     for (int i = 0; i < WPW; ++i)
       if (WREM == 0 || i < WPW - 1 || wid < WREM) { dma16_w(rs_w, gw[i] != TF_OOB ? gw[i] + kb : TF_OOB, base + (unsigned)i * 8192u); ++n; }
     return n;
+  };
+  auto stage_w = [&](int slot, int g, int tap) -> int { return stage_wk(slot, (unsigned)(tap * Cc_ + g * SLAB) * ES); };      // (slab g, tap)
+  // extra segment: LDS offset of activation slot e % 3, and the activation tile of its 64-channel slab e (3 pieces per wave)
+  const int xb_free = (G & 1) * PB;                        // the patch buffer the last slab does not read
+  auto xslot = [&](int e) -> int { const int r = e % 3; return r == 0 ? xb_free : r == 1 ? (XS1 > 0 ? xb_free + AST : 2 * PB + NS * WST) : PB - xb_free; };
+  auto stage_x = [&](int e) -> int {
+    const int c = e * 64, C3_ = p.C3;
+    const bool second = c >= C3_;
+    const unsigned long long px = (unsigned long long)(second ? p.x4 : p.x3);
+    i4v rs;
+    rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)px); rs[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(px >> 32) & 0xffffu));
+    rs[2] = __builtin_amdgcn_readfirstlane((int)(second ? p.x4_bytes : p.x3_bytes)); rs[3] = 0x00020000;
+    const int ld2 = __builtin_amdgcn_readfirstlane((second ? p.C4 : C3_) * 2);
+    const int cb = __builtin_amdgcn_readfirstlane((second ? c - C3_ : c) * 2) + csp * 16;       // (rows 8 q + sub: the patch rows' swizzle)
+    const unsigned base = lds0 + (unsigned)xslot(e) + (unsigned)wid * 1024u;
+#pragma unroll
+    for (int i = 0; i < BM / 64; ++i) dma16(rs, (unsigned)((m0 + 8 * (wid + 8 * i) + sub) * ld2 + cb), base + (unsigned)i * 8192u);
+    return BM / 64;
   };
 
   // ---- fragment addressing
@@ -192,6 +217,21 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
     for (int i = 0; i < NI; ++i) {
       wf[0][i] = *reinterpret_cast<const h8*>(smem + wo0 + (slot * WST + i * 2048));
       wf[1][i] = *reinterpret_cast<const h8*>(smem + wo1 + (slot * WST + i * 2048));
+    }
+  };
+  auto read_frags_x = [&](int slot, int abase) {          // a tile of the extra segment: rows of the activation slot at abase, weight ring slot `slot` (run-time)
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+      const int r = wm * (BM / 4) + j * 16 + lr;
+      const int a = abase + r * 128 + ((lg ^ (r & 6)) << 4);
+      xf[0][j] = *reinterpret_cast<const h8*>(smem + a);
+      xf[1][j] = *reinterpret_cast<const h8*>(smem + (a ^ 64));
+    }
+    const char* wb = smem + slot * WST;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      wf[0][i] = *reinterpret_cast<const h8*>(wb + wo0 + i * 2048);
+      wf[1][i] = *reinterpret_cast<const h8*>(wb + wo1 + i * 2048);
     }
   };
   auto mma = [&]() {
@@ -276,9 +316,10 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
       int nl = 0;                                          // loads this wave issues during this tile: the newest ones, they stay in flight
       if (tap + D < 9) nl += stage_w((tap + D) % NS, g, tap + D);
       else if (g + 1 < G) nl += stage_w((tap + D) % NS, g + 1, tap + D - 9);
+      else if (tap + D - 9 < GE) { nl += stage_wk((tap + D) % NS, (unsigned)(9 * Cc_ + (tap + D - 9) * 64) * 2u); nl += stage_x(tap + D - 9); }   // the first tiles of the extra segment
       if (tap < PPW && g + 1 < G) nl += stage_patch(g + 1, tap);
       if (F8 && tap == 7 && g + 1 < G) nl += stage_sc(g + 1);
-      const bool next = t + 1 < nt;
+      const bool next = t + 1 < nt + GE;
       PP3_STAMP(1);
       if (next && grp == 1) wait_vm_dyn(nl);               // tile t + 1 (and every patch piece of an earlier tile) landed
       wait_lds_reads();
@@ -311,6 +352,19 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
     stamps[58] = a_; stamps[59] = b_;
   }
 #endif
+  // ---- the extra 1x1 segment: tile 9 G + e in weight slot e % 3 (9 G is a multiple of 3) and activation slot e % 3
+  for (int e = 0; e < GE; ++e) {
+    read_frags_x(e % NS, xslot(e));
+    int nl = 0;
+    if (e + D < GE) { nl += stage_wk((e + D) % NS, (unsigned)(9 * Cc_ + (e + D) * 64) * 2u); nl += stage_x(e + D); }
+    const bool next = e + 1 < GE;
+    if (next && grp == 1) wait_vm_dyn(nl);
+    wait_lds_reads();
+    barrier();
+    mma();
+    if (next && grp == 0) wait_vm_dyn(nl);
+    barrier();
+  }
   if (grp == 0) barrier();                                 // the first half waits for the second: every wave is done with the ring and the patches
 
   if constexpr (F8) {                                      // per-output-channel weight scales (this lane's 4 consecutive channels of every n-tile)
