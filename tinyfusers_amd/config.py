@@ -43,6 +43,10 @@ concat_stats = _flag("TF_CONCAT_STATS", True)
 # GroupNorm (+ SiLU) in front of a convolution applied inside the conv launch (tf_conv2d_gn_f16): the loader waves normalise the
 # activation pieces in LDS.  False = a GroupNorm-apply launch in front of every such conv (the unfused reference structure).
 fuse_group_norm = _flag("TF_FUSE_GROUP_NORM", True)
+# ... up to this many input elements (rows x channels).  The fused form normalises a block's activation rows once per n-tile, so its extra work grows
+# with rows x channels x n-tiles while the launch it saves is a constant 8.5 us: a win at batch 1 (BASELINE config 2: 0.65-2.6 M elements per proj_in),
+# a loss on config 5's shape (5.9-23.6 M: 73 against 26 + 6 us at 4608 x 1280, the step 0.37 ms slower with it: profiles/r04_ab.txt).
+fuse_group_norm_max_elems = int(os.environ.get("TF_FUSE_GROUP_NORM_MAX_ELEMS", str(4 << 20)))
 # ... also for the 3x3 convolutions of the ResBlocks (patch kernel).  Correct and covered by the GPU tests, but MEASURED SLOWER on MI355X
 # (profiles/r02_gn_in_conv.txt): every block normalises its whole input patch for all its n-tiles (4-8x the elements k_gn_apply
 # touches) on loader waves whose LDS-DMA issue is the kernel's critical path: +12...20 us per conv against the 8.5 us launch saved.

@@ -1004,6 +1004,7 @@ int tf_gemm_tune_load(const char* path) {
     if (act == 1 && (bn % 64) != 0) ok = false;
     if ((act == 1 || ln || (k[9] & 256)) && sk > 1) ok = false;
     if (wide == 5) ok = bm == 128 && bn == 128 && sk == 1 && !f8;
+    if (wide == 6) ok = bm == 192 && (bn == 128 || bn == 160) && sk == 1 && k[5] == 3 && k[6] == 1 && act == 0 && !ln && (!f8 || (k[9] & 512));   // the patch form: 3x3 / stride 1; e4m3 only block-scaled
     if (ok) g_tuned[k] = {{bm, bn, sk}, wide < 0 || wide > 6 ? 0 : wide, order != 0 ? 1 : 0};
   }
   fclose(f);

@@ -26,6 +26,8 @@ def _gn_in_args(x, x2, norm, k, r, s, stride, pad, up, c3, c4):
         return None
     n, c1, h, wd = x.shape
     c2 = x2.shape[1] if x2 is not None else 0
+    if n * h * wd * (c1 + c2) > config.fuse_group_norm_max_elems:      # (large inputs: the apply launch is cheaper than normalising per n-tile)
+        return None
     G = norm.num_groups
     if x2 is None:
         if x.gn[2] != G:
