@@ -39,6 +39,10 @@ fold_proj_out = _flag("TF_FOLD_PROJ_OUT", True)
 # GroupNorm over an equal-split channel concat (output path of the UNet) from the 32-group partials of the two producers
 # (pairs of groups merge) instead of a statistics pass over the concat.
 concat_stats = _flag("TF_CONCAT_STATS", True)
+# ... for tensors up to this many elements: the producers then carry a statistics epilogue (and cannot run on the persistent short-K kernel, which has none),
+# which pays at batch 1 (a statistics launch saved per concat) and costs 0.17 ms per step on config 5's shape, where the statistics pass over a concat is
+# a 20-us HBM-bound launch (profiles/r04_ab.txt)
+concat_stats_max_elems = int(os.environ.get("TF_CONCAT_STATS_MAX_ELEMS", str(4 << 20)))
 
 # GroupNorm (+ SiLU) in front of a convolution applied inside the conv launch (tf_conv2d_gn_f16): the loader waves normalise the
 # activation pieces in LDS.  False = a GroupNorm-apply launch in front of every such conv (the unfused reference structure).

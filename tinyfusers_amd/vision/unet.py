@@ -238,7 +238,7 @@ class UNetModel:
             if not joined and isinstance(bb, SpatialTransformer):
                 br.join(); joined = True            # first consumer of kv_all
             # tensors saved for (or entering) the output path's concat carry 32-group statistics when the concat is an equal split
-            want = config.concat_stats and (i in ends or nxt is None)
+            want = config.concat_stats and (i in ends or nxt is None) and x.size <= config.concat_stats_max_elems
             x = run(x, bb, nxt, force_gn=32 if want else 0)
             if i in ends:
                 saved_inputs.append(x)
@@ -253,7 +253,7 @@ class UNetModel:
                 # the output enters the next concat: emit its statistics in sub-groups as wide as the 32 groups of the saved partner
                 # (32 sub-groups for an equal split, 64 for the 2:1 splits), so that the concat's GroupNorm is apply-only
                 fg = 0
-                if config.concat_stats and nxt is None and saved_inputs:
+                if config.concat_stats and nxt is None and saved_inputs and saved_inputs[-1].size <= config.concat_stats_max_elems:
                     c2 = saved_inputs[-1].shape[1]
                     sub = c2 // 32
                     if c2 % 32 == 0 and sub >= 4 and cout % sub == 0 and ((cout + c2) // 32) % sub == 0 and cout // sub <= 256:
