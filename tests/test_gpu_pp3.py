@@ -18,7 +18,7 @@ def conv_nchw(x, w, pad=1):
 
 
 @pytest.mark.parametrize("n,c1,c2,hw,cout", [(1, 64, 0, 24, 64), (2, 64, 0, 24, 200), (3, 128, 64, 24, 320), (2, 64, 64, 48, 136), (1, 192, 0, 96, 160), (2, 320, 0, 48, 320),
-                                             (1, 64, 64, 96, 200), (1, 128, 0, 48, 64), (2, 256, 64, 24, 136)])
+                                             (1, 64, 64, 96, 200), (1, 128, 0, 48, 64), (2, 256, 64, 24, 136), (1, 320, 0, 96, 4), (2, 64, 0, 48, 4)])     # (4 channels: conv_out, unet.py:49)
 def test_pp3_conv_exact_integers(tf, n, c1, c2, hw, cout):
     """1 ... 5 channel slabs (prologue-only patch, the double buffer's both parities), image borders on every side of a tile, ragged channel tiles,
     the concat pair, several images; bias + time embedding + residual in the shared epilogue.  Integers small enough that every partial sum is
