@@ -12,6 +12,29 @@ template <> __device__ __forceinline__ f4 part_load4<half_t>(const half_t* p) {
   const h4 h = *reinterpret_cast<const h4*>(p);
   return (f4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
 }
+// The split partials of one element quad, summed in split order with NB independent loads in flight.  The loads are UNCONDITIONAL -- a slab index
+// past the last one re-reads the last slab and its value is dropped -- because a load under `z < splitk` compiles to load / wait / branch one slab at a
+// time (round 4: the reducers spent 8-16 serial L2 latencies per element that way, 14 us for a launch that moves 5 MB).  NB is the smallest of 2 / 4 /
+// 8 / 16 that covers splitk in one batch where it can: no redundant loads for the common split counts.
+template <typename PT, int NB>
+__device__ __forceinline__ f4 sum_partials_nb(const PT* __restrict__ partial, long long total, long long e0, int splitk) {
+  f4 v = {0.f, 0.f, 0.f, 0.f};
+  for (int z0 = 0; z0 < splitk; z0 += NB) {
+    f4 u[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) u[i] = part_load4<PT>(partial + (long long)min(z0 + i, splitk - 1) * total + e0);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) v += z0 + i < splitk ? u[i] : (f4){0.f, 0.f, 0.f, 0.f};
+  }
+  return v;
+}
+template <typename PT>
+__device__ __forceinline__ f4 sum_partials(const PT* __restrict__ partial, long long total, long long e0, int splitk) {
+  if (splitk <= 2) return sum_partials_nb<PT, 2>(partial, total, e0, splitk);
+  if (splitk <= 4) return sum_partials_nb<PT, 4>(partial, total, e0, splitk);
+  if (sizeof(PT) == 2 && splitk > 8) return sum_partials_nb<PT, 16>(partial, total, e0, splitk);
+  return sum_partials_nb<PT, 8>(partial, total, e0, splitk);
+}
 // split-K reduce + epilogue: y[m,n] = sum_z partial[z,m,n] + bias + bias_nc + residual   (N % 4 == 0 fast path)
 template <typename PT>
 __global__ void __launch_bounds__(256) k_splitk_reduce(half_t* __restrict__ y, const PT* __restrict__ partial, const half_t* __restrict__ bias,
@@ -24,14 +47,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(half_t* __restrict__ y, c
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += gs) {
       long long e0 = i << 2;
       int m = (int)(e0 / N), n = (int)(e0 - (long long)m * N);
-      f4 v = {0.f, 0.f, 0.f, 0.f};
-      for (int z0 = 0; z0 < splitk; z0 += 8) {           // 8 independent loads in flight, added in split order
-        f4 u[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) u[i] = z0 + i < splitk ? part_load4<PT>(partial + (long long)(z0 + i) * total + e0) : (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v += u[i];
-      }
+      f4 v = sum_partials<PT>(partial, total, e0, splitk);
       if (bias) { h4 b = *reinterpret_cast<const h4*>(bias + n); for (int e = 0; e < 4; ++e) v[e] += (float)b[e]; }
       if (bias_nc) { h4 b = *reinterpret_cast<const h4*>(bias_nc + (long long)(m / HoWo) * bnc_stride + n); for (int e = 0; e < 4; ++e) v[e] += (float)b[e]; }
       if (residual) { h4 b = *reinterpret_cast<const h4*>(residual + e0); for (int e = 0; e < 4; ++e) v[e] += (float)b[e]; }
@@ -77,14 +93,7 @@ __global__ void __launch_bounds__(1024) k_splitk_reduce_gn(half_t* __restrict__ 
       h4 bnc = {0, 0, 0, 0}, res = {0, 0, 0, 0};
       if (bias_nc) bnc = *reinterpret_cast<const h4*>(bias_nc + (long long)(m / HoWo) * bnc_stride + n);
       if (residual) res = *reinterpret_cast<const h4*>(residual + e0);
-      f4 v = {0.f, 0.f, 0.f, 0.f};
-      for (int z0 = 0; z0 < splitk; z0 += 8) {
-        f4 u[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) u[i] = z0 + i < splitk ? part_load4<PT>(partial + (long long)(z0 + i) * total + e0) : (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v += u[i];
-      }
+      f4 v = sum_partials<PT>(partial, total, e0, splitk);
       v += bv;
       for (int e = 0; e < 4; ++e) v[e] += (float)bnc[e];
       for (int e = 0; e < 4; ++e) v[e] += (float)res[e];
@@ -137,9 +146,11 @@ __global__ void __launch_bounds__(1024) k_splitk_reduce_gn_apply(half_t* __restr
   const long long total = (long long)M * N;
   f4 bv = {0.f, 0.f, 0.f, 0.f};
   h4 bnc = {0, 0, 0, 0};
+  h4 gm = {1, 1, 1, 1}, bt = {0, 0, 0, 0};               // (fetched here, under the partials' latency: behind the block barriers they would be one more serial L2 round trip)
   if (act) {
     if (bias) { h4 b = *reinterpret_cast<const h4*>(bias + n); for (int e = 0; e < 4; ++e) bv[e] = (float)b[e]; }
     if (bias_nc) bnc = *reinterpret_cast<const h4*>(bias_nc + (long long)img * bnc_stride + n);
+    if (gamma) { gm = *reinterpret_cast<const h4*>(gamma + n); bt = *reinterpret_cast<const h4*>(beta + n); }
   }
   h4 out[RGA_MAXR];
   f4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
@@ -151,14 +162,7 @@ __global__ void __launch_bounds__(1024) k_splitk_reduce_gn_apply(half_t* __restr
       const long long e0 = ((long long)img * HoWo + r) * N + n;
       h4 res = {0, 0, 0, 0};
       if (residual) res = *reinterpret_cast<const h4*>(residual + e0);
-      f4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int z0 = 0; z0 < splitk; z0 += 8) {
-        f4 u[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) u[i] = z0 + i < splitk ? part_load4<PT>(partial + (long long)(z0 + i) * total + e0) : (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc += u[i];
-      }
+      f4 acc = sum_partials<PT>(partial, total, e0, splitk);
       acc += bv;
       for (int e = 0; e < 4; ++e) acc[e] += (float)bnc[e];
       for (int e = 0; e < 4; ++e) acc[e] += (float)res[e];
@@ -210,8 +214,6 @@ __global__ void __launch_bounds__(1024) k_splitk_reduce_gn_apply(half_t* __restr
   if (!act) return;
   float a[4], b[4];
   {
-    h4 gm = {1, 1, 1, 1}, bt = {0, 0, 0, 0};
-    if (gamma) { gm = *reinterpret_cast<const h4*>(gamma + n); bt = *reinterpret_cast<const h4*>(beta + n); }
     for (int e = 0; e < 4; ++e) {
       const int g = (v * 4 + e) / cpg;
       a[e] = st[2 * g + 1] * (float)gm[e];
