@@ -169,6 +169,10 @@ CONV_MX = [   # n, c, hw, cout, r, (bm, bn, splitk)
     (1, 384, 48, 256, 3, (192, 128, 1, 2048)),   # three slabs: both parities of the double buffers, scale loads on tap 7
     (3, 256, 24, 200, 3, (192, 128, 1, 2048)),   # ragged channel tile, several images
     (2, 640, 48, 640, 3, (192, 128, 1, 2048)),   # config 5's level-1 conv
+    (1, 320, 96, 320, 3, (192, 128, 1, 2048)),   # the half-slab form: 320 channels = 2.5 slabs (the last one half full), two 2-byte scale loads per patch row; config 5's most frequent conv
+    (1, 192, 48, 136, 3, (192, 128, 1, 2048)),   # 1.5 slabs, ragged channel tile
+    (1, 640, 96, 320, 3, (192, 128, 1, 2048)),   # 96-pixel rows on the 128 grid (the same instance)
+    (1, 960, 48, 640, 3, (192, 128, 1, 2048)),   # 7.5 slabs
 ]
 
 

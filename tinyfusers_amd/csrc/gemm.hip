@@ -453,9 +453,10 @@ static int stats_bm(int bm, int variant) { return (variant == 4 || variant == 6)
 // BASELINE config 5, the OUTPUT row length a template parameter; nearest-2x up-sampling folds into the patch gather), no split-K; fp16, or block-scaled
 // e4m3 on the 128-channel grid; two patch buffers + three weight slots in LDS
 static bool pp3_setup(GemmP& p, int bm, int bn) {
-  if (bm != 192 || bn != (p.Wo == 96 ? 160 : 128)) return false;                                      // the instantiated (output row length, tile width) pairs
+  if (bm != 192 || bn != ((p.Wo == 96 && !p.fp8) ? 160 : 128)) return false;                          // the instantiated (output row length, tile width) pairs
   if (p.bf16 || p.gi_part || p.ln_colsum || p.act || p.out8 || p.out32 || gemm_generic(p)) return false;
-  if (p.fp8 && (!p.mx || p.Wo == 96 || (p.C1 % 128) || (p.C2 % 128))) return false;                 // e4m3: block-scaled, 128-channel slabs, the 48 / 24-pixel instances
+  // e4m3: block-scaled, 128-channel slabs; a channel count on the 64 grid (one source tensor, its last slab half full) has instances for 96 / 48-pixel rows
+  if (p.fp8 && (!p.mx || ((p.C1 % 128) && (p.C2 || p.Wo == 24)) || (p.C2 % 128))) return false;
   if (p.S != 3 || p.Kc != 9 * p.C || p.K != p.Kc + p.C3 + p.C4 || p.stride != 1 || p.pad != 1) return false;
   if ((p.C3 || p.C4) && (p.fp8 || p.ups || (p.C3 % 64) || (p.C4 % 64))) return false;               // the folded 1x1 skip projection: fp16, its sources at output resolution
   if ((p.C1 % 64) || (p.C2 % 64) || (p.H << p.ups) != p.Ho || (p.W << p.ups) != p.Wo) return false;   // (nearest-2x up-sampling folds into the patch gather)
@@ -864,7 +865,7 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
   if (wide == 6) {
     // the tile is the kernel's own: a forced tile keeps its width where the kernel has it; a table row this launch cannot take falls back
     GemmP q = p;
-    const int bn6 = p.Wo == 96 ? 160 : 128;
+    const int bn6 = (p.Wo == 96 && !p.fp8) ? 160 : 128;
     if (pp3_setup(q, 192, bn6)) t.c = {192, bn6, 1};
     else if (g_force_wide == 6) { tf_set_error("run_gemm: the patch form of the ping-pong kernel cannot run this launch"); return TF_E_UNSUPPORTED; }
     else { wide = 0; if (t.c.bm >= 192) t.c = choose_tiles(p.M, p.N, p.K, p.act, workspace != nullptr); }

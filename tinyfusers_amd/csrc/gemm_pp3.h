@@ -46,8 +46,13 @@
 //   one buffer_load_dword ... lds each, on tap 7 of the previous slab (the patch pieces ride on taps 0 .. PPW - 1 <= 6), and a lane reads the byte of (its
 //   patch row, block lg) with one ds_read_u8 per pixel tile at an immediate offset per tap.  Channel counts on the 128 grid; weights carry one fp32 scale
 //   per output channel, applied to the accumulators in front of the epilogue.
-template <int BN, int W, bool F8 = false>
+// H2 (F8 only) = channel counts on the 64 grid (320, 960: one source tensor): the last slab holds 64 channels -- the lanes of its upper 64 bytes fetch out of range
+//   (zero codes; the weight bytes they meet belong to the next tap or row, finite e4m3 values, and contribute nothing) -- and a patch row's four scale bytes sit at
+//   an offset that is only 2-byte aligned (C / 32 = 10 bytes per pixel), so they travel as two buffer_load_ushort ... lds into two tables (blocks 0-1 | blocks 2-3; the
+//   second one out of range for the half slab: E8M0 0 instead of a neighbour's byte, which could be the NaN code).
+template <int BN, int W, bool F8 = false, bool H2 = false>
 __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
+  static_assert(F8 || !H2, "the half-slab form is the e4m3 kernel's");
   constexpr int BM = 192, TN = BN / 2, MJ = 3, NI = TN / 16, NS = 3, D = NS - 1;
   constexpr int ES = F8 ? 1 : 2, SLAB = 128 / ES;          // bytes per element; channels of a slab (128 bytes of a patch row)
   constexpr int WST = BN * 128;                            // bytes of a weight ring slot
@@ -56,8 +61,9 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
   constexpr int PPW = (NPP + 7) / 8;                       // patch pieces per wave at most: they ride on taps 0 .. PPW - 1 and are waited for D - 1 tiles later
   static_assert(W % 8 == 0 && BM % W == 0, "the tile is whole image rows; PW = 4 mod 8");
   static_assert(PPW - 1 + D - 1 <= 8, "a slab's patch must have landed when its first tile is read");
-  constexpr int SCB = F8 ? ((PROWS + 63) / 64) * 256 : 0;  // bytes of a scale patch: one dword per patch row, whole 64-row wave loads
   constexpr int NSW = (PROWS + 63) / 64;                   // waves that fetch scales
+  constexpr int SCT = F8 ? NSW * 256 : 0;                  // bytes of a scale table: one dword per patch row, whole 64-row wave loads
+  constexpr int SCB = (H2 ? 2 : 1) * SCT;                  // bytes of a scale patch (H2: two tables)
   static_assert(2 * PB + NS * WST + 2 * SCB <= 163840, "LDS budget");
   static_assert(!F8 || (PPW <= 7 && NSW <= 8), "the scale loads ride on tap 7");
   constexpr int AST = BM * 128;                            // bytes of an activation tile of the extra 1x1 segment
@@ -80,7 +86,8 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
   else { tile_n = bid / p.ntm; tile_m = bid - tile_n * p.ntm; }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int img = m0 / p.HoWo, y0 = (m0 - img * p.HoWo) / W;
-  const int G = p.C / SLAB, nt = G * 9;                    // channel slabs, K tiles of the nine taps
+  const int G = (p.C + SLAB - 1) / SLAB, nt = G * 9;       // channel slabs (H2: the last one half full), K tiles of the nine taps
+  const bool half_last = H2 && (p.C & 64);
   const int GE = F8 ? 0 : (p.C3 + p.C4) >> 6;              // K tiles of the extra 1x1 segment
   const unsigned lds0 = lds_off(smem);
   const unsigned lds_w = lds0 + 2u * (unsigned)PB;
@@ -119,7 +126,8 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
     rs[2] = __builtin_amdgcn_readfirstlane(second ? nb2 : nb1); rs[3] = 0x00020000;
     const int ld2 = __builtin_amdgcn_readfirstlane((second ? C2_ : C1_) * ES);
     const int cb = __builtin_amdgcn_readfirstlane((second ? c - C1_ : c) * ES) + csp * 16;
-    dma16(rs, pp_pix[i] >= 0 ? (unsigned)(pp_pix[i] * ld2 + cb) : TF_OOB, lds0 + (unsigned)(g & 1) * (unsigned)PB + (unsigned)wid * 1024u + (unsigned)i * 8192u);
+    const bool dead = H2 && half_last && g == G - 1 && csp >= 4;       // the upper 64 bytes of a half slab
+    dma16(rs, (pp_pix[i] >= 0 && !dead) ? (unsigned)(pp_pix[i] * ld2 + cb) : TF_OOB, lds0 + (unsigned)(g & 1) * (unsigned)PB + (unsigned)wid * 1024u + (unsigned)i * 8192u);
     return 1;
   };
   // F8: the scale dwords of patch(g): lane L of wave w < NSW fetches those of patch row 64 w + L.  A source tensor holds its E8M0 bytes behind its
@@ -144,6 +152,12 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
     const int ld32 = __builtin_amdgcn_readfirstlane((second ? C2_ : C1_) >> 5), c32 = __builtin_amdgcn_readfirstlane((second ? c - C1_ : c) >> 5);
     const unsigned off = sc_pix >= 0 ? (unsigned)s_nb + (unsigned)(sc_pix * ld32 + c32) : TF_OOB;
     const unsigned ldsb = lds_w + (unsigned)NS * WST + (unsigned)(g & 1) * SCB + (unsigned)wid * 256u;
+    if constexpr (H2) {
+      const unsigned off_hi = (sc_pix >= 0 && !(half_last && g == G - 1)) ? off + 2u : TF_OOB;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_ushort %1, %2, 0 offen lds" :: "s"(__builtin_amdgcn_readfirstlane((int)ldsb)), "v"(off), "s"(rs) : "memory");
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_ushort %1, %2, 0 offen lds" :: "s"(__builtin_amdgcn_readfirstlane((int)(ldsb + SCT))), "v"(off_hi), "s"(rs) : "memory");
+      return 2;
+    }
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" :: "s"(__builtin_amdgcn_readfirstlane((int)ldsb)), "v"(off), "s"(rs) : "memory");
     return 1;
   };
@@ -183,7 +197,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
   for (int j = 0; j < MJ; ++j) {
     const int ml = wm * (BM / 4) + j * 16 + lr;
     const int yl = ml / W;
-    asx[j] = 2 * PB + NS * WST + (yl * PW + (ml - yl * W)) * 4 + lg;
+    asx[j] = 2 * PB + NS * WST + (yl * PW + (ml - yl * W)) * 4 + (H2 ? (lg >> 1) * SCT + (lg & 1) : lg);
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       const int pr = yl * PW + (ml - yl * W) + dx;
