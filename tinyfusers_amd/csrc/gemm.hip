@@ -401,7 +401,7 @@ static TileCfg choose_tiles(int M, int N, int K, int act, bool allow_split) {
 }
 
 // GroupNorm statistics from the producing conv: limits shared by the host entry, the tuner and the launches
-#define TF_GN_MAX_CHUNKS 128
+#define TF_GN_MAX_CHUNKS 192    // (192: a 128-wide tile on 96 x 96 outputs emits 2 pieces x 96 half-tile chunks per image: the block-scaled patch kernel at config 5's first level)
 static int gn_reduce_chunks(int HoWo) { int R = (HoWo + TF_GN_MAX_CHUNKS - 1) / TF_GN_MAX_CHUNKS; while (HoWo % R) ++R; return HoWo / R; }
 static int gn_pieces(const GemmP& p, int bn) { return bn % p.gn_cpg == 0 ? 1 : 2; }   // chunks per m-tile (igemm_gn_stats)
 static int gn_chunks_for(const GemmP& p, TileCfg c, int splitk) {
