@@ -77,9 +77,45 @@ def _free_port():
     return p
 
 
+def visible_gpus():
+    """How many GPUs the ranks will see, WITHOUT a HIP call (the launcher never touches the GPU): KFD topology nodes that have compute units,
+    cut down by ROCR_ / HIP_ / CUDA_VISIBLE_DEVICES.  None = unknown (no KFD sysfs, or its properties are unreadable): no check then."""
+    import re
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        nodes = os.listdir(base)
+    except OSError:
+        return None
+    n = 0
+    for d in nodes:
+        try:
+            m = re.search(r"^simd_count\s+(\d+)", open(os.path.join(base, d, "properties")).read(), re.M)
+        except OSError:
+            continue
+        if m and int(m.group(1)) > 0:
+            n += 1
+    if n == 0:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip()]))
+    return n
+
+
 def launch_ranks(args, argv):
+    if not args.dry_run:
+        have = visible_gpus()
+        if have is not None and have < args.gpus:
+            # one named error from the parent, before any rank starts (eight ranks failing one by one inside torch.distributed.run say much less)
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} GPU{'s are' if have != 1 else ' is'} visible on this host "
+                             "(KFD topology, *_VISIBLE_DEVICES): not starting any rank\n")
+            return 2
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # one token per launch: the ranks' RCCL unique-id hand-over (--comm tf, tinyfusers_amd.dist.exchange_unique_id) accepts only a file that
+    # carries it, so an id file an earlier job left behind on the same rendezvous port is never mistaken for this job's
+    env.setdefault("TF_COMM_NONCE", "%d-%s" % (os.getpid(), os.urandom(8).hex()))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, text=True)
@@ -452,6 +488,7 @@ def config5_leg(wstate, steps, seed):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
+    t_proc = time.perf_counter()                   # start-up clock of this rank (everything before the warm-up steps: imports, weights, compile + capture)
     in_group = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # started by torch.distributed.run (or by our launcher through it)
     if args.gpus > 1 and not in_group:
         return launch_ranks(args, argv)           # parent: no GPU call before or after
@@ -481,9 +518,12 @@ def main(argv=None):
     import ctypes
     T.ensure_init(local_rank)
     config.set_dtype(args.dtype)
+    t_import = time.perf_counter() - t_proc
 
     sd = StableDiffusion()
+    t_w0 = time.perf_counter()
     arena, arena_bytes, t_gen, t_bcast, wstate = build_weight_arena(sd.model.diffusion_model, rank, world, local_rank, args.comm)
+    t_weights = time.perf_counter() - t_w0
     seed = 1234 + rank
     B, S = args.images, args.latent
     lat = sd.latent_from_numpy(synth_normal(seed, "sd.latent", (B, 4, S, S)))
@@ -495,7 +535,11 @@ def main(argv=None):
     alphas_prev = np.concatenate((np.array([1.0]), alphas[:-1])).astype(np.float32)
     if args.tune_cache:
         hip.tf_gemm_tune_load(args.tune_cache.encode())
+    t_c0 = time.perf_counter()
     sd.compile(unc, ctx, lat, timesteps=timesteps)
+    sd.synchronize()
+    t_compile = time.perf_counter() - t_c0
+    t_startup = time.perf_counter() - t_proc
     if args.tune_cache and rank == 0:
         hip.tf_gemm_tune_save(args.tune_cache.encode())
 
@@ -532,6 +576,13 @@ def main(argv=None):
     hip.tf_event_elapsed_ms(ctypes.byref(ms), ev0, ev1)
     from tinyfusers_amd.dist import max_over_ranks
     wall = max_over_ranks(wall, device=f"cuda:{local_rank}")
+    # start-up per rank, slowest rank: with N Python drivers on one host (each imports torch, packs nothing but compiles and captures its own
+    # graph) host contention shows here first -- the timed region itself has no host work beyond one graph launch per step
+    startup = {"startup_s": round(max_over_ranks(t_startup, device=f"cuda:{local_rank}"), 2),
+               "import_init_s": round(max_over_ranks(t_import, device=f"cuda:{local_rank}"), 2),
+               "weights_s": round(max_over_ranks(t_weights, device=f"cuda:{local_rank}"), 2),
+               "compile_capture_s": round(max_over_ranks(t_compile, device=f"cuda:{local_rank}"), 2),
+               "note": "max over ranks; wall clock of each rank from interpreter entry of main() to the captured step graph (imports + device init, weight arena synthesis / broadcast, eager warm-up + capture)"}
     final = lat.numpy()
     assert np.isfinite(final).all(), "non-finite latent after the timed steps"
 
@@ -559,6 +610,7 @@ def main(argv=None):
             "step_tflops": round(flop_unit * B * args.steps / (ms.value * 1e-3) / 1e12, 1) if flop_unit else None,
             "step_mfma_frac": round(flop_unit * B * args.steps / (ms.value * 1e-3) / 1e12 / peak, 4) if flop_unit else None,
             "weights": {"bytes": arena_bytes, "synth_s": round(t_gen, 2), "bcast_s": round(t_bcast, 4), "bcast_via": ("tf_bcast (C-ABI, librccl)" if args.comm == "tf" else "torch.distributed nccl") if use_dist else None},
+            "startup": startup,
             "roofline": roofline,
         }
         if world == 1 and (B, S, args.dtype) == (1, 64, "fp16") and not args.no_e2e:

@@ -67,3 +67,42 @@ def test_launcher_parent_never_imports_torch():
     assert "import torch" not in head
     body = src[src.index("def main"):]
     assert body.index("launch_ranks(args, argv)") < body.index("import torch")
+
+
+def test_launcher_refuses_more_ranks_than_visible_gpus():
+    """`bench.py --gpus N` on a host that shows fewer than N GPUs: ONE named error from the parent, before any rank starts.  The
+    parent counts KFD topology nodes (no HIP call) cut by *_VISIBLE_DEVICES; where the count is unknown (no KFD sysfs: this container) there is no check."""
+    sys.path.insert(0, ROOT)
+    import bench
+    have = bench.visible_gpus()
+    if have is None:
+        # no KFD here: the function must say "unknown", and an environment list alone must not invent devices
+        os.environ["HIP_VISIBLE_DEVICES"] = "0,1"
+        try:
+            assert bench.visible_gpus() is None
+        finally:
+            del os.environ["HIP_VISIBLE_DEVICES"]
+        # rehearse the refusal with a fake topology
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            for i, simd in enumerate((0, 1024, 1024)):            # node 0 = the CPU
+                os.makedirs(os.path.join(d, str(i)))
+                open(os.path.join(d, str(i), "properties"), "w").write(f"cpu_cores_count 0\nsimd_count {simd}\n")
+            real_listdir, real_open = os.listdir, open
+            base = "/sys/class/kfd/kfd/topology/nodes"
+            import builtins
+            try:
+                os.listdir = lambda p=".": real_listdir(d if p == base else p)
+                builtins.open = lambda f, *a, **k: real_open(f.replace(base, d) if isinstance(f, str) else f, *a, **k)
+                assert bench.visible_gpus() == 2
+                os.environ["ROCR_VISIBLE_DEVICES"] = "1"
+                assert bench.visible_gpus() == 1
+                rc = bench.launch_ranks(bench.parse(["--gpus", "2"]), ["--gpus", "2"])
+                assert rc == 2
+            finally:
+                os.listdir, builtins.open = real_listdir, real_open
+                os.environ.pop("ROCR_VISIBLE_DEVICES", None)
+    else:
+        r = _run(["--gpus", str(have + 1), "--steps", "1", "--warmup", "0"])
+        assert r.returncode == 2 and f"only {have} GPU" in r.stderr
+        assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]

@@ -57,6 +57,16 @@ def test_weight_broadcast_and_sharding_world2():
     assert t0 == t1 == 2.0                                    # timing = max over ranks
 
 
+def _native_or_skip():
+    """The C-ABI tests below load libtinyfusers_hip.so (host code only, no device work): skip -- like tests/test_abi.py's fixture -- on a box where it
+    cannot be loaded (no hipcc-built library, no libamdhip64)."""
+    try:
+        import tinyfusers_amd.native as native
+    except (RuntimeError, OSError) as e:
+        pytest.skip(f"libtinyfusers_hip.so cannot be loaded here: {e}")
+    return native
+
+
 # ---- the C-ABI's own collective: the unique-id hand-over (host code of tinyfusers_amd.dist.TfComm) and the kernel choices of the ranks ----
 def _id_worker(rank, world, path, q):
     sys.path.insert(0, ROOT)
@@ -86,6 +96,7 @@ def _id_worker(rank, world, path, q):
 def test_unique_id_handover_and_identical_kernel_choices_world2(tmp_path):
     """bench.py --comm tf: rank 0 publishes the 128-byte RCCL id through a file, rank 1 picks it up; and with WORLD_SIZE > 1 both ranks
     hold the same tuning table (tf_gemm_tune_* is host code) and will not tune at run time, so they launch the same kernels."""
+    _native_or_skip()
     path = str(tmp_path / "uid")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -112,8 +123,57 @@ def test_unique_id_handover_and_identical_kernel_choices_world2(tmp_path):
 
 
 def test_table_only_mode_is_set_with_world_size(monkeypatch):
+    _native_or_skip()
     import subprocess
     code = ("import ctypes, tinyfusers_amd.native as n; k=(ctypes.c_int*10)(7,7,64,64,0,1,1,0,0,0); "
             "print(n.lib.tf_gemm_autotune(3), n.lib.tf_gemm_autotune(2))")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, WORLD_SIZE="2"))
     assert r.returncode == 0 and r.stdout.split() == ["10001", "0"], r.stdout + r.stderr
+
+
+# ---- a stale id file (ADVICE r4 / VERDICT r4 item 8): a job that died between publishing its id and release_unique_id leaves the file behind; the
+# next job's waiting ranks must not accept it ---------------------------------------------------------------------------------------------------
+def _stale_worker(rank, path, nonce, delay, q):
+    sys.path.insert(0, ROOT)
+    import time
+    os.environ["TF_COMM_NONCE"] = nonce
+    from tinyfusers_amd.dist import exchange_unique_id
+    time.sleep(delay)
+    t0 = time.time()
+    uid = exchange_unique_id(rank, lambda: bytes([7] * 128), path, timeout=30.0)
+    q.put((rank, uid, time.time() - t0))
+
+
+def test_stale_unique_id_file_of_a_dead_job_is_ignored(tmp_path):
+    from tinyfusers_amd import dist as tfd
+    path = str(tmp_path / "uid")
+    # what a dead job left behind: the round-4 format (128 bare bytes) ...
+    open(path, "wb").write(bytes(range(128)))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stale_worker, args=(1, path, "job-B", 0.0, q)), ctx.Process(target=_stale_worker, args=(0, path, "job-B", 1.0, q))]
+    for p in procs: p.start()                              # rank 1 polls the stale file for a second before rank 0 publishes
+    res = dict((r, (u, dt)) for r, u, dt in (q.get(timeout=60) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert res[0][0] == res[1][0] == bytes([7] * 128) and res[1][1] >= 0.8      # the fresh id, and only once rank 0 had written it
+    blob = open(path, "rb").read()
+    assert len(blob) == 16 + 128 and (os.stat(path).st_mode & 0o777) == 0o600
+    # ... and one in the current format carrying ANOTHER job's nonce: a waiting rank of this job times out on it instead of joining a dead id
+    os.environ["TF_COMM_NONCE"] = "job-A"
+    try:
+        stale = tfd.job_nonce() + bytes(range(128))
+        os.environ["TF_COMM_NONCE"] = "job-C"
+        assert tfd.job_nonce() != stale[:16]
+        open(path, "wb").write(stale)
+        with pytest.raises(TimeoutError):
+            tfd.exchange_unique_id(1, None, path, timeout=0.3)
+        # distinct jobs also meet at distinct default names
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29500")
+        pc = tfd.comm_id_path()
+        os.environ["TF_COMM_NONCE"] = "job-A"
+        assert tfd.comm_id_path() != pc
+    finally:
+        for k in ("TF_COMM_NONCE", "MASTER_ADDR", "MASTER_PORT"):
+            os.environ.pop(k, None)

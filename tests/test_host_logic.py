@@ -63,3 +63,22 @@ def test_shard_range_and_arena_plan():
     assert total == 1719055872 and all(o % 256 == 0 for o in offs.values())     # 1.72 GB fp16
     w = np.arange(2 * 3 * 2 * 2, dtype=np.float16).reshape(2, 3, 2, 2)
     assert pack_tensor(w).shape == (2, 2, 2, 3) and pack_tensor(w)[1, 0, 1, 2] == w[1, 2, 0, 1]
+
+
+def test_state_walk_cuts_cycles_but_visits_a_shared_module_under_both_names():
+    """_slots (storage/state.py:4-23's recursive walk): a module two parents share is a leaf owner under BOTH dotted names (the
+    round-4 visited set dropped the second name), while a back-reference to an ancestor does not make the walk spin."""
+    from tinyfusers_amd.storage.state import _slots, param_shapes
+    from tinyfusers_amd.ff.linear import Linear
+
+    class Box:
+        pass
+    shared = Linear(8, 4, init=False)
+    root, a, b = Box(), Box(), Box()
+    a.proj, b.proj = shared, shared
+    root.a, root.b = a, b
+    a.parent = root                                        # a public back-reference: a cycle
+    root.items = [shared, {"again": shared}]
+    names = [n for n, *_ in _slots(root)]
+    assert sorted(names) == sorted(f"{p}.{leaf}" for p in ("a.proj", "b.proj", "items.0", "items.1.again") for leaf in ("weight", "bias"))
+    assert param_shapes(root)["b.proj.weight"] == (4, 8) and param_shapes(root)["a.proj.bias"] == (4,)

@@ -87,6 +87,10 @@ def set_dtype(name):
     global dtype
     if name not in ("fp16", "fp8", "bf16"):
         raise ValueError(f"config.set_dtype: unknown dtype {name!r}")
+    if name == "bf16" and (parallel_branches or cfg_parallel):
+        # those two experiments (both measured slower, both off by default) have fp16-only side paths: refuse the combination instead of
+        # producing wrong latents
+        raise ValueError("config.set_dtype('bf16'): not with TF_PARALLEL_BRANCHES / TF_CFG_PARALLEL (fp16-only experiments)")
     dtype = name
 
 

@@ -61,41 +61,69 @@ def max_over_ranks(value, device=None):
 # For hosts without torch.distributed -- and what `bench.py --comm tf` exercises: rank 0 draws the 128-byte RCCL unique id and hands it to
 # the other ranks through a FILE (any host channel would do; a file needs nothing but a shared /tmp on the one node the path runs on).
 UNIQUE_ID_BYTES = 128
+_NONCE_BYTES = 16
+
+
+def job_nonce():
+    """16 bytes every rank of ONE job derives identically and another job does not: a digest of $TF_COMM_NONCE (``bench.py --gpus N`` draws one
+    per launch and hands it to its ranks through the environment), else of torchrun's run id + the launcher's pid (every local rank is a child
+    of the same agent process; the default run id of a stand-alone torchrun is the constant "none", so the id alone would not do).  Ranks
+    started by hand with neither get the all-zero nonce, i.e. the round-4 behaviour: give them a $TF_COMM_NONCE or a fresh $TF_COMM_ID_FILE."""
+    import hashlib
+    tok = os.environ.get("TF_COMM_NONCE")
+    if not tok and os.environ.get("TORCHELASTIC_RUN_ID") is not None:
+        tok = "%s/%d" % (os.environ["TORCHELASTIC_RUN_ID"], os.getppid())
+    return hashlib.sha256(tok.encode()).digest()[:_NONCE_BYTES] if tok else bytes(_NONCE_BYTES)
 
 
 def comm_id_path():
-    """Where the ranks of one job meet: $TF_COMM_ID_FILE, else a name derived from the rendezvous the launcher already gave every rank."""
+    """Where the ranks of one job meet: $TF_COMM_ID_FILE, else a per-user, per-job name derived from the rendezvous the launcher already gave every
+    rank and the job's nonce (a file an earlier job left behind then has another name, and another user's cannot be mistaken for ours)."""
     p = os.environ.get("TF_COMM_ID_FILE")
     if p:
         return p
     import tempfile
-    return os.path.join(tempfile.gettempdir(), "tf_comm_id_%s_%s" % (os.environ.get("MASTER_ADDR", "local"), os.environ.get("MASTER_PORT", str(os.getppid()))))
+    return os.path.join(tempfile.gettempdir(), "tf_comm_id_%d_%s_%s_%s" % (os.getuid(), os.environ.get("MASTER_ADDR", "local"),
+                                                                          os.environ.get("MASTER_PORT", str(os.getppid())), job_nonce().hex()[:16]))
 
 
-def exchange_unique_id(rank, make_id, path=None, timeout=120.0):
-    """Rank 0 calls make_id() -> 128 bytes and publishes them atomically (write to a temporary name, then rename); every other rank waits
-    for the file.  Returns the id.  The file is left in place until rank 0 calls release_unique_id (after every rank has joined)."""
+def exchange_unique_id(rank, make_id, path=None, timeout=120.0, nonce=None):
+    """Rank 0 calls make_id() -> 128 bytes and publishes [job nonce | id] atomically: any file already at the name is unlinked first, the bytes go
+    to a temporary name created with O_EXCL and mode 0600, then a rename.  Every other rank waits for a file that carries THIS job's nonce -- a
+    file left behind by a job that died between publishing and release_unique_id (or planted by someone else) is ignored, so nobody joins
+    ncclCommInitRank with a dead id.  Returns the id.  The file stays until rank 0 calls release_unique_id (after every rank has joined)."""
     import time
     path = path or comm_id_path()
+    nonce = job_nonce() if nonce is None else bytes(nonce)
+    assert len(nonce) == _NONCE_BYTES
     if rank == 0:
         uid = bytes(make_id())
         assert len(uid) == UNIQUE_ID_BYTES, len(uid)
+        try:
+            os.unlink(path)                                   # a stale id of an earlier job must not be readable while we write ours
+        except OSError:
+            pass
         tmp = "%s.%d.tmp" % (path, os.getpid())
-        with open(tmp, "wb") as f:
-            f.write(uid)
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
+            f.write(nonce + uid)
         os.replace(tmp, path)
         return uid
     t0 = time.time()
     while True:
         try:
             with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) == UNIQUE_ID_BYTES:
-                return uid
-        except FileNotFoundError:
+                blob = f.read()
+            if len(blob) == _NONCE_BYTES + UNIQUE_ID_BYTES and blob[:_NONCE_BYTES] == nonce:
+                return blob[_NONCE_BYTES:]
+        except OSError:
             pass
         if time.time() - t0 > timeout:
-            raise TimeoutError("rank %d: no RCCL unique id at %s after %.0f s (did rank 0 start?)" % (rank, path, timeout))
+            raise TimeoutError("rank %d: no RCCL unique id of this job at %s after %.0f s (did rank 0 start? do all ranks share TF_COMM_NONCE / the launcher?)" % (rank, path, timeout))
         time.sleep(0.01)
 
 

@@ -31,14 +31,14 @@ def _slots(root, prefix=""):
     """Yield (dotted name, owner dict, key, current value, module) for every ``weight`` / ``bias`` slot below ``root``.  Private
     attributes (``_x``), scalars and arrays that are not such leaves are not descended into; ``module`` is the object the slot
     belongs to (``param_shapes`` reads the shape off it)."""
-    stack = [(prefix, root)]
-    seen = set()                                           # ids of the containers / objects already walked: a public back-reference (a module holding
-    while stack:                                           # its parent, a compiled graph reachable from the root) must not make the walk spin
-        pre, node = stack.pop()
-        if id(node) in seen:
-            continue
-        seen.add(id(node))
-        below = []
+    # Depth first, siblings in declaration order.  Only CYCLES are cut (a public back-reference: a module holding its parent, a compiled graph
+    # reachable from the root): a node is skipped when it is one of its own ancestors on the current path.  A module reachable under two names
+    # (shared between two parents) is walked under BOTH, so update_state fills it from either key and param_shapes lists both names, as the
+    # reference's recursive walk does (storage/state.py:4-23).
+    def walk(pre, node, path):
+        if id(node) in path:
+            return
+        path = path | {id(node)}
         for name, child, owner in _children(node):
             dotted = f"{pre}.{name}" if pre else name
             if name in _LEAVES and owner is not None:
@@ -46,8 +46,8 @@ def _slots(root, prefix=""):
             elif name.startswith("_") or child is None or isinstance(child, _OPAQUE):
                 continue
             else:
-                below.append((dotted, child))
-        stack.extend(reversed(below))                      # depth first, siblings in declaration order
+                yield from walk(dotted, child, path)
+    yield from walk(prefix, root, frozenset())
 
 
 def _to_numpy(v):

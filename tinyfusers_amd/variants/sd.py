@@ -138,18 +138,25 @@ class StableDiffusion:
         Step-invariant work stays out of the captured step (config.hoist_step_invariants): the cross-attention K|V projection of the
         context runs here and in ``set_context`` -- it depends on the context alone -- and the time-embedding row of a timestep (the MLP
         of unet.py:54-56 + the 22 ResBlock projections of resnet.py:28) is computed once per distinct timestep, kept in a table, and
-        handed to the replay by the launch that sets the step scalars.  ``timesteps``: the schedule, to fill the table up front."""
+        handed to the replay by the launch that sets the step scalars.  ``timesteps``: the schedule, to fill the table up front.
+
+        The captured step reads PRIVATE buffers (the stacked context and, hoisted, its K|V projection): ``set_context`` is the only supported
+        way to change the prompts of a compiled sampler -- writing into the arrays handed to ``compile`` (or into ``_ctx2``) changes nothing the
+        cross-attention reads.  The hoisted tables are keyed by ``weights_key()``: eager steps (``step(..., eager=True)``) follow weights replaced
+        after ``compile``; the captured graph holds the addresses of the weights it was captured with, so a new weight set needs ``compile`` again."""
+        if config.is_bf16() and (config.parallel_branches or config.cfg_parallel):
+            raise RuntimeError("StableDiffusion.compile: the bfloat16 step has no parallel-branch / two-chain CFG form (TF_PARALLEL_BRANCHES / TF_CFG_PARALLEL are fp16-only experiments)")
         self._stream = stream or Stream()
         self._latent, self._unc, self._ctx = latent, unconditional_context, context
         sp = self._step_params()
         unet = self.model.diffusion_model
         with use_stream(self._stream):
             self._ctx2 = self._stack_context(unconditional_context, context)
-            self._kv_all, self._emb_cur, self._emb_rows, self._emb_key = None, None, {}, None
+            self._kv_all, self._kv_key, self._emb_cur, self._emb_rows, self._emb_key = None, None, None, {}, None
             if config.hoist_step_invariants and not config.cfg_parallel:
-                self._kv_all = unet.context_kv(self._ctx2)
+                self._kv_all, self._kv_key = unet.context_kv(self._ctx2), unet.weights_key()
                 _, row = unet.time_embedding_all(sp.set(981.0))
-                self._emb_cur = DeviceArray.empty(row.shape, np.float16, "row")      # what the captured step reads
+                self._emb_cur = DeviceArray.empty(row.shape, row.dtype, "row")       # what the captured step reads (fp16, or bfloat16 bits in the bf16 step)
                 assert self._emb_cur.nbytes % 16 == 0
                 hip.tf_memcpy_async(self._emb_cur.ptr, row.ptr, row.nbytes, 3, _sh())   # (the warm-up steps below run at t = 981)
                 self._keep_row = row
@@ -216,7 +223,13 @@ class StableDiffusion:
         sp = self._params
         with use_stream(self._stream, ordered=False):
             if getattr(self, "_emb_cur", None) is not None:
-                row = self._emb_row(float(timestep))          # (computed on this stream the first time a timestep is seen)
+                key = self.model.diffusion_model.weights_key()
+                if getattr(self, "_kv_all", None) is not None and self._kv_key != key:
+                    # a to_k / to_v (or any hoisted) weight was replaced since compile(): the K|V projection the graph reads is stale -- refresh it in place
+                    kv = self.model.diffusion_model.context_kv(self._ctx2)
+                    hip.tf_memcpy_async(self._kv_all.ptr, kv.ptr, kv.nbytes, 3, _sh())
+                    self._kv_tmp, self._kv_key = kv, key
+                row = self._emb_row(float(timestep), key)     # (computed on this stream the first time a timestep is seen)
                 hip.tf_set_step_params_copy(sp.dev.ptr, float(timestep), float(a_t), float(a_prev), float(guidance), self._emb_cur.ptr, row.ptr, row.nbytes, _sh())
             else:
                 sp.set(timestep, a_t, a_prev, guidance)
@@ -225,10 +238,10 @@ class StableDiffusion:
             else:
                 hip.tf_graph_launch(self._graph, self._stream.handle)
 
-    def _emb_row(self, t):
+    def _emb_row(self, t, key=None):
         """The cached time-embedding row of timestep t (keyed by the weights it was computed from; at most 1024 rows are kept)."""
         unet = self.model.diffusion_model
-        key = unet.weights_key()
+        key = unet.weights_key() if key is None else key
         if self._emb_key != key:
             self._emb_rows, self._emb_key = {}, key
         row = self._emb_rows.get(t)
@@ -251,7 +264,7 @@ class StableDiffusion:
             if getattr(self, "_kv_all", None) is not None:
                 kv = self.model.diffusion_model.context_kv(self._ctx2)
                 hip.tf_memcpy_async(self._kv_all.ptr, kv.ptr, kv.nbytes, 3, _sh())
-                self._kv_tmp = kv                                  # (referenced until the copy has run)
+                self._kv_tmp, self._kv_key = kv, self.model.diffusion_model.weights_key()   # (referenced until the copy has run)
         self._unc, self._ctx = unconditional_context, context
 
     def synchronize(self):
