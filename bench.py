@@ -39,8 +39,8 @@ sys.path.insert(0, ROOT)
 FLOP_PER_STEP = 1.6088e12          # algorithmic FLOPs of one step (conv 887.89 G + linear 466.49 G + SDPA 252.10 G + 2.28 G)
 PEAK_MFMA_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp8": 5000.0}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_PROFILE = os.path.join("profiles", "r04_pmc_traffic.json")
-FAMILY_PROFILE = os.path.join("profiles", "r04_kernel_family.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r05_pmc_traffic.json")
+FAMILY_PROFILE = os.path.join("profiles", "r05_kernel_family.json")
 
 
 def parse(argv=None):
@@ -384,13 +384,18 @@ def roofline_leg(sd, run, n_inst, peak, default_workload):
     sd.synchronize()
     gfull, gms, gfl, gl = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
     hip.tf_prof_read_full(ctypes.byref(gfull), ctypes.byref(gms), ctypes.byref(gfl), ctypes.byref(gl))
+    fams = {}
+    for fam, name in ((1, "group_norm"), (2, "splitk_reduce"), (3, "layer_norm"), (4, "sdpa")):
+        fms, fwork, fn = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+        hip.tf_prof_read_family(fam, ctypes.byref(fms), ctypes.byref(fwork), ctypes.byref(fn))
+        fams[name] = (fms.value, fwork.value, fn.value)
     lib.tf_prof_enable(0)
     ach = gfl.value / (gfull.value * 1e-3) / 1e12 if gfull.value > 0 else 0.0
     ach_k = gfl.value / (gms.value * 1e-3) / 1e12 if gms.value > 0 else 0.0
     # HBM bytes per launch of this kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction +
     # WRITE_SIZE, separate runs of this same command; tools/pmc_summary.py): they cannot be sampled live, so the profile is stamped with
     # the hash of the kernel sources it was taken on and is reported only while that still matches
-    traffic, tnote = None, f"no {TRAFFIC_PROFILE}"
+    traffic, tnote, pj = None, f"no {TRAFFIC_PROFILE}", {}
     try:
         pj = json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))
         if pj.get("csrc_sha16") == csrc_hash() and default_workload:
@@ -400,6 +405,35 @@ def roofline_leg(sd, run, n_inst, peak, default_workload):
             tnote = f"{TRAFFIC_PROFILE} was taken on other kernel sources or another workload ({pj.get('csrc_sha16')} vs {csrc_hash()}): not reported"
     except Exception:
         pass
+    # The HBM-bound families against the 8 TB/s roof (north_star: "rocprof HBM GB/s ... against the chip's peak" for the norm kernels): live
+    # event time per launch (same brackets, same overhead correction as the GEMM family) over the launch's ALGORITHMIC bytes (every operand
+    # read once, every result written once: what the launcher computes from its shapes); `traffic` = the fabric bytes per launch the
+    # committed PMC passes counted for that family, quoted while the kernel sources match
+    hbm = {}
+    kernels = {"group_norm": ("k_gn_stats / k_gn_apply (GroupNorm [+ SiLU] apply; the statistics ride on the producing conv)", "k_gn"),
+               "splitk_reduce": ("k_splitk_reduce / _gn / _gn_apply (partial slabs -> y [+ statistics, + the next GroupNorm applied])", "k_splitk_reduce"),
+               "layer_norm": ("k_layer_norm* (stand-alone LayerNorm: inside the UNet it is folded into the consuming GEMM)", "k_layer_norm")}
+    for name, (desc, pkey) in kernels.items():
+        fms, fwork, fn = fams[name]
+        if fn == 0 or fms <= 0:
+            hbm[name] = {"kernel": desc, "launches_per_step": 0.0}
+            continue
+        gbs = fwork / (fms * 1e-3) / 1e9
+        tr = None
+        try:
+            if pj.get("csrc_sha16") == csrc_hash() and default_workload and pkey in pj:
+                tr = round(pj[pkey]["hbm_bytes_per_launch"])
+        except Exception:
+            pass
+        hbm[name] = {"kernel": desc, "bound": "hbm", "launches_per_step": fn / n_inst, "avg_launch_us": round(fms * 1e3 / fn, 2), "ms_per_step": round(fms / n_inst, 4),
+                     "algorithmic_bytes_per_launch": round(fwork / fn), "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                     "traffic": tr, "traffic_gbs": round(tr / (fms * 1e-3 / fn) / 1e9, 1) if tr else None}
+    sms, swork, sn = fams["sdpa"]
+    sdpa = None
+    if sn and sms > 0:
+        stf = swork / (sms * 1e-3) / 1e12
+        sdpa = {"kernel": "k_sdpa_dma / k_sdpa (flash attention; FLOPs = 4 B NH Tq Tk d)", "bound": "mfma", "launches_per_step": sn / n_inst, "avg_launch_us": round(sms * 1e3 / sn, 2),
+                "ms_per_step": round(sms / n_inst, 4), "achieved": round(stf, 1), "peak": PEAK_MFMA_TFLOPS["fp16"], "unit": "TFLOP/s", "frac": round(stf / PEAK_MFMA_TFLOPS["fp16"], 4)}
     # the same family in the committed rocprofv3 --kernel-trace --stats run (tools/prof_summary.py), quoted while the sources match
     rocprof = None
     try:
@@ -422,7 +456,7 @@ def roofline_leg(sd, run, n_inst, peak, default_workload):
             "gemm_kernel_only": {"achieved": round(ach_k, 1), "frac": round(ach_k / peak, 4), "ms_per_step": round(gms.value / n_inst, 4),
                                  "avg_launch_us": round(gms.value * 1e3 / max(1, gl.value), 2)},
             "event_bracket_overhead_us": round(float(lib.tf_prof_overhead_us()), 2),
-            "rocprof": rocprof}
+            "rocprof": rocprof, "hbm": hbm, "sdpa": sdpa}
 
 
 def config5_leg(wstate, steps, seed):
@@ -476,7 +510,9 @@ def config5_leg(wstate, steps, seed):
             out[dtype] = {"image_steps_per_s": round(B * 1e3 / per, 2), "ms_per_step": round(per, 3),
                           "step_tflops": round(4.30e12 * B / (per * 1e-3) / 1e12, 1),
                           "gemm_family_tflops": rl["achieved"], "gemm_ms_per_step": rl["gemm_ms_per_step"], "gemm_launches_per_step": rl["launches_per_step"],
-                          "frac_of_2500_tflops_f16_peak": round(rl["achieved"] / 2500.0, 4), "frac_of_5000_tflops_f8_peak": round(rl["achieved"] / 5000.0, 4)}
+                          "frac_of_2500_tflops_f16_peak": round(rl["achieved"] / 2500.0, 4), "frac_of_5000_tflops_f8_peak": round(rl["achieved"] / 5000.0, 4),
+                          "hbm": {k: {kk: v.get(kk) for kk in ("launches_per_step", "avg_launch_us", "ms_per_step", "algorithmic_bytes_per_launch", "achieved", "frac")} for k, v in rl["hbm"].items()},
+                          "sdpa": {kk: rl["sdpa"].get(kk) for kk in ("launches_per_step", "avg_launch_us", "ms_per_step", "achieved", "frac")} if rl["sdpa"] else None}
             del sd
         finally:
             config.set_dtype("fp16")

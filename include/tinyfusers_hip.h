@@ -156,6 +156,12 @@ int tf_prof_read(double* gemm_ms, double* gemm_flops, long long* gemm_launches);
 int tf_prof_read_full(double* ms_with_reduce, double* ms_gemm_kernel_only, double* gemm_flops, long long* gemm_launches);
 float tf_prof_overhead_us(void);   /* the per-bracket event overhead tf_prof_enable(1) measured (spin-kernel pair, see csrc/gemm.hip) and subtracts */
 int tf_prof_dump(const char* csv_path);   /* per-shape table: M,N,K,taps,tile,split-K,launches,ms,TFLOP/s */
+/* the same event brackets around the launches of the other kernel families of the step while tf_prof_enable(1) is on (eager launches only):
+ * family 1 = GroupNorm (k_gn_stats / k_gn_apply; ff/group_norm.py:3-21), 2 = the split-K reduce launches (incl. the forms that emit / apply the next
+ * GroupNorm), 3 = LayerNorm (ff/layer_norm.py:8-49), 4 = SDPA (attention/sdpa.py:53-77).  `work` = the launches' ALGORITHMIC work: HBM bytes
+ * (every operand read once, every result written once) for families 1-3, FLOPs (4 B NH Tq Tk d) for family 4 -- what bench.py prices against
+ * the 8 TB/s HBM roof / the MFMA peak */
+int tf_prof_read_family(int family, double* ms, double* work, long long* launches);
 /* element type of the split-K partial slabs a split GEMM hands to its reduce launch: 16 (default) = fp16 -- half the bytes of that seam,
  * accumulated in fp32 in split order by the reducer -- or 32 = fp32 (rounds 1-3) */
 int tf_gemm_splitk_partials(int bits);

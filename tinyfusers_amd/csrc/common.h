@@ -40,6 +40,22 @@ struct tfEvent_st { hipEvent_t e; };
 struct tfGraph_st { hipGraph_t g; hipGraphExec_t x; };
 static inline hipStream_t tf_hs(struct tfStream_st* s) { return s ? s->s : (hipStream_t)0; }
 
+// ---- per-launch profiling of kernel FAMILIES with HIP events on the launch stream (runtime.hip; bench.py's roofline legs).  While
+// tf_prof_enable(1) is on, a launcher brackets its kernel with `TfProfScope scope(family, work, stream);` -- work = the launch's algorithmic
+// HBM bytes (norm / reduce families) or FLOPs (SDPA) -- and tf_prof_read_family hands back accumulated milliseconds, work and launches.
+enum { TF_PROF_FAM_GROUP_NORM = 1, TF_PROF_FAM_SPLITK_REDUCE = 2, TF_PROF_FAM_LAYER_NORM = 3, TF_PROF_FAM_SDPA = 4, TF_PROF_NFAM = 5 };
+extern bool g_tf_prof;
+extern float g_tf_prof_overhead_ms;     // what an event bracket reads beyond the kernel's own duration (measured by tf_prof_enable, csrc/gemm.hip)
+void tf_prof_fam_reset();
+void tf_prof_fam_begin(int family, double work, hipStream_t st);
+void tf_prof_fam_end(hipStream_t st);
+void tf_prof_fam_add(int family, double work, double ms);          // a bracket the caller timed itself (the split-K reduce inside run_gemm)
+struct TfProfScope {
+  hipStream_t st; bool on;
+  TfProfScope(int family, double work, hipStream_t s) : st(s), on(g_tf_prof) { if (on) tf_prof_fam_begin(family, work, s); }
+  ~TfProfScope() { if (on) tf_prof_fam_end(st); }
+};
+
 // device-side helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

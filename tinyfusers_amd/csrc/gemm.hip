@@ -358,10 +358,10 @@ __global__ void __launch_bounds__(256) k_ln_fold(half_t* __restrict__ wo, half_t
 
 // ------------------------------------------------------------------------------------------------
 // per-launch event profiling of this kernel family (bench.py roofline leg)
-static bool g_prof = false;
+#define g_prof g_tf_prof      /* the one switch of every family (common.h) */
 static double g_prof_ms = 0.0, g_prof_ms_full = 0.0, g_prof_flops = 0.0;
 static long long g_prof_launches = 0;
-struct ProfRec { hipEvent_t a, b, c; bool has_reduce; double flops; int M, N, K, taps, bm, bn, splitk, variant; };   // a .. b: the GEMM kernel alone; a .. c: with the split-K reduce that finishes it
+struct ProfRec { hipEvent_t a, b, c; bool has_reduce; double flops, reduce_bytes; int M, N, K, taps, bm, bn, splitk, variant; };   // a .. b: the GEMM kernel alone; a .. c: with the split-K reduce that finishes it
 #include <map>
 #include <array>
 static std::map<std::array<int, 8>, std::pair<long long, double>> g_prof_shapes;
@@ -902,7 +902,11 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
   if (rc) return rc;
   if (g_prof) {
     // the second bracket only where a reduce launch followed the GEMM (an event pair of its own costs ~2 us of stream time)
-    rec.has_reduce = eff_splitk(p, wide, t.c.splitk) > 1;
+    const int eff = eff_splitk(p, wide, t.c.splitk);
+    rec.has_reduce = eff > 1;
+    // algorithmic bytes of the reduce launch: the slabs in, y out (+ the normalised z of the fused form), bias rows negligible
+    const double mn = (double)p.M * p.N;
+    rec.reduce_bytes = mn * eff * ((g_part16 && (p.N & 7) == 0) ? 2.0 : 4.0) + mn * 2.0 * (1.0 + (p.residual ? 1.0 : 0.0) + ((p.on_z && p.gn_part) ? 1.0 : 0.0));
     if (rec.has_reduce) TF_HIP(hipEventRecord(rec.c, st));
     g_prof_pending.push_back(rec);
   }
@@ -1035,6 +1039,7 @@ int tf_prof_enable(int on) {
   g_prof = on != 0;
   if (on) {
     g_prof_ms = 0.0; g_prof_ms_full = 0.0; g_prof_flops = 0.0; g_prof_launches = 0; g_prof_pending.clear(); g_prof_shapes.clear();
+    tf_prof_fam_reset();
     hipEvent_t a, b;
     TF_HIP(hipEventCreate(&a)); TF_HIP(hipEventCreate(&b));
     float v[9];
@@ -1048,6 +1053,7 @@ int tf_prof_enable(int on) {
     }
     for (int i = 0; i < 9; ++i) for (int j = i + 1; j < 9; ++j) if (v[j] < v[i]) { float t = v[i]; v[i] = v[j]; v[j] = t; }
     g_prof_overhead_ms = v[4] > 0.f ? v[4] : 0.f;
+    g_tf_prof_overhead_ms = g_prof_overhead_ms;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
   }
   return TF_OK;
@@ -1066,6 +1072,7 @@ static int prof_collect() {
       TF_HIP(hipEventElapsedTime(&tr, r.b, r.c));
       tr -= g_prof_overhead_ms;
       if (tr > 0.f) tf += tr;
+      tf_prof_fam_add(TF_PROF_FAM_SPLITK_REDUCE, r.reduce_bytes, tr > 0.f ? tr : 0.0);
     }
     g_prof_ms += t; g_prof_ms_full += tf; g_prof_flops += r.flops; g_prof_launches += 1;
     auto& e = g_prof_shapes[{r.M, r.N, r.K, r.taps, r.bm, r.bn, r.splitk, r.variant}];

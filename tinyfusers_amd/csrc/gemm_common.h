@@ -508,8 +508,10 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
     f4 v0 = *reinterpret_cast<const f4*>(r), v1 = *reinterpret_cast<const f4*>(r + 4);
     const long long o = (long long)m * p.N + n;
     if (part && p.part16 && p.splitk > 1) {                 // fp16 slab (N % 8 == 0: one 16-byte store per item)
+      // (a partial is a SUB-sum: it may exceed fp16's range where the full sum does not, and (half_t) does not saturate -- clamp, so that an
+      // out-of-range partial costs accuracy, not an inf / NaN in y; the bfloat16 launches keep fp32 slabs: launch_one)
       h8 hv;
-      for (int e = 0; e < 4; ++e) { hv[e] = (half_t)v0[e]; hv[4 + e] = (half_t)v1[e]; }
+      for (int e = 0; e < 4; ++e) { hv[e] = (half_t)__builtin_fminf(__builtin_fmaxf(v0[e], -65504.0f), 65504.0f); hv[4 + e] = (half_t)__builtin_fminf(__builtin_fmaxf(v1[e], -65504.0f), 65504.0f); }
       *reinterpret_cast<h8*>(reinterpret_cast<half_t*>(p.partial) + (long long)split * p.M * p.N + o) = hv;
       continue;
     }

@@ -365,6 +365,7 @@ static int layer_norm_impl(void* y, const void* x, const void* gamma, const void
   TF_REQUIRE((gamma == nullptr) == (beta == nullptr), "tf_layer_norm_f16: gamma and beta must both be given or both NULL");
   TF_REQUIRE(C > 0, "tf_layer_norm_f16: C=%d", C);
   if (rows == 0) return TF_OK;
+  TfProfScope prof_(TF_PROF_FAM_LAYER_NORM, (double)rows * C * (2.0 + (out8 ? 1.0 : 2.0)), tf_hs(s));
   if (C % 8 != 0 || C > 64 * 8 * LN_MAXV) {
     // any row length: a wave per row while the row is short, a block per row beyond
     if (C <= 4096) hipLaunchKernelGGL((k_layer_norm_any<true, T>), dim3(ceil_div(rows, 4)), dim3(256), 0, tf_hs(s), (T*)y, (const T*)x,
@@ -407,6 +408,7 @@ static int group_norm_impl(void* y, const void* x, const void* x2, const void* g
   gn_geometry(HW, C, N, &CV, &RPB, &threads, &chunks, &ppc, &ablocks, &appb);
   float* partial = (float*)workspace;
   int tl = (threads + 7) & ~7;                         // the folds work in groups of 8 lanes
+  TfProfScope prof_(TF_PROF_FAM_GROUP_NORM, (double)N * HW * C * 6.0, tf_hs(s));     // statistics pass (1 read) + apply (1 read + 1 write), 16-bit
   hipLaunchKernelGGL(k_gn_stats<T>, dim3(chunks, N), dim3(tl), (size_t)threads * 16 * sizeof(float), tf_hs(s), partial, (const T*)x,
                      (const T*)x2, HW, C1, C2, G, chunks, ppc, CV, RPB);
   TF_LAUNCH_CHECK();
@@ -444,6 +446,7 @@ int tf_group_norm_apply_f16(void* y, const void* x, const void* gamma, const voi
   int CV, RPB, threads, sc, ppc, ablocks, appb;
   gn_geometry(HW, C, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
   int tl = (threads + 7) & ~7;
+  TfProfScope prof_(TF_PROF_FAM_GROUP_NORM, (double)N * HW * C * 4.0, tf_hs(s));
   hipLaunchKernelGGL(k_gn_apply<0>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)nullptr,
                      (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
   TF_LAUNCH_CHECK();
@@ -473,6 +476,7 @@ static int gn_apply_8(void* y8, const void* x, const void* x2, const void* gamma
     int CV, RPB, threads, sc, ppc, ablocks, appb;
     gn_geometry(HW, C1, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
     int tl = (threads + 7) & ~7;
+    TfProfScope prof_(TF_PROF_FAM_GROUP_NORM, (double)N * HW * C1 * 3.0, tf_hs(s));         // fp16 in, e4m3 out
     if (mode == 2) hipLaunchKernelGGL(k_gn_apply<2>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y8, (const half_t*)x, (const half_t*)nullptr,
                        (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
     else hipLaunchKernelGGL(k_gn_apply<1>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y8, (const half_t*)x, (const half_t*)nullptr,
@@ -509,6 +513,7 @@ static int gn_apply_cat(void* y, const void* x, const void* x2, const void* gamm
   int CV, RPB, threads, sc, ppc, ablocks, appb;
   gn_geometry(HW, C, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
   int tl = (threads + 7) & ~7;
+  TfProfScope prof_(TF_PROF_FAM_GROUP_NORM, (double)N * HW * C * (out8 ? 3.0 : 4.0), tf_hs(s));
   if (out8 == 2) hipLaunchKernelGGL(k_gn_apply<2>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
                                (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB,
                                (const float*)partial2, chunks2, groups1, groups2, cpg / sub);

@@ -14,7 +14,61 @@ void tf_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- family profiling (common.h: TfProfScope) -----------------------------------------------------------------------------------
+#include <vector>
+bool g_tf_prof = false;
+float g_tf_prof_overhead_ms = 0.f;
+namespace {
+struct FamRec { hipEvent_t a, b; int fam; double work; };
+std::vector<FamRec> g_fam_pending;
+FamRec g_fam_open = {nullptr, nullptr, 0, 0.0};
+double g_fam_ms[TF_PROF_NFAM], g_fam_work[TF_PROF_NFAM];
+long long g_fam_n[TF_PROF_NFAM];
+}
+void tf_prof_fam_reset() {
+  for (auto& r : g_fam_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_fam_pending.clear();
+  for (int i = 0; i < TF_PROF_NFAM; ++i) { g_fam_ms[i] = 0.0; g_fam_work[i] = 0.0; g_fam_n[i] = 0; }
+}
+void tf_prof_fam_begin(int family, double work, hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cs);
+  g_fam_open = {nullptr, nullptr, 0, 0.0};
+  if (cs != hipStreamCaptureStatusNone || family < 1 || family >= TF_PROF_NFAM) return;     // (never inside a capture: an event pair there is a graph node)
+  FamRec r = {nullptr, nullptr, family, work};
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  (void)hipEventRecord(r.a, st);
+  g_fam_open = r;
+}
+void tf_prof_fam_end(hipStream_t st) {
+  if (!g_fam_open.fam) return;
+  (void)hipEventRecord(g_fam_open.b, st);
+  g_fam_pending.push_back(g_fam_open);
+  g_fam_open = {nullptr, nullptr, 0, 0.0};
+}
+void tf_prof_fam_add(int family, double work, double ms) {
+  if (family < 1 || family >= TF_PROF_NFAM) return;
+  g_fam_ms[family] += ms; g_fam_work[family] += work; g_fam_n[family] += 1;
+}
+
 extern "C" {
+
+int tf_prof_read_family(int family, double* ms, double* work, long long* launches) {
+  TF_REQUIRE(family >= 1 && family < TF_PROF_NFAM, "tf_prof_read_family: family=%d (1 GroupNorm, 2 split-K reduce, 3 LayerNorm, 4 SDPA)", family);
+  for (auto& r : g_fam_pending) {
+    float t = 0.f;
+    TF_HIP(hipEventSynchronize(r.b));
+    TF_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    t -= g_tf_prof_overhead_ms;
+    g_fam_ms[r.fam] += t > 0.f ? t : 0.f; g_fam_work[r.fam] += r.work; g_fam_n[r.fam] += 1;
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  g_fam_pending.clear();
+  if (ms) *ms = g_fam_ms[family];
+  if (work) *work = g_fam_work[family];
+  if (launches) *launches = g_fam_n[family];
+  return TF_OK;
+}
 
 const char* tf_last_error(void) { return g_err; }
 int tf_version(void) { return 100; }

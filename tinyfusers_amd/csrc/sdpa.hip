@@ -636,6 +636,7 @@ extern "C" int tf_sdpa_f16(void* o, const void* q, const void* k, const void* v,
   p.causal = causal;
   p.dbg = g_sdpa_dbg;
   hipStream_t st = tf_hs(s);
+  TfProfScope prof_(TF_PROF_FAM_SDPA, 4.0 * B * NH * (double)Tq * Tk * HS, st);      // (FLOPs = 4 B NH Tq Tk d)
   // K/V offsets inside a (batch, head) slice must fit the 32-bit buffer offsets of the DMA kernels
   const bool small = ((long long)Tk * k_st + HS) * 2 < (1ll << 31) && ((long long)Tk * v_st + HS) * 2 < (1ll << 31);
   if (small && !g_sdpa_generic) {
