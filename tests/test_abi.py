@@ -86,3 +86,21 @@ def test_shipped_library_holds_no_ablation_kernel(native):
     assert native.lib.tf_gemm_debug(512) == 0 and native.lib.tf_gemm_debug(0) == 0   # (variant selection is a test hook, not an ablation)
     src = open(os.path.join(ROOT, "tinyfusers_amd", "csrc", "sdpa.hip")).read()
     assert re.search(r"#ifdef TF_ABLATION\s*\nstatic int g_sdpa_dbg = getenv", src)   # TF_SDPA_DBG is read by the ablation build only
+
+
+def test_host_code_is_clean_under_asan_ubsan():
+    """SURVEY 5 "race detection / sanitizers": the host side of the library (table loader, run_gemm's tile logic, shape predicates, status
+    paths, tf_rtc_* / tf_comm_* argument handling) under AddressSanitizer + UndefinedBehaviorSanitizer -- `python -m tinyfusers_amd.build
+    --asan-host` builds lib/libtinyfusers_hip_asan.so (device code unsanitised; CPU container only), tests/aux/host_sanitizer_drive.py drives
+    it in a child process with the ASan runtime preloaded; any finding aborts the child.  Skips where that library has not been built."""
+    import subprocess
+    import sys
+    from tinyfusers_amd import build as b
+    if not os.path.exists(b.LIB_ASAN):
+        pytest.skip("lib/libtinyfusers_hip_asan.so not built (python -m tinyfusers_amd.build --asan-host)")
+    srcs = [os.path.join(b.CSRC, f) for f in os.listdir(b.CSRC)]
+    if any(os.path.getmtime(f) > os.path.getmtime(b.LIB_ASAN) for f in srcs):
+        pytest.skip("lib/libtinyfusers_hip_asan.so is older than the sources: rebuild it with --asan-host")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "aux", "host_sanitizer_drive.py")], env=b.sanitizer_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "HOST_SANITIZER_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr, r.stderr[-4000:]
