@@ -361,8 +361,8 @@ int tf_layer_norm_f16(void* y, const void* x, const void* gamma, const void* bet
  * The reference's op tests run every case in bfloat16 as well as float16 (tests/group_norm.py:12-19 and
  * tests/layer_norm.py:13-27 with atol = rtol = 0.125; tests/linear.py:13 lists it): the same four operators with every
  * 16-bit tensor (x, x2, w, gamma, beta, bias, residual, y) holding bfloat16.  Statistics and accumulation are fp32 as
- * in the float16 forms; the GEMMs use the gfx950 bf16 MFMA (v_mfma_f32_16x16x32_bf16), one launch, no split-K.
- * The UNet step itself stays float16 (the reference's weights and activations are float16, storage/tensor.py). */
+ * in the float16 forms; the GEMMs use the gfx950 bf16 MFMA (v_mfma_f32_16x16x32_bf16) on the tuned kernels of the float16 forms (round 5; these
+ * entries take no workspace, so they never split K: tf_linear_16 / tf_conv2d_fused_16 below are the full forms). */
 int tf_group_norm_bf16(void* y, const void* x, const void* x2, const void* gamma, const void* beta, int N, int HW,
                        int C1, int C2, int G, float eps, int silu, void* workspace, size_t workspace_bytes, tfStream_t s);
 int tf_layer_norm_bf16(void* y, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, tfStream_t s);
@@ -371,8 +371,8 @@ int tf_linear_bf16(void* y, const void* x, const void* w, const void* bias, cons
 /* tf_conv2d_f16's arguments without the workspace (vision/conv2d.py:9-28): NHWC x (+ concat x2), w (Cout, R, S, C1 + C2) */
 /* the bfloat16 STEP (round 4: config.set_dtype("bf16"), bench.py --dtype bf16): the sampler on bfloat16 tensors throughout -- conv / linear /
  * GEGLU on the bf16 MFMA (tf_conv2d_bf16, tf_linear_act_bf16), GroupNorm / LayerNorm / SiLU in bfloat16, the time-embedding chain, CFG duplicate
- * and the CFG + DDIM update reading bfloat16 (vision/unet.py:51-97, variants/sd.py:14-46); the attention core stays the fp16 kernel behind one
- * conversion in and one out (tf_convert_*) */
+ * and the CFG + DDIM update reading bfloat16 (vision/unet.py:51-97, variants/sd.py:14-46); since round 5 the step runs on the dtype-tagged fused
+ * entries below (tf_*_16) and attention is native bfloat16 (tf_sdpa_16); tf_convert_* remain for callers that mix the types */
 int tf_linear_act_bf16(void* y, const void* x, const void* w, const void* bias, const void* residual, int M, int N, int K, int act, tfStream_t s);
 int tf_silu_bf16(void* y, const void* x, long long n, tfStream_t s);
 int tf_convert_f16_to_bf16(void* y_bf16, const void* x_f16, long long n, tfStream_t s);
@@ -383,6 +383,46 @@ int tf_cfg_ddim_step_bf16(void* latent, const void* eps2, const void* params, in
 int tf_conv2d_bf16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
                    const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
                    tfStream_t s);
+
+/* ---- dtype-tagged forms of the step's fused entries (round 5): the bfloat16 step runs the SAME structure as the float16 step -- every fusion,
+ * split-K, the tuned tiles -- so each of these is its _f16 namesake (same arguments, same semantics, same reference lines) with one leading tag
+ * saying what every 16-bit tensor of the call holds: TF_DTYPE_F16 (= the _f16 entry) or TF_DTYPE_BF16 (v_mfma_f32_16x16x32_bf16; fp32 accumulation,
+ * statistics and split-K partial slabs).  The reference's own op tests run bfloat16 next to float16 (tests/group_norm.py:12-19, tests/layer_norm.py:12-19,
+ * tests/linear.py:13).  tf_sdpa_16: attention natively in bfloat16 (Q K^T and P V on the bf16 MFMA, P rounded to bfloat16): no fp16 hop, so
+ * activations beyond 65504 stay finite. */
+#define TF_DTYPE_F16 0
+#define TF_DTYPE_BF16 1
+int tf_conv2d_fused_16(int dtype, void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
+                       const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
+                       void* workspace, size_t workspace_bytes, const void* x3, const void* x4, int C3, int C4, void* gn_partial,
+                       size_t gn_partial_bytes, int gn_groups, int* gn_chunks, tfStream_t s);
+int tf_conv2d_fused_norm_16(int dtype, void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
+                            const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
+                            void* workspace, size_t workspace_bytes, const void* x3, const void* x4, int C3, int C4, void* gn_partial,
+                            size_t gn_partial_bytes, int gn_groups, int* gn_chunks, void* z, const void* z_gamma, const void* z_beta, float z_eps,
+                            int z_silu, int* z_written, tfStream_t s);
+int tf_conv2d_gn_16(int dtype, void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
+                    const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
+                    void* workspace, size_t workspace_bytes, const void* x3, const void* x4, int C3, int C4, void* gn_partial,
+                    size_t gn_partial_bytes, int gn_groups, int* gn_chunks, const void* in_gamma, const void* in_beta, const void* in_partial,
+                    int in_chunks, int in_groups1, const void* in_partial2, int in_chunks2, int in_groups2, int in_groups, float in_eps, int in_silu,
+                    tfStream_t s);
+int tf_linear_16(int dtype, void* y, const void* x, const void* w, const void* bias, const void* residual, int M, int N, int K, int act,
+                 void* workspace, size_t workspace_bytes, tfStream_t s);
+int tf_ln_fold_weights_16(int dtype, void* w_out, void* bias_out, void* colsum_out_f32, const void* w, const void* bias, const void* gamma, const void* beta,
+                          int N, int K, tfStream_t s);
+int tf_linear_ln_16(int dtype, void* y, const void* x, const void* w_folded, const void* bias_folded, const void* colsum_f32, const void* residual,
+                    int M, int N, int K, int act, float eps, tfStream_t s);
+int tf_gemv_16(int dtype, void* y, const void* x, const void* w, const void* bias, int M, int N, int K, int silu_input, tfStream_t s);
+int tf_sdpa_16(int dtype, void* o, const void* q, const void* k, const void* v, int B, int NH, int Tq, int Tk, int HS,
+               long long q_sb, long long q_sh, long long q_st, long long k_sb, long long k_sh, long long k_st,
+               long long v_sb, long long v_sh, long long v_st, long long o_sb, long long o_sh, long long o_st, int causal, tfStream_t s);
+int tf_group_norm_apply_16(int dtype, void* y, const void* x, const void* gamma, const void* beta, const void* partial, int chunks,
+                           int N, int HW, int C, int G, float eps, int silu, tfStream_t s);
+int tf_group_norm_apply_cat_16(int dtype, void* y, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial, int chunks,
+                               int groups1, const void* partial2, int chunks2, int groups2, int N, int HW, int C1, int C2, int G, float eps,
+                               int silu, tfStream_t s);
+int tf_add_16(int dtype, void* y, const void* a, const void* b, long long n, tfStream_t s);
 
 /* ---- elementwise (storage/tensor.py:64-86; ff/nn.py:10-12; vision/unet.py:72, :81-83) ---------- */
 int tf_silu_f16(void* y, const void* x, long long n, tfStream_t s);

@@ -21,12 +21,14 @@ LIB_ABLATION = os.path.join(LIBDIR, "libtinyfusers_hip_ablation.so")
 LIB_ASAN = os.path.join(LIBDIR, "libtinyfusers_hip_asan.so")
 ASAN_FLAGS = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g", "-fno-sanitize-recover=undefined"]
 # the GEMM family is one translation unit per kernel family (gemm_k_*.hip) so that its instances compile in parallel; the largest first
-SOURCES = ["gemm_k_pp16.hip", "gemm_k_pp8.hip", "gemm_k_igemm_128.hip", "gemm_k_igemm_64.hip", "gemm_k_igemm_160.hip", "gemm_k_patch.hip", "sdpa.hip",
-           "gemm_k_igemm8.hip", "gemm_k_c4.hip", "gemm_k_pp3.hip", "gemm.hip", "norm.hip", "elementwise.hip", "runtime.hip", "sgemm.hip", "comm.hip", "rtc.hip"]
+SOURCES = ["gemm_k_pp16.hip", "gemm_k_pp16_bf16.hip", "gemm_k_pp8.hip", "gemm_k_igemm_128.hip", "gemm_k_igemm_128_bf16.hip", "gemm_k_igemm_64.hip", "gemm_k_igemm_64_bf16.hip",
+           "gemm_k_igemm_160.hip", "gemm_k_igemm_160_bf16.hip", "gemm_k_patch.hip", "gemm_k_patch_bf16.hip", "sdpa.hip", "sdpa_bf16.hip",
+           "gemm_k_igemm8.hip", "gemm_k_c4.hip", "gemm_k_c4_bf16.hip", "gemm_k_pp3.hip", "gemm_k_pp3_bf16.hip", "gemm.hip", "norm.hip", "elementwise.hip", "runtime.hip", "sgemm.hip",
+           "comm.hip", "rtc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-ffp-contract=fast"]
 # sdpa.hip: keep the MFMA accumulators in VGPRs (the softmax reads every score: no v_accvgpr_read traffic) and drop
 # the NaN-canonicalising v_max in front of every fmaxf on MFMA outputs (scores are never NaN; -inf masks still work)
-EXTRA = {"sdpa.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}
+EXTRA = {"sdpa.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"], "sdpa_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}
 
 
 def _hipcc():
@@ -67,7 +69,8 @@ def build(force=False, verbose=False, ablation=False, tag=None, defs=(), asan_ho
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src] + headers):
+        twin = [os.path.join(CSRC, s.replace("_bf16.hip", ".hip"))] if s.endswith("_bf16.hip") else []
+        if force or _stale(obj, [src] + twin + headers):
             jobs.append([hipcc] + FLAGS + (["-DTF_ABLATION"] if ablation else []) + (ASAN_FLAGS if asan_host else []) + list(defs) + EXTRA.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):

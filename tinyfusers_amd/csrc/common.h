@@ -112,5 +112,58 @@ __device__ __forceinline__ uint2 mx_quant8(f4 v0, f4 v1, unsigned& scale_byte) {
   return make_uint2((unsigned)lo, (unsigned)hi);
 }
 
+typedef bf16_t b8v __attribute__((ext_vector_type(8)));   // MFMA operand of the bfloat16 instances (same register image as h8)
+// ---- element type of a launch's 16-bit tensors: float16 (BF = false) or bfloat16 (BF = true: GemmP::bf16, round 5 -- every kernel of the family
+// has both forms, the bfloat16 instances in translation units of their own, gemm_k_*_bf16.hip).  Registers and LDS hold the elements in h8 / h4 /
+// half_t CONTAINERS either way (the loaders move bytes); only these helpers look inside.
+template <bool BF> __device__ __forceinline__ f4 mfma16(h8 a, h8 b, f4 c) {
+  if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8v, a), __builtin_bit_cast(b8v, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+template <bool BF> __device__ __forceinline__ float e2f(half_t raw) {
+  if constexpr (BF) return (float)__builtin_bit_cast(bf16_t, raw);
+  else return (float)raw;
+}
+template <bool BF> __device__ __forceinline__ half_t f2e(float f) {
+  if constexpr (BF) return __builtin_bit_cast(half_t, (bf16_t)f);        // (v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN)
+  else return (half_t)f;
+}
+// (sum, sum of squares) of the 8 elements of x added to (s, q): 8 v_dot2 (LayerNorm fold: row statistics from staged / fragment data)
+template <bool BF> __device__ __forceinline__ void dot2_stats(h8 x, float& s, float& q) {
+  if constexpr (BF) {
+    typedef bf16_t bb2 __attribute__((ext_vector_type(2)));
+    const b8v xb = __builtin_bit_cast(b8v, x);
+    const bb2 one2 = {(bf16_t)1.0f, (bf16_t)1.0f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bb2 v = {xb[2 * e], xb[2 * e + 1]};
+      s = __builtin_amdgcn_fdot2_f32_bf16(v, one2, s, false);
+      q = __builtin_amdgcn_fdot2_f32_bf16(v, v, q, false);
+    }
+  } else {
+    typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+    const hh2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hh2 v = {x[2 * e], x[2 * e + 1]};
+      s = __builtin_amdgcn_fdot2(v, one2, s, false);
+      q = __builtin_amdgcn_fdot2(v, v, q, false);
+    }
+  }
+}
+
+// The bfloat16 instances live in translation units of their own -- gemm_k_<family>_bf16.hip / sdpa_bf16.hip = `#define TF_TU_BF 1` + `#include` of the fp16
+// unit -- so that the fp16 code objects are byte for byte what they were without them: in such a unit kBF is true and every launcher name
+// carries the suffix _bf16 (TFK).
+#ifndef TF_TU_BF
+#define TF_TU_BF 0
+#endif
+#if TF_TU_BF
+#define TFK(name) name##_bf16
+#else
+#define TFK(name) name
+#endif
+static constexpr bool kBF = TF_TU_BF != 0;
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }

@@ -54,18 +54,20 @@ __global__ void __launch_bounds__(EW_BLOCK) k_convert16(TO* __restrict__ y, cons
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) { long long i = (nvec << 3) + threadIdx.x; y[i] = (TO)(float)x[i]; }
 }
 
-__global__ void __launch_bounds__(EW_BLOCK) k_add(half_t* __restrict__ y, const half_t* __restrict__ a, const half_t* __restrict__ b, long long n) {
+template <typename T = half_t>
+__global__ void __launch_bounds__(EW_BLOCK) k_add(T* __restrict__ y, const T* __restrict__ a, const T* __restrict__ b, long long n) {
+  typedef T T8 __attribute__((ext_vector_type(8)));
   long long nvec = n >> 3;
   long long stride = (long long)gridDim.x * EW_BLOCK;
   for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < nvec; i += stride) {
-    h8 u = *reinterpret_cast<const h8*>(a + i * 8), v = *reinterpret_cast<const h8*>(b + i * 8), o;
+    T8 u = *reinterpret_cast<const T8*>(a + i * 8), v = *reinterpret_cast<const T8*>(b + i * 8), o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)u[j] + (float)v[j]);
-    *reinterpret_cast<h8*>(y + i * 8) = o;
+    for (int j = 0; j < 8; ++j) o[j] = (T)((float)u[j] + (float)v[j]);
+    *reinterpret_cast<T8*>(y + i * 8) = o;
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
     long long i = (nvec << 3) + threadIdx.x;
-    y[i] = (half_t)((float)a[i] + (float)b[i]);
+    y[i] = (T)((float)a[i] + (float)b[i]);
   }
 }
 
@@ -387,7 +389,16 @@ EW_UNARY(tf_quick_gelu_f16, OP_QGELU)
 int tf_add_f16(void* y, const void* a, const void* b, long long n, tfStream_t s) {
   TF_REQUIRE(y && a && b && n >= 0, "tf_add_f16: bad arguments");
   if (n == 0) return TF_OK;
-  hipLaunchKernelGGL(k_add, dim3(ew_grid(n >> 3)), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)y, (const half_t*)a, (const half_t*)b, n);
+  hipLaunchKernelGGL(k_add<half_t>, dim3(ew_grid(n >> 3)), dim3(EW_BLOCK), 0, tf_hs(s), (half_t*)y, (const half_t*)a, (const half_t*)b, n);
+  TF_LAUNCH_CHECK();
+  return TF_OK;
+}
+int tf_add_16(int dtype, void* y, const void* a, const void* b, long long n, tfStream_t s) {
+  if (dtype == TF_DTYPE_F16) return tf_add_f16(y, a, b, n, s);
+  TF_REQUIRE(dtype == TF_DTYPE_BF16, "tf_add_16: dtype=%d (0 = float16, 1 = bfloat16)", dtype);
+  TF_REQUIRE(y && a && b && n >= 0, "tf_add_16: bad arguments");
+  if (n == 0) return TF_OK;
+  hipLaunchKernelGGL(k_add<bf16_t>, dim3(ew_grid(n >> 3)), dim3(EW_BLOCK), 0, tf_hs(s), (bf16_t*)y, (const bf16_t*)a, (const bf16_t*)b, n);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }

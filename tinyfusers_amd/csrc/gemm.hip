@@ -36,7 +36,8 @@ __device__ __forceinline__ f4 sum_partials(const PT* __restrict__ partial, long 
   return sum_partials_nb<PT, 8>(partial, total, e0, splitk);
 }
 // split-K reduce + epilogue: y[m,n] = sum_z partial[z,m,n] + bias + bias_nc + residual   (N % 4 == 0 fast path)
-template <typename PT>
+// BF: bias / bias_nc / residual / gamma / beta / y / z hold bfloat16 (containers as in gemm_common.h: e2f / f2e)
+template <typename PT, bool BF = false>
 __global__ void __launch_bounds__(256) k_splitk_reduce(half_t* __restrict__ y, const PT* __restrict__ partial, const half_t* __restrict__ bias,
                                                        const half_t* __restrict__ bias_nc, const half_t* __restrict__ residual, int M, int N,
                                                        int HoWo, int splitk, long long bnc_stride) {
@@ -48,11 +49,11 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(half_t* __restrict__ y, c
       long long e0 = i << 2;
       int m = (int)(e0 / N), n = (int)(e0 - (long long)m * N);
       f4 v = sum_partials<PT>(partial, total, e0, splitk);
-      if (bias) { h4 b = *reinterpret_cast<const h4*>(bias + n); for (int e = 0; e < 4; ++e) v[e] += (float)b[e]; }
-      if (bias_nc) { h4 b = *reinterpret_cast<const h4*>(bias_nc + (long long)(m / HoWo) * bnc_stride + n); for (int e = 0; e < 4; ++e) v[e] += (float)b[e]; }
-      if (residual) { h4 b = *reinterpret_cast<const h4*>(residual + e0); for (int e = 0; e < 4; ++e) v[e] += (float)b[e]; }
+      if (bias) { h4 b = *reinterpret_cast<const h4*>(bias + n); for (int e = 0; e < 4; ++e) v[e] += e2f<BF>(b[e]); }
+      if (bias_nc) { h4 b = *reinterpret_cast<const h4*>(bias_nc + (long long)(m / HoWo) * bnc_stride + n); for (int e = 0; e < 4; ++e) v[e] += e2f<BF>(b[e]); }
+      if (residual) { h4 b = *reinterpret_cast<const h4*>(residual + e0); for (int e = 0; e < 4; ++e) v[e] += e2f<BF>(b[e]); }
       h4 o;
-      for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+      for (int e = 0; e < 4; ++e) o[e] = f2e<BF>(v[e]);
       *reinterpret_cast<h4*>(y + e0) = o;
     }
   } else {
@@ -60,10 +61,10 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(half_t* __restrict__ y, c
       int m = (int)(i / N), n = (int)(i - (long long)m * N);
       float v = 0.f;
       for (int z = 0; z < splitk; ++z) v += (float)partial[(long long)z * total + i];
-      if (bias) v += (float)bias[n];
-      if (bias_nc) v += (float)bias_nc[(long long)(m / HoWo) * bnc_stride + n];
-      if (residual) v += (float)residual[i];
-      y[i] = (half_t)v;
+      if (bias) v += e2f<BF>(bias[n]);
+      if (bias_nc) v += e2f<BF>(bias_nc[(long long)(m / HoWo) * bnc_stride + n]);
+      if (residual) v += e2f<BF>(residual[i]);
+      y[i] = f2e<BF>(v);
     }
   }
 }
@@ -72,7 +73,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(half_t* __restrict__ y, c
 // whole output rows (R = HoWo / chunks); thread t owns column quad t % nq and the rows r = t / nq (mod RL), so the
 // per-channel sums stay in its registers; row lanes and channels -> groups meet through LDS in a fixed order.
 // The split partials of an element are fetched 8 at a time (independent loads) and added in split order.
-template <typename PT>
+template <typename PT, bool BF = false>
 __global__ void __launch_bounds__(1024) k_splitk_reduce_gn(half_t* __restrict__ y, const PT* __restrict__ partial, const half_t* __restrict__ bias,
                                                            const half_t* __restrict__ bias_nc, const half_t* __restrict__ residual, int M, int N,
                                                            int HoWo, int splitk, long long bnc_stride, float* __restrict__ gn_part, int G, int cpg,
@@ -86,7 +87,7 @@ __global__ void __launch_bounds__(1024) k_splitk_reduce_gn(half_t* __restrict__ 
     const int n = q0 << 2;
     f4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
     f4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (bias) { h4 b = *reinterpret_cast<const h4*>(bias + n); for (int e = 0; e < 4; ++e) bv[e] = (float)b[e]; }
+    if (bias) { h4 b = *reinterpret_cast<const h4*>(bias + n); for (int e = 0; e < 4; ++e) bv[e] = e2f<BF>(b[e]); }
     for (int r = rl; r < R; r += RL) {
       const int m = m_first + r;
       const long long e0 = (long long)m * N + n;
@@ -95,10 +96,10 @@ __global__ void __launch_bounds__(1024) k_splitk_reduce_gn(half_t* __restrict__ 
       if (residual) res = *reinterpret_cast<const h4*>(residual + e0);
       f4 v = sum_partials<PT>(partial, total, e0, splitk);
       v += bv;
-      for (int e = 0; e < 4; ++e) v[e] += (float)bnc[e];
-      for (int e = 0; e < 4; ++e) v[e] += (float)res[e];
+      for (int e = 0; e < 4; ++e) v[e] += e2f<BF>(bnc[e]);
+      for (int e = 0; e < 4; ++e) v[e] += e2f<BF>(res[e]);
       h4 o;
-      for (int e = 0; e < 4; ++e) { o[e] = (half_t)v[e]; float f = (float)o[e]; cs[e] += f; cq[e] += f * f; }
+      for (int e = 0; e < 4; ++e) { o[e] = f2e<BF>(v[e]); float f = e2f<BF>(o[e]); cs[e] += f; cq[e] += f * f; }
       *reinterpret_cast<h4*>(y + e0) = o;
     }
     float* ch = chan + (long long)rl * N * 2;
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(1024) k_splitk_reduce_gn(half_t* __restrict__ 
 // residual, rounded to fp16 (y, optional), per-channel sums in registers -> LDS -> fixed-order fold -> (mean, rstd) -> z = silu?(y a + b).
 // Also leaves the (sum, sum of squares) of every group as a one-chunk partial table, so y.gn stays available to later consumers.
 #define RGA_MAXR 8
-template <typename PT>
+template <typename PT, bool BF = false>
 __global__ void __launch_bounds__(1024) k_splitk_reduce_gn_apply(half_t* __restrict__ y, half_t* __restrict__ z, const PT* __restrict__ partial,
                                                                  const half_t* __restrict__ bias, const half_t* __restrict__ bias_nc,
                                                                  const half_t* __restrict__ residual, int M, int N, int HoWo, int splitk, long long bnc_stride,
@@ -146,9 +147,9 @@ __global__ void __launch_bounds__(1024) k_splitk_reduce_gn_apply(half_t* __restr
   const long long total = (long long)M * N;
   f4 bv = {0.f, 0.f, 0.f, 0.f};
   h4 bnc = {0, 0, 0, 0};
-  h4 gm = {1, 1, 1, 1}, bt = {0, 0, 0, 0};               // (fetched here, under the partials' latency: behind the block barriers they would be one more serial L2 round trip)
+  h4 gm = {f2e<BF>(1.f), f2e<BF>(1.f), f2e<BF>(1.f), f2e<BF>(1.f)}, bt = {0, 0, 0, 0};               // (fetched here, under the partials' latency: behind the block barriers they would be one more serial L2 round trip)
   if (act) {
-    if (bias) { h4 b = *reinterpret_cast<const h4*>(bias + n); for (int e = 0; e < 4; ++e) bv[e] = (float)b[e]; }
+    if (bias) { h4 b = *reinterpret_cast<const h4*>(bias + n); for (int e = 0; e < 4; ++e) bv[e] = e2f<BF>(b[e]); }
     if (bias_nc) bnc = *reinterpret_cast<const h4*>(bias_nc + (long long)img * bnc_stride + n);
     if (gamma) { gm = *reinterpret_cast<const h4*>(gamma + n); bt = *reinterpret_cast<const h4*>(beta + n); }
   }
@@ -164,10 +165,10 @@ __global__ void __launch_bounds__(1024) k_splitk_reduce_gn_apply(half_t* __restr
       if (residual) res = *reinterpret_cast<const h4*>(residual + e0);
       f4 acc = sum_partials<PT>(partial, total, e0, splitk);
       acc += bv;
-      for (int e = 0; e < 4; ++e) acc[e] += (float)bnc[e];
-      for (int e = 0; e < 4; ++e) acc[e] += (float)res[e];
+      for (int e = 0; e < 4; ++e) acc[e] += e2f<BF>(bnc[e]);
+      for (int e = 0; e < 4; ++e) acc[e] += e2f<BF>(res[e]);
       h4 o;
-      for (int e = 0; e < 4; ++e) { o[e] = (half_t)acc[e]; float f = (float)o[e]; cs[e] += f; cq[e] += f * f; }
+      for (int e = 0; e < 4; ++e) { o[e] = f2e<BF>(acc[e]); float f = e2f<BF>(o[e]); cs[e] += f; cq[e] += f * f; }
       out[k] = o;
       if (y) *reinterpret_cast<h4*>(y + e0) = o;
     }
@@ -216,8 +217,8 @@ __global__ void __launch_bounds__(1024) k_splitk_reduce_gn_apply(half_t* __restr
   {
     for (int e = 0; e < 4; ++e) {
       const int g = (v * 4 + e) / cpg;
-      a[e] = st[2 * g + 1] * (float)gm[e];
-      b[e] = (float)bt[e] - st[2 * g] * a[e];
+      a[e] = st[2 * g + 1] * e2f<BF>(gm[e]);
+      b[e] = e2f<BF>(bt[e]) - st[2 * g] * a[e];
     }
   }
 #pragma unroll
@@ -225,7 +226,7 @@ __global__ void __launch_bounds__(1024) k_splitk_reduce_gn_apply(half_t* __restr
     const int r = rl + k * RPS;
     if (r < HoWo) {
       h4 o;
-      for (int e = 0; e < 4; ++e) { float f = (float)out[k][e] * a[e] + b[e]; o[e] = (half_t)(do_silu ? silu_f(f) : f); }
+      for (int e = 0; e < 4; ++e) { float f = e2f<BF>(out[k][e]) * a[e] + b[e]; o[e] = f2e<BF>(do_silu ? silu_f(f) : f); }
       *reinterpret_cast<h4*>(z + ((long long)img * HoWo + r) * N + n) = o;
     }
   }
@@ -301,6 +302,7 @@ __global__ void __launch_bounds__(256) k_pack_weight_fp8(unsigned char* __restri
 }
 
 // ---- weight-streaming GEMV for M <= 8 (time-embedding MLP, ResBlock emb_layers): one wave per output row
+template <bool BF = false>
 __global__ void __launch_bounds__(256) k_gemv(half_t* __restrict__ y, const half_t* __restrict__ x, const half_t* __restrict__ w,
                                               const half_t* __restrict__ bias, int M, int N, int K, int silu_in) {
   int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -318,9 +320,9 @@ __global__ void __launch_bounds__(256) k_gemv(half_t* __restrict__ y, const half
         h8 xv = *reinterpret_cast<const h8*>(x + (long long)m * K + k);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float xf = (float)xv[j];
+          float xf = e2f<BF>(xv[j]);
           if (silu_in) xf = silu_f(xf);
-          acc[m] += xf * (float)wv8[j];
+          acc[m] += xf * e2f<BF>(wv8[j]);
         }
       }
     }
@@ -329,13 +331,14 @@ __global__ void __launch_bounds__(256) k_gemv(half_t* __restrict__ y, const half
   for (int m = 0; m < 8; ++m) {
     if (m < M) {
       float v = wave_sum(acc[m]);
-      if (l == 0) y[(long long)m * N + n] = (half_t)(v + (bias ? (float)bias[n] : 0.f));
+      if (l == 0) y[(long long)m * N + n] = f2e<BF>(v + (bias ? e2f<BF>(bias[n]) : 0.f));
     }
   }
 }
 
 // LayerNorm fold of a Linear weight (one wave per output row n):
 //   w'[n,k] = fp16(w[n,k] * gamma[k]);  colsum[n] = sum_k float(w'[n,k]);  bias'[n] = sum_k beta[k] * w[n,k] + bias[n]
+template <bool BF = false>
 __global__ void __launch_bounds__(256) k_ln_fold(half_t* __restrict__ wo, half_t* __restrict__ bo, float* __restrict__ colsum, const half_t* __restrict__ w,
                                                  const half_t* __restrict__ bias, const half_t* __restrict__ gamma, const half_t* __restrict__ beta, int N, int K) {
   int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -346,14 +349,14 @@ __global__ void __launch_bounds__(256) k_ln_fold(half_t* __restrict__ wo, half_t
     h8 v = *reinterpret_cast<const h8*>(w + (long long)n * K + k), g = *reinterpret_cast<const h8*>(gamma + k), b = *reinterpret_cast<const h8*>(beta + k), o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      o[j] = (half_t)((float)v[j] * (float)g[j]);
-      cs += (float)o[j];
-      bs += (float)b[j] * (float)v[j];
+      o[j] = f2e<BF>(e2f<BF>(v[j]) * e2f<BF>(g[j]));
+      cs += e2f<BF>(o[j]);
+      bs += e2f<BF>(b[j]) * e2f<BF>(v[j]);
     }
     *reinterpret_cast<h8*>(wo + (long long)n * K + k) = o;
   }
   cs = wave_sum(cs); bs = wave_sum(bs);
-  if (l == 0) { colsum[n] = cs; bo[n] = (half_t)(bs + (bias ? (float)bias[n] : 0.f)); }
+  if (l == 0) { colsum[n] = cs; bo[n] = f2e<BF>(bs + (bias ? e2f<BF>(bias[n]) : 0.f)); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -432,7 +435,7 @@ static bool patch_setup(GemmP& p, int bm, int bn) {
 static bool pp_ok(const GemmP& p, int bn, int bm = 256) {
   if (bn != 128 && bn != 160 && bn != 256) return false;
   if (bm != 256 && !(bm == 192 && bn != 256)) return false;
-  if (p.bf16 || p.gi_part || gemm_generic(p)) return false;
+  if ((p.bf16 && p.fp8) || p.gi_part || gemm_generic(p)) return false;
   if (p.ln_colsum && (p.fp8 || p.S != 1 || p.stride != 1 || p.ups)) return false;   // the LayerNorm fold: linears, fp16
   if (p.fp8) {
     // the e4m3 form: block-scaled activations only, the lean addressing only (stride 1, no up-sampling), a whole K tile's fragments in
@@ -454,7 +457,7 @@ static int stats_bm(int bm, int variant) { return (variant == 4 || variant == 6)
 // e4m3 on the 128-channel grid; two patch buffers + three weight slots in LDS
 static bool pp3_setup(GemmP& p, int bm, int bn) {
   if (bm != 192 || bn != ((p.Wo == 96 && !p.fp8) ? 160 : 128)) return false;                          // the instantiated (output row length, tile width) pairs
-  if (p.bf16 || p.gi_part || p.ln_colsum || p.act || p.out8 || p.out32 || gemm_generic(p)) return false;
+  if ((p.bf16 && p.fp8) || p.gi_part || p.ln_colsum || p.act || p.out8 || p.out32 || gemm_generic(p)) return false;
   // e4m3: block-scaled, 128-channel slabs; a channel count on the 64 grid (one source tensor, its last slab half full) has instances for 96 / 48-pixel rows
   if (p.fp8 && (!p.mx || ((p.C1 % 128) && (p.C2 || p.Wo == 24)) || (p.C2 % 128))) return false;
   if (p.S != 3 || p.Kc != 9 * p.C || p.K != p.Kc + p.C3 + p.C4 || p.stride != 1 || p.pad != 1) return false;
@@ -466,7 +469,7 @@ static bool pp3_setup(GemmP& p, int bm, int bn) {
 // k_gemm_c4 (variant 5): the persistent short-K kernel -- linears / 1x1 stride-1 convolutions of fp16 operands whose channel counts sit on
 // the 64 grid, one launch (no split-K), no statistics, no time-embedding bias; bias, residual, GEGLU and the LayerNorm fold ride along
 static bool c4_ok(const GemmP& p) {
-  if (p.fp8 || p.bf16 || p.gi_part || p.gn_part || p.bias_nc || p.out32 || p.out8 || p.on_z) return false;
+  if (p.fp8 || p.gi_part || p.gn_part || p.bias_nc || p.out32 || p.out8 || p.on_z) return false;
   if (p.S != 1 || p.stride != 1 || p.pad != 0 || p.ups || p.C3 || p.C4 || p.K != p.Kc) return false;
   if ((p.C1 % 64) || (p.C2 % 64) || (p.N % 8) || p.M < 1) return false;
   return p.act == 0 || (p.act == 1 && p.N % 64 == 0);
@@ -517,7 +520,7 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
   p.ktiles_per_split = (p.ktiles + c.splitk - 1) / c.splitk;
   p.splitk = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
   p.partial = (float*)workspace;
-  p.part16 = (g_part16 && p.splitk > 1 && (p.N & 7) == 0) ? 1 : 0;     // 16-byte rows segments of halves; other widths keep fp32 slabs
+  p.part16 = (g_part16 && !p.bf16 && p.splitk > 1 && (p.N & 7) == 0) ? 1 : 0;     // 16-byte rows segments of halves; other widths -- and the bfloat16 launches, whose partials may leave fp16's range -- keep fp32 slabs
   p.ntm = (p.M + c.bm - 1) / c.bm;
   p.ntn = (p.N + c.bn - 1) / c.bn;
   float* gn_part = p.gn_part;
@@ -526,26 +529,27 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
     if (p.splitk > 1) { p.gn_chunks = gn_reduce_chunks(p.HoWo); p.gn_part = nullptr; }
     else p.gn_chunks = gn_pieces(p, c.bn) * (p.HoWo / stats_bm(c.bm, variant));
   }
-  if (p.bf16) rc = tfk_launch_igemm_bf16(p, st, c.bm, c.bn);
-  else if (p.mx && variant != 4 && variant != 6) { tf_set_error("run_gemm: block-scaled e4m3 operands run on the ping-pong kernel only (variant %d, tile %dx%d)", variant, c.bm, c.bn); return TF_E_UNSUPPORTED; }
+  const bool bf = p.bf16 != 0;
+  if (bf && p.fp8) { tf_set_error("run_gemm: e4m3 operands with bfloat16 outputs: no such kernel"); return TF_E_UNSUPPORTED; }
+  if (p.mx && variant != 4 && variant != 6) { tf_set_error("run_gemm: block-scaled e4m3 operands run on the ping-pong kernel only (variant %d, tile %dx%d)", variant, c.bm, c.bn); return TF_E_UNSUPPORTED; }
   else if (p.fp8 && variant != 4 && variant != 6) rc = tfk_launch_igemm8(p, st, c.bm, c.bn);
   else if (variant == 4) {
     if (!pp_ok(p, c.bn, c.bm)) { tf_set_error("run_gemm: the ping-pong kernel cannot run tile %dx%d of this launch", c.bm, c.bn); return TF_E_UNSUPPORTED; }
-    rc = p.fp8 ? tfk_launch_pp8(p, st, c.bm, c.bn) : tfk_launch_pp16(p, st, c.bm, c.bn, g_pp_np);
+    rc = p.fp8 ? tfk_launch_pp8(p, st, c.bm, c.bn) : bf ? tfk_launch_pp16_bf16(p, st, c.bm, c.bn, g_pp_np) : tfk_launch_pp16(p, st, c.bm, c.bn, g_pp_np);
   }
   else if (variant == 5) {
     if (!c4_ok(p) || c.bm != 128 || c.bn != 128 || p.splitk != 1) { tf_set_error("run_gemm: the persistent short-K kernel cannot run this launch (tile %dx%d, split %d)", c.bm, c.bn, p.splitk); return TF_E_UNSUPPORTED; }
-    rc = tfk_launch_c4(p, st);
+    rc = bf ? tfk_launch_c4_bf16(p, st) : tfk_launch_c4(p, st);
   }
   else if (variant == 6) {
     if (p.splitk != 1 || !pp3_setup(p, c.bm, c.bn)) { tf_set_error("run_gemm: the patch form of the ping-pong kernel cannot run this launch (tile %dx%d, split %d)", c.bm, c.bn, p.splitk); return TF_E_UNSUPPORTED; }
-    rc = tfk_launch_pp3(p, st, c.bn);
+    rc = bf ? tfk_launch_pp3_bf16(p, st, c.bn) : tfk_launch_pp3(p, st, c.bn);
   }
-  else if (variant == 2 && patch_setup(p, c.bm, c.bn)) rc = tfk_launch_patch(p, st, c.bm, c.bn);
-  else if (c.bm == 256 && c.bn == 128) rc = tfk_launch_igemm_256x128(p, st);
-  else if (c.bn == 160) rc = tfk_launch_igemm_160(p, st, c.bm, wide, all8);
-  else if (c.bn == 128) rc = tfk_launch_igemm_128(p, st, c.bm, wide, all8);
-  else if (c.bn == 64) rc = tfk_launch_igemm_64(p, st, c.bm, wide, all8);
+  else if (variant == 2 && patch_setup(p, c.bm, c.bn)) rc = bf ? tfk_launch_patch_bf16(p, st, c.bm, c.bn) : tfk_launch_patch(p, st, c.bm, c.bn);
+  else if (c.bm == 256 && c.bn == 128) rc = bf ? tfk_launch_igemm_256x128_bf16(p, st) : tfk_launch_igemm_256x128(p, st);
+  else if (c.bn == 160) rc = bf ? tfk_launch_igemm_160_bf16(p, st, c.bm, wide, all8) : tfk_launch_igemm_160(p, st, c.bm, wide, all8);
+  else if (c.bn == 128) rc = bf ? tfk_launch_igemm_128_bf16(p, st, c.bm, wide, all8) : tfk_launch_igemm_128(p, st, c.bm, wide, all8);
+  else if (c.bn == 64) rc = bf ? tfk_launch_igemm_64_bf16(p, st, c.bm, wide, all8) : tfk_launch_igemm_64(p, st, c.bm, wide, all8);
   else { tf_set_error("run_gemm: no kernel for tile %dx%d", c.bm, c.bn); return TF_E_UNSUPPORTED; }
   if (rc) return rc;
   if (g_prof_end) { TF_HIP(hipEventRecord(g_prof_end, st)); g_prof_end = nullptr; }   // the bracket holds k_igemm* alone (what rocprofv3 lists under that name)
@@ -559,15 +563,16 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
     if (!attr_set) {
       TF_HIP(hipFuncSetAttribute((const void*)k_splitk_reduce_gn_apply<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       TF_HIP(hipFuncSetAttribute((const void*)k_splitk_reduce_gn_apply<half_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      TF_HIP(hipFuncSetAttribute((const void*)k_splitk_reduce_gn_apply<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set = true;
     }
     const int nimg = p.M / p.HoWo;
-    if (p.part16) hipLaunchKernelGGL(k_splitk_reduce_gn_apply<half_t>, dim3(nimg * (p.gn_G / rg_gpb)), dim3(1024), rg_lds, st, p.y, p.on_z, (const half_t*)p.partial, p.bias, p.bias_nc,
-                       p.residual, p.M, p.N, p.HoWo, p.splitk, p.bias_nc_stride, p.gn_part, p.gn_G, p.gn_cpg, rg_gpb, p.on_gamma, p.on_beta, p.on_eps, p.on_silu,
-                       rg_rps, rg_cv);
-    else hipLaunchKernelGGL(k_splitk_reduce_gn_apply<float>, dim3(nimg * (p.gn_G / rg_gpb)), dim3(1024), rg_lds, st, p.y, p.on_z, (const float*)p.partial, p.bias, p.bias_nc,
-                       p.residual, p.M, p.N, p.HoWo, p.splitk, p.bias_nc_stride, p.gn_part, p.gn_G, p.gn_cpg, rg_gpb, p.on_gamma, p.on_beta, p.on_eps, p.on_silu,
-                       rg_rps, rg_cv);
+#define TF_RGA_LAUNCH(PT, BFV) hipLaunchKernelGGL((k_splitk_reduce_gn_apply<PT, BFV>), dim3(nimg * (p.gn_G / rg_gpb)), dim3(1024), rg_lds, st, p.y, p.on_z, (const PT*)p.partial, p.bias, p.bias_nc, \
+                       p.residual, p.M, p.N, p.HoWo, p.splitk, p.bias_nc_stride, p.gn_part, p.gn_G, p.gn_cpg, rg_gpb, p.on_gamma, p.on_beta, p.on_eps, p.on_silu, rg_rps, rg_cv)
+    if (bf) TF_RGA_LAUNCH(float, true);
+    else if (p.part16) TF_RGA_LAUNCH(half_t, false);
+    else TF_RGA_LAUNCH(float, false);
+#undef TF_RGA_LAUNCH
     TF_LAUNCH_CHECK();
     if (p.on_applied) *p.on_applied = 1;
   } else if (p.splitk > 1 && p.gn_part) {
@@ -575,20 +580,23 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
     int RL = 1024 / nq;
     if (RL > R) RL = R;
     int threads = (RL * nq + 63) & ~63;
-    if (p.part16) hipLaunchKernelGGL(k_splitk_reduce_gn<half_t>, dim3(p.M / R), dim3(threads), (size_t)RL * p.N * 2 * sizeof(float), st, p.y, (const half_t*)p.partial,
-                       p.bias, p.bias_nc, p.residual, p.M, p.N, p.HoWo, p.splitk, p.bias_nc_stride, p.gn_part, p.gn_G, p.gn_cpg, p.gn_chunks, R, RL);
-    else hipLaunchKernelGGL(k_splitk_reduce_gn<float>, dim3(p.M / R), dim3(threads), (size_t)RL * p.N * 2 * sizeof(float), st, p.y, (const float*)p.partial,
-                       p.bias, p.bias_nc, p.residual, p.M, p.N, p.HoWo, p.splitk, p.bias_nc_stride, p.gn_part, p.gn_G, p.gn_cpg, p.gn_chunks, R, RL);
+#define TF_RG_LAUNCH(PT, BFV) hipLaunchKernelGGL((k_splitk_reduce_gn<PT, BFV>), dim3(p.M / R), dim3(threads), (size_t)RL * p.N * 2 * sizeof(float), st, p.y, (const PT*)p.partial, \
+                       p.bias, p.bias_nc, p.residual, p.M, p.N, p.HoWo, p.splitk, p.bias_nc_stride, p.gn_part, p.gn_G, p.gn_cpg, p.gn_chunks, R, RL)
+    if (bf) TF_RG_LAUNCH(float, true);
+    else if (p.part16) TF_RG_LAUNCH(half_t, false);
+    else TF_RG_LAUNCH(float, false);
+#undef TF_RG_LAUNCH
     TF_LAUNCH_CHECK();
   } else if (p.splitk > 1) {
     long long nv = ((long long)p.M * p.N) >> 2;
     int grid = (int)((nv + 255) / 256);
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;
-    if (p.part16) hipLaunchKernelGGL(k_splitk_reduce<half_t>, dim3(grid), dim3(256), 0, st, p.y, (const half_t*)p.partial, p.bias, p.bias_nc, p.residual, p.M, p.N,
-                       p.HoWo, p.splitk, p.bias_nc_stride);
-    else hipLaunchKernelGGL(k_splitk_reduce<float>, dim3(grid), dim3(256), 0, st, p.y, (const float*)p.partial, p.bias, p.bias_nc, p.residual, p.M, p.N,
-                       p.HoWo, p.splitk, p.bias_nc_stride);
+#define TF_R_LAUNCH(PT, BFV) hipLaunchKernelGGL((k_splitk_reduce<PT, BFV>), dim3(grid), dim3(256), 0, st, p.y, (const PT*)p.partial, p.bias, p.bias_nc, p.residual, p.M, p.N, p.HoWo, p.splitk, p.bias_nc_stride)
+    if (bf) TF_R_LAUNCH(float, true);
+    else if (p.part16) TF_R_LAUNCH(half_t, false);
+    else TF_R_LAUNCH(float, false);
+#undef TF_R_LAUNCH
     TF_LAUNCH_CHECK();
   }
   return TF_OK;
@@ -780,7 +788,21 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
   return TF_OK;
 }
 
+#if TF_IGEMM_STAMP
+// diagnostic build (tools/igemm_stamp.py): every k_igemm launch writes its blocks' phase stamps here; tf_debug_stamps copies them out
+static unsigned long long* g_stamp_buf = nullptr;
+#define TF_STAMP_BLOCKS 8192
+extern "C" int tf_debug_stamps(void* host_out, int blocks) {
+  TF_REQUIRE(host_out && blocks >= 1 && blocks <= TF_STAMP_BLOCKS && g_stamp_buf, "tf_debug_stamps: no stamps");
+  TF_HIP(hipMemcpy(host_out, g_stamp_buf, (size_t)blocks * 64, hipMemcpyDeviceToHost));
+  return TF_OK;
+}
+#endif
 static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_bm, int force_bn, int force_split, hipStream_t st, int* gn_chunks = nullptr) {
+#if TF_IGEMM_STAMP
+  if (!g_stamp_buf) { TF_HIP(hipMalloc((void**)&g_stamp_buf, (size_t)TF_STAMP_BLOCKS * 64)); TF_HIP(hipMemset(g_stamp_buf, 0, (size_t)TF_STAMP_BLOCKS * 64)); }
+  p.stamp = g_stamp_buf;
+#endif
   p.ktiles = (p.K + 63) / 64;
   p.dbg = g_dbg;
   fast_div_magic((unsigned)p.HoWo, &p.dv_howo_mul, &p.dv_howo_shr);
@@ -801,19 +823,20 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     tuned = true;
     fp8_default = t;
   }
-  if (p.bf16) {                                           // two tiles, no tuner: 128 x 128 once that gives every CU a block, else 64 x 64
-    long long b128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    t.c = b128 >= 256 ? TileCfg{128, 128, 1} : TileCfg{64, 64, 1};
-    t.variant = 0; t.order = 0; tuned = true;
-  }
+  if (false) {}
   else if (force_bm) {
     t.c = {force_bm, force_bn, force_split > 0 ? force_split : 1};
     t.order = g_force_order > 0 ? 1 : 0;
     if (p.gi_part) t.variant = p.S == 3 ? 2 : 0;
   } else if (g_autotune && !g_dbg) {
     std::array<int, 10> key = {p.M, p.N, p.K, p.C1, p.C2, p.S, p.stride, p.ups, p.act,
-                               (p.bias ? 1 : 0) | (p.residual ? 2 : 0) | (p.bias_nc ? 4 : 0) | (p.ln_colsum ? 8 : 0) | (p.gi_part ? 16 : 0) | (p.fp8 ? 64 : 0) | (p.out8 ? 128 : 0) | (p.out32 ? 256 : 0) | (p.mx ? 512 : 0)};   // (on_z shares the plain key: same tile, another reduce kernel)
+                               (p.bias ? 1 : 0) | (p.residual ? 2 : 0) | (p.bias_nc ? 4 : 0) | (p.ln_colsum ? 8 : 0) | (p.gi_part ? 16 : 0) | (p.fp8 ? 64 : 0) | (p.out8 ? 128 : 0) | (p.out32 ? 256 : 0) | (p.mx ? 512 : 0) | (p.bf16 ? 1024 : 0)};   // (on_z shares the plain key: same tile, another reduce kernel)
     auto it = g_tuned.find(key);
+    if (it == g_tuned.end() && p.bf16) {                    // a bfloat16 launch without a row of its own takes the fp16 row of the shape: the same kernels, the same bytes and FLOPs
+      std::array<int, 10> k16 = key;
+      k16[9] &= ~1024;
+      it = g_tuned.find(k16);
+    }
     if (g_trace_keys) g_traced[key] = it != g_tuned.end();
     if (it != g_tuned.end()) {
       t = it->second; tuned = true;
@@ -906,7 +929,7 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     rec.has_reduce = eff > 1;
     // algorithmic bytes of the reduce launch: the slabs in, y out (+ the normalised z of the fused form), bias rows negligible
     const double mn = (double)p.M * p.N;
-    rec.reduce_bytes = mn * eff * ((g_part16 && (p.N & 7) == 0) ? 2.0 : 4.0) + mn * 2.0 * (1.0 + (p.residual ? 1.0 : 0.0) + ((p.on_z && p.gn_part) ? 1.0 : 0.0));
+    rec.reduce_bytes = mn * eff * ((g_part16 && !p.bf16 && (p.N & 7) == 0) ? 2.0 : 4.0) + mn * 2.0 * (1.0 + (p.residual ? 1.0 : 0.0) + ((p.on_z && p.gn_part) ? 1.0 : 0.0));
     if (rec.has_reduce) TF_HIP(hipEventRecord(rec.c, st));
     g_prof_pending.push_back(rec);
   }
@@ -1189,19 +1212,30 @@ static int conv2d_impl(void* y, const void* x, const void* x2, const void* w, co
   return run_gemm(p, workspace, workspace_bytes, g_force_bm, g_force_bn, g_force_split, tf_hs(s), gn_chunks);
 }
 
+#define TF_REQUIRE_DTYPE(fn) TF_REQUIRE(dtype == TF_DTYPE_F16 || dtype == TF_DTYPE_BF16, fn ": dtype=%d (0 = float16, 1 = bfloat16)", dtype)
+int tf_conv2d_fused_norm_16(int dtype, void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
+                            const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
+                            void* workspace, size_t workspace_bytes, const void* x3, const void* x4, int C3, int C4, void* gn_partial,
+                            size_t gn_partial_bytes, int gn_groups, int* gn_chunks, void* z, const void* z_gamma, const void* z_beta, float z_eps,
+                            int z_silu, int* z_written, tfStream_t s) {
+  TF_REQUIRE_DTYPE("tf_conv2d_fused_norm_16");
+  TF_REQUIRE(gn_partial && gn_chunks && z && z_written, "tf_conv2d_fused_norm_f16: gn_partial, gn_chunks, z and z_written must be given");
+  TF_REQUIRE((z_gamma == nullptr) == (z_beta == nullptr), "tf_conv2d_fused_norm_f16: gamma and beta must both be given or both NULL");
+  *z_written = 0;
+  GemmP ex = {};
+  ex.bf16 = dtype == TF_DTYPE_BF16;
+  ex.on_z = (half_t*)z; ex.on_gamma = (const half_t*)z_gamma; ex.on_beta = (const half_t*)z_beta; ex.on_eps = z_eps; ex.on_silu = z_silu ? 1 : 0;
+  ex.on_applied = z_written;
+  return conv2d_impl(y, x, x2, w, bias, bias_nc, bias_nc_stride, residual, N, H, W, C1, C2, Cout, R, S, stride, pad, upsample, workspace,
+                     workspace_bytes, (float*)gn_partial, gn_partial_bytes, gn_groups, gn_chunks, x3, x4, C3, C4, s, &ex);
+}
 int tf_conv2d_fused_norm_f16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
                              const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
                              void* workspace, size_t workspace_bytes, const void* x3, const void* x4, int C3, int C4, void* gn_partial,
                              size_t gn_partial_bytes, int gn_groups, int* gn_chunks, void* z, const void* z_gamma, const void* z_beta, float z_eps,
                              int z_silu, int* z_written, tfStream_t s) {
-  TF_REQUIRE(gn_partial && gn_chunks && z && z_written, "tf_conv2d_fused_norm_f16: gn_partial, gn_chunks, z and z_written must be given");
-  TF_REQUIRE((z_gamma == nullptr) == (z_beta == nullptr), "tf_conv2d_fused_norm_f16: gamma and beta must both be given or both NULL");
-  *z_written = 0;
-  GemmP ex = {};
-  ex.on_z = (half_t*)z; ex.on_gamma = (const half_t*)z_gamma; ex.on_beta = (const half_t*)z_beta; ex.on_eps = z_eps; ex.on_silu = z_silu ? 1 : 0;
-  ex.on_applied = z_written;
-  return conv2d_impl(y, x, x2, w, bias, bias_nc, bias_nc_stride, residual, N, H, W, C1, C2, Cout, R, S, stride, pad, upsample, workspace,
-                     workspace_bytes, (float*)gn_partial, gn_partial_bytes, gn_groups, gn_chunks, x3, x4, C3, C4, s, &ex);
+  return tf_conv2d_fused_norm_16(TF_DTYPE_F16, y, x, x2, w, bias, bias_nc, bias_nc_stride, residual, N, H, W, C1, C2, Cout, R, S, stride, pad, upsample, workspace, workspace_bytes,
+                                 x3, x4, C3, C4, gn_partial, gn_partial_bytes, gn_groups, gn_chunks, z, z_gamma, z_beta, z_eps, z_silu, z_written, s);
 }
 
 int tf_conv2d_gn_supported(int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample, int C3, int C4, int in_groups) {
@@ -1216,16 +1250,18 @@ int tf_conv2d_gn_supported(int N, int H, int W, int C1, int C2, int Cout, int R,
   return gi_any_ok(p) ? 1 : 0;
 }
 
-int tf_conv2d_gn_f16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
-                     const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
-                     void* workspace, size_t workspace_bytes, const void* x3, const void* x4, int C3, int C4, void* gn_partial,
-                     size_t gn_partial_bytes, int gn_groups, int* gn_chunks, const void* in_gamma, const void* in_beta, const void* in_partial,
-                     int in_chunks, int in_groups1, const void* in_partial2, int in_chunks2, int in_groups2, int in_groups, float in_eps, int in_silu,
-                     tfStream_t s) {
+int tf_conv2d_gn_16(int dtype, void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
+                    const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
+                    void* workspace, size_t workspace_bytes, const void* x3, const void* x4, int C3, int C4, void* gn_partial,
+                    size_t gn_partial_bytes, int gn_groups, int* gn_chunks, const void* in_gamma, const void* in_beta, const void* in_partial,
+                    int in_chunks, int in_groups1, const void* in_partial2, int in_chunks2, int in_groups2, int in_groups, float in_eps, int in_silu,
+                    tfStream_t s) {
+  TF_REQUIRE_DTYPE("tf_conv2d_gn_16");
   TF_REQUIRE(!gn_partial || gn_chunks, "tf_conv2d_gn_f16: gn_chunks must be given with gn_partial");
   TF_REQUIRE(in_partial && in_chunks >= 1 && in_chunks <= 4096 && in_groups >= 1 && (C1 + C2) % in_groups == 0, "tf_conv2d_gn_f16: input statistics missing (chunks=%d groups=%d)", in_chunks, in_groups);
   TF_REQUIRE((in_gamma == nullptr) == (in_beta == nullptr), "tf_conv2d_gn_f16: gamma and beta must both be given or both NULL");
   GemmP gi = {};
+  gi.bf16 = dtype == TF_DTYPE_BF16;
   gi.gi_part = (const float*)in_partial; gi.gi_gamma = (const half_t*)in_gamma; gi.gi_beta = (const half_t*)in_beta;
   gi.gi_chunks = in_chunks; gi.gi_G = in_groups; gi.gi_G1 = in_groups; gi.gi_mr = 1; gi.gi_eps = in_eps; gi.gi_silu = in_silu ? 1 : 0;
   if (in_partial2) {
@@ -1240,6 +1276,16 @@ int tf_conv2d_gn_f16(void* y, const void* x, const void* x2, const void* w, cons
   return conv2d_impl(y, x, x2, w, bias, bias_nc, bias_nc_stride, residual, N, H, W, C1, C2, Cout, R, S, stride, pad, upsample, workspace,
                      workspace_bytes, (float*)gn_partial, gn_partial_bytes, gn_groups, gn_chunks, x3, x4, C3, C4, s, &gi);
 }
+int tf_conv2d_gn_f16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
+                     const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
+                     void* workspace, size_t workspace_bytes, const void* x3, const void* x4, int C3, int C4, void* gn_partial,
+                     size_t gn_partial_bytes, int gn_groups, int* gn_chunks, const void* in_gamma, const void* in_beta, const void* in_partial,
+                     int in_chunks, int in_groups1, const void* in_partial2, int in_chunks2, int in_groups2, int in_groups, float in_eps, int in_silu,
+                     tfStream_t s) {
+  return tf_conv2d_gn_16(TF_DTYPE_F16, y, x, x2, w, bias, bias_nc, bias_nc_stride, residual, N, H, W, C1, C2, Cout, R, S, stride, pad, upsample, workspace, workspace_bytes, x3, x4, C3, C4,
+                         gn_partial, gn_partial_bytes, gn_groups, gn_chunks, in_gamma, in_beta, in_partial, in_chunks, in_groups1, in_partial2, in_chunks2, in_groups2, in_groups, in_eps,
+                         in_silu, s);
+}
 
 int tf_conv2d_f16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
                   const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
@@ -1248,13 +1294,23 @@ int tf_conv2d_f16(void* y, const void* x, const void* x2, const void* w, const v
                      workspace_bytes, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, s);
 }
 
+int tf_conv2d_fused_16(int dtype, void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
+                       const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
+                       void* workspace, size_t workspace_bytes, const void* x3, const void* x4, int C3, int C4, void* gn_partial,
+                       size_t gn_partial_bytes, int gn_groups, int* gn_chunks, tfStream_t s) {
+  TF_REQUIRE_DTYPE("tf_conv2d_fused_16");
+  TF_REQUIRE(!gn_partial || gn_chunks, "tf_conv2d_fused_f16: gn_chunks must be given with gn_partial");
+  GemmP ex = {};
+  ex.bf16 = dtype == TF_DTYPE_BF16;
+  return conv2d_impl(y, x, x2, w, bias, bias_nc, bias_nc_stride, residual, N, H, W, C1, C2, Cout, R, S, stride, pad, upsample, workspace,
+                     workspace_bytes, (float*)gn_partial, gn_partial_bytes, gn_groups, gn_chunks, x3, x4, C3, C4, s, &ex);
+}
 int tf_conv2d_fused_f16(void* y, const void* x, const void* x2, const void* w, const void* bias, const void* bias_nc, long long bias_nc_stride,
                         const void* residual, int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample,
                         void* workspace, size_t workspace_bytes, const void* x3, const void* x4, int C3, int C4, void* gn_partial,
                         size_t gn_partial_bytes, int gn_groups, int* gn_chunks, tfStream_t s) {
-  TF_REQUIRE(!gn_partial || gn_chunks, "tf_conv2d_fused_f16: gn_chunks must be given with gn_partial");
-  return conv2d_impl(y, x, x2, w, bias, bias_nc, bias_nc_stride, residual, N, H, W, C1, C2, Cout, R, S, stride, pad, upsample, workspace,
-                     workspace_bytes, (float*)gn_partial, gn_partial_bytes, gn_groups, gn_chunks, x3, x4, C3, C4, s);
+  return tf_conv2d_fused_16(TF_DTYPE_F16, y, x, x2, w, bias, bias_nc, bias_nc_stride, residual, N, H, W, C1, C2, Cout, R, S, stride, pad, upsample, workspace, workspace_bytes, x3, x4, C3, C4,
+                            gn_partial, gn_partial_bytes, gn_groups, gn_chunks, s);
 }
 
 size_t tf_conv2d_fused_workspace(int N, int H, int W, int C1, int C2, int Cout, int R, int S, int stride, int pad, int upsample, int C3, int C4) {
@@ -1267,6 +1323,11 @@ size_t tf_linear_workspace(int M, int N, int K, int act) { return gemm_workspace
 
 int tf_linear_f16(void* y, const void* x, const void* w, const void* bias, const void* residual, int M, int N, int K, int act,
                   void* workspace, size_t workspace_bytes, tfStream_t s) {
+  return tf_linear_16(TF_DTYPE_F16, y, x, w, bias, residual, M, N, K, act, workspace, workspace_bytes, s);
+}
+int tf_linear_16(int dtype, void* y, const void* x, const void* w, const void* bias, const void* residual, int M, int N, int K, int act,
+                 void* workspace, size_t workspace_bytes, tfStream_t s) {
+  TF_REQUIRE_DTYPE("tf_linear_16");
   TF_REQUIRE(y && x && w, "tf_linear_f16: null tensor");
   TF_REQUIRE(M >= 0 && N >= 1 && K >= 8 && K % 8 == 0, "tf_linear_f16: K=%d must be a positive multiple of 8", K);
   TF_REQUIRE(act == 0 || act == 1, "tf_linear_f16: act=%d", act);
@@ -1276,6 +1337,7 @@ int tf_linear_f16(void* y, const void* x, const void* w, const void* bias, const
   p.x = (const half_t*)x; p.w = (const half_t*)w; p.y = (half_t*)y; p.bias = (const half_t*)bias; p.residual = (const half_t*)residual;
   p.M = M; p.N = act == 1 ? 2 * N : N; p.K = K; p.Kc = K; p.C1 = K; p.C2 = 0; p.C = K;
   p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.HoWo = M; p.S = 1; p.stride = 1; p.pad = 0; p.ups = 0; p.act = act;
+  p.bf16 = dtype == TF_DTYPE_BF16;
   {
     long long xb = (long long)M * K * 2, wb = (long long)p.N * K * 2;
     TF_REQUIRE(xb < (1LL << 31) && wb < (1LL << 31), "tf_linear_f16: tensors must be < 2 GiB each");
@@ -1514,17 +1576,29 @@ int tf_linear_mx8(void* y, const void* x_mx, const void* w8, const void* wscale,
   return run_gemm(p, workspace, workspace_bytes, g_force_bm, g_force_bn, g_force_split, tf_hs(s));
 }
 
-int tf_ln_fold_weights_f16(void* w_out, void* bias_out, void* colsum_out, const void* w, const void* bias, const void* gamma, const void* beta,
-                           int N, int K, tfStream_t s) {
+int tf_ln_fold_weights_16(int dtype, void* w_out, void* bias_out, void* colsum_out, const void* w, const void* bias, const void* gamma, const void* beta,
+                          int N, int K, tfStream_t s) {
+  TF_REQUIRE_DTYPE("tf_ln_fold_weights_16");
   TF_REQUIRE(w_out && bias_out && colsum_out && w && gamma && beta && N >= 1 && K % 8 == 0, "tf_ln_fold_weights_f16: bad arguments (K=%d)", K);
-  hipLaunchKernelGGL(k_ln_fold, dim3(ceil_div(N, 4)), dim3(256), 0, tf_hs(s), (half_t*)w_out, (half_t*)bias_out, (float*)colsum_out, (const half_t*)w,
-                     (const half_t*)bias, (const half_t*)gamma, (const half_t*)beta, N, K);
+  if (dtype == TF_DTYPE_BF16) hipLaunchKernelGGL(k_ln_fold<true>, dim3(ceil_div(N, 4)), dim3(256), 0, tf_hs(s), (half_t*)w_out, (half_t*)bias_out, (float*)colsum_out, (const half_t*)w,
+                                                 (const half_t*)bias, (const half_t*)gamma, (const half_t*)beta, N, K);
+  else hipLaunchKernelGGL(k_ln_fold<false>, dim3(ceil_div(N, 4)), dim3(256), 0, tf_hs(s), (half_t*)w_out, (half_t*)bias_out, (float*)colsum_out, (const half_t*)w,
+                          (const half_t*)bias, (const half_t*)gamma, (const half_t*)beta, N, K);
   TF_LAUNCH_CHECK();
   return TF_OK;
+}
+int tf_ln_fold_weights_f16(void* w_out, void* bias_out, void* colsum_out, const void* w, const void* bias, const void* gamma, const void* beta,
+                           int N, int K, tfStream_t s) {
+  return tf_ln_fold_weights_16(TF_DTYPE_F16, w_out, bias_out, colsum_out, w, bias, gamma, beta, N, K, s);
 }
 
 int tf_linear_ln_f16(void* y, const void* x, const void* w_folded, const void* bias_folded, const void* colsum, const void* residual, int M, int N,
                      int K, int act, float eps, tfStream_t s) {
+  return tf_linear_ln_16(TF_DTYPE_F16, y, x, w_folded, bias_folded, colsum, residual, M, N, K, act, eps, s);
+}
+int tf_linear_ln_16(int dtype, void* y, const void* x, const void* w_folded, const void* bias_folded, const void* colsum, const void* residual, int M, int N,
+                    int K, int act, float eps, tfStream_t s) {
+  TF_REQUIRE_DTYPE("tf_linear_ln_16");
   TF_REQUIRE(y && x && w_folded && bias_folded && colsum, "tf_linear_ln_f16: null tensor");
   TF_REQUIRE(M >= 0 && N >= 1 && K >= 64 && K % 64 == 0, "tf_linear_ln_f16: K=%d must be a positive multiple of 64", K);
   TF_REQUIRE(act == 0 || act == 1, "tf_linear_ln_f16: act=%d", act);
@@ -1533,6 +1607,7 @@ int tf_linear_ln_f16(void* y, const void* x, const void* w_folded, const void* b
   GemmP p = {};
   p.x = (const half_t*)x; p.w = (const half_t*)w_folded; p.y = (half_t*)y; p.bias = (const half_t*)bias_folded; p.residual = (const half_t*)residual;
   p.ln_colsum = (const float*)colsum; p.ln_eps = eps;
+  p.bf16 = dtype == TF_DTYPE_BF16;
   p.M = M; p.N = act == 1 ? 2 * N : N; p.K = K; p.Kc = K; p.C1 = K; p.C2 = 0; p.C = K;
   p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.HoWo = M; p.S = 1; p.stride = 1; p.pad = 0; p.ups = 0; p.act = act;
   {
@@ -1543,11 +1618,16 @@ int tf_linear_ln_f16(void* y, const void* x, const void* w_folded, const void* b
   return run_gemm(p, nullptr, 0, g_force_bm, g_force_bn, g_force_split, tf_hs(s));
 }
 
-int tf_gemv_f16(void* y, const void* x, const void* w, const void* bias, int M, int N, int K, int silu_input, tfStream_t s) {
+int tf_gemv_16(int dtype, void* y, const void* x, const void* w, const void* bias, int M, int N, int K, int silu_input, tfStream_t s) {
+  TF_REQUIRE_DTYPE("tf_gemv_16");
   TF_REQUIRE(y && x && w && M >= 1 && M <= 8 && N >= 1 && K % 8 == 0, "tf_gemv_f16: needs 1 <= M <= 8 (M=%d) and K %% 8 == 0 (K=%d)", M, K);
-  hipLaunchKernelGGL(k_gemv, dim3(ceil_div(N, 4)), dim3(256), 0, tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)w, (const half_t*)bias, M, N, K, silu_input);
+  if (dtype == TF_DTYPE_BF16) hipLaunchKernelGGL(k_gemv<true>, dim3(ceil_div(N, 4)), dim3(256), 0, tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)w, (const half_t*)bias, M, N, K, silu_input);
+  else hipLaunchKernelGGL(k_gemv<false>, dim3(ceil_div(N, 4)), dim3(256), 0, tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)w, (const half_t*)bias, M, N, K, silu_input);
   TF_LAUNCH_CHECK();
   return TF_OK;
+}
+int tf_gemv_f16(void* y, const void* x, const void* w, const void* bias, int M, int N, int K, int silu_input, tfStream_t s) {
+  return tf_gemv_16(TF_DTYPE_F16, y, x, w, bias, M, N, K, silu_input, s);
 }
 
 }  // extern "C"

@@ -20,7 +20,7 @@
 //   * the two blocks of a CU are independent programs: one's epilogue and first-tile latency overlap the other's MFMAs.
 // S = 1 / stride 1 / no padding (rows are contiguous K vectors; the concat pair of the FF2 . proj_out fold is two sources), channel
 // counts on the 64 grid, fp16, no split-K / statistics / time embedding (those launches keep the kernels above).
-template <bool LNF>
+template <bool LNF, bool BF = false>   // BF: bfloat16 operands / outputs (gemm_k_c4_bf16.hip)
 __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
   constexpr int BM = 128, BN = 128, MJ = 4, NI = 4;
   constexpr int STAGE = (BM + BN) * 128;                  // 32 KiB
@@ -147,17 +147,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
       __builtin_amdgcn_sched_barrier(0);
       if (LNF && need_stats) {
         // row statistics from the fragments: the two waves that share these 64 rows (wn = 0, 1) take one 32-deep k-step each
-        typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
-        const hh2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
         auto acc_stats = [&](const h8 (&x)[MJ]) {
 #pragma unroll
-          for (int j = 0; j < MJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              hh2 v = {x[j][2 * e], x[j][2 * e + 1]};
-              ls[j] = __builtin_amdgcn_fdot2(v, one2, ls[j], false);
-              lq[j] = __builtin_amdgcn_fdot2(v, v, lq[j], false);
-            }
+          for (int j = 0; j < MJ; ++j) dot2_stats<BF>(x[j], ls[j], lq[j]);
         };
         if (wn == 0) acc_stats(xf[0]); else acc_stats(xf[1]);
       }
@@ -166,7 +158,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
-          for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[f][i], xf[f][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < MJ; ++j) acc[i][j] = mfma16<BF>(wf[f][i], xf[f][j], acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (LNF && need_stats) {                               // this wave's half of the row sums -> LDS, the partner's half comes back behind the barrier
@@ -207,7 +199,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < MJ; ++j) acc[i][j] += (f4){(float)braw[i][0], (float)braw[i][1], (float)braw[i][2], (float)braw[i][3]};
+      for (int j = 0; j < MJ; ++j) acc[i][j] += (f4){e2f<BF>(braw[i][0]), e2f<BF>(braw[i][1]), e2f<BF>(braw[i][2]), e2f<BF>(braw[i][3])};
     asm volatile("" ::: "memory");
     // ---- the next tile's rows and its first K tile (slot 0), in flight during the rest of this tile's epilogue
     const int cm0 = m0, cn0 = n0;
@@ -232,14 +224,14 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
 #pragma unroll
           for (int i = 0; i < NI; i += 2) {
             h4 o;
-            for (int e = 0; e < 4; ++e) o[e] = (half_t)(acc[i][j][e] * gelu_f(acc[i + 1][j][e]));
+            for (int e = 0; e < 4; ++e) o[e] = f2e<BF>(acc[i][j][e] * gelu_f(acc[i + 1][j][e]));
             asm volatile("ds_write_b64 %0, %1" ::"v"(rowa + (unsigned)((i >> 1) * 32 + lg * 8)), "v"(o) : "memory");
           }
         } else {
 #pragma unroll
           for (int i = 0; i < NI; ++i) {
             h4 o;
-            for (int e = 0; e < 4; ++e) o[e] = (half_t)acc[i][j][e];
+            for (int e = 0; e < 4; ++e) o[e] = f2e<BF>(acc[i][j][e]);
             asm volatile("ds_write_b64 %0, %1" ::"v"(rowa + (unsigned)(i * 32 + lg * 8)), "v"(o) : "memory");
           }
         }
@@ -254,7 +246,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pa + (unsigned)row * 144u + (unsigned)c8 * 16u) : "memory");
         if (m < M_ && no < No) {
           const long long o = (long long)m * No + no;
-          if (p.residual) { h8 r = *reinterpret_cast<const h8*>(p.residual + o); for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)r[e]); }
+          if (p.residual) { h8 r = *reinterpret_cast<const h8*>(p.residual + o); for (int e = 0; e < 8; ++e) v[e] = f2e<BF>(e2f<BF>(v[e]) + e2f<BF>(r[e])); }
           *reinterpret_cast<h8*>(p.y + o) = v;
         }
       }

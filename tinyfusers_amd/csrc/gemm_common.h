@@ -21,6 +21,9 @@
 #include "../../include/tinyfusers_hip.h"
 #include <vector>
 
+#ifndef TF_IGEMM_STAMP
+#define TF_IGEMM_STAMP 0
+#endif
 struct GemmP {
   const half_t* x; const half_t* x2; const half_t* w; half_t* y;
   // extra K segment after the R*S taps (tf_conv2d_fused_f16): a 1x1 projection of a second activation (pair) x3 | x4 read
@@ -76,8 +79,13 @@ struct GemmP {
   // q k^T scores of the unfused attention path, which must not be rounded to fp16 before the softmax; NULL = off
   float* out32;
   int c4_chunk;         // k_gemm_c4: consecutive tiles a block takes before it strides on by gridDim chunks (launch_c4)
+#if TF_IGEMM_STAMP
+  unsigned long long* stamp;   // diagnostic build only (tools/igemm_stamp.py): [block][8] s_memrealtime phase stamps of k_igemm, never in the shipped library
+#endif
 };
 
+// TF_IGEMM_STAMP (defined above GemmP, default 0): python -m tinyfusers_amd.build --tag stamp16 -DTF_IGEMM_STAMP=1 -- k_igemm records where a
+// launch's time goes (phase stamps of wave 0 and wave 4 of every block on the 100 MHz constant clock; tools/igemm_stamp.py)
 // Ablation switches (kernels that skip work and return WRONG results by design, for tools/*_dbg.py) exist only in the second library
 // built with -DTF_ABLATION (python -m tinyfusers_amd.build --ablation -> lib/libtinyfusers_hip_ablation.so, loaded through TF_LIB_PATH);
 // in the shipped library every TF_ABL(...) is the constant 0 and the DBG template instances are not compiled.
@@ -87,7 +95,6 @@ struct GemmP {
 #define TF_ABL(x) 0
 #endif
 typedef __amdgpu_buffer_rsrc_t rsrc_t;   // 128-bit buffer resource
-typedef bf16_t b8v __attribute__((ext_vector_type(8)));   // MFMA operand of the bfloat16 instances (same register image as h8)
 
 // n / d for n < 2^31 via a precomputed multiplier: q = (umulhi(mul, n) + n) >> shr   (round-up method)
 __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
@@ -235,6 +242,7 @@ __device__ __forceinline__ void lds_write16(unsigned a, h8 v) { asm volatile("ds
 // partials of image `img` into (mean, rstd) per group -- the very fold of k_gn_apply (8 lanes per group strided over the chunks,
 // fp64, fixed order: the same bits) -- then a[c] = rstd * gamma[c], b[c] = beta[c] - mean * a[c] for every input channel.
 // Contains two workgroup barriers (A: statistics in LDS, B: table in LDS); the loader waves execute the matching pair.
+template <bool BF = false>
 __device__ __forceinline__ void gi_prologue(const GemmP& p, char* smem, int img, int t) {
   f2* st = reinterpret_cast<f2*>(smem + p.gi_off);
   f2* ab = st + p.gi_G;
@@ -282,7 +290,7 @@ __device__ __forceinline__ void gi_prologue(const GemmP& p, char* smem, int img,
   asm volatile("" ::: "memory");
   for (int c = t; c < C; c += 256) {
     f2 m = st[c / cpg];
-    float gm = p.gi_gamma ? (float)p.gi_gamma[c] : 1.0f, bt = p.gi_beta ? (float)p.gi_beta[c] : 0.0f;
+    float gm = p.gi_gamma ? e2f<BF>(p.gi_gamma[c]) : 1.0f, bt = p.gi_beta ? e2f<BF>(p.gi_beta[c]) : 0.0f;
     float a = m[1] * gm;
     ab[c] = (f2){a, bt - m[0] * a};
   }
@@ -304,12 +312,13 @@ __device__ __forceinline__ void gi_load_ab(const GemmP& p, char* smem, int c0, f
 }
 // normalise one 16-byte element vector: x * a + b, optional SiLU, rounded to fp16 exactly as k_gn_apply does; `keep` = false
 // leaves zeros (zero padding of the convolution is applied AFTER the normalisation: the padded pixels must stay zero)
+template <bool BF = false>
 __device__ __forceinline__ h8 gi_apply(h8 x, const float (&a)[8], const float (&b)[8], int do_silu, bool keep) {
   h8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    float f = (float)x[j] * a[j] + b[j];
-    o[j] = (half_t)(do_silu ? silu_f(f) : f);
+    float f = e2f<BF>(x[j]) * a[j] + b[j];
+    o[j] = f2e<BF>(do_silu ? silu_f(f) : f);
   }
   if (!keep) o = (h8){0, 0, 0, 0, 0, 0, 0, 0};
   return o;
@@ -643,7 +652,6 @@ int tfk_launch_igemm_160(const GemmP& p, hipStream_t st, int bm, bool wide, bool
 int tfk_launch_igemm_128(const GemmP& p, hipStream_t st, int bm, bool wide, bool all8);
 int tfk_launch_igemm_64(const GemmP& p, hipStream_t st, int bm, bool wide, bool all8);
 int tfk_launch_igemm_256x128(const GemmP& p, hipStream_t st);
-int tfk_launch_igemm_bf16(const GemmP& p, hipStream_t st, int bm, int bn);
 //   k_igemm_patch (gemm_k_patch.hip); the caller has run patch_setup
 int tfk_launch_patch(const GemmP& p, hipStream_t st, int bm, int bn);
 //   k_igemm8 (gemm_k_igemm8.hip)
@@ -654,3 +662,12 @@ int tfk_launch_pp8(const GemmP& p, hipStream_t st, int bm, int bn);
 //   k_gemm_c4 (gemm_k_c4.hip)
 int tfk_launch_c4(const GemmP& p, hipStream_t st);
 int tfk_launch_pp3(const GemmP& p, hipStream_t st, int bn);
+//   the bfloat16 instances of the same kernels (gemm_k_*_bf16.hip)
+int tfk_launch_igemm_160_bf16(const GemmP& p, hipStream_t st, int bm, bool wide, bool all8);
+int tfk_launch_igemm_128_bf16(const GemmP& p, hipStream_t st, int bm, bool wide, bool all8);
+int tfk_launch_igemm_64_bf16(const GemmP& p, hipStream_t st, int bm, bool wide, bool all8);
+int tfk_launch_igemm_256x128_bf16(const GemmP& p, hipStream_t st);
+int tfk_launch_patch_bf16(const GemmP& p, hipStream_t st, int bm, int bn);
+int tfk_launch_pp16_bf16(const GemmP& p, hipStream_t st, int bm, int bn, int np_force);
+int tfk_launch_c4_bf16(const GemmP& p, hipStream_t st);
+int tfk_launch_pp3_bf16(const GemmP& p, hipStream_t st, int bn);

@@ -19,9 +19,8 @@
 // lose in MFMA issue slots; one of the autotuned variants.
 // GI = true: the instance that can normalise its input (GemmP::gi_*); a template parameter so that the launches without it run the very
 // code they ran before the feature existed (its branches and SGPRs cost 3 % of the step when they sat in every instance)
-template <int BM, int BN, bool GENERIC, bool WIDE, bool ALL8 = false, bool GI = false, bool BF = false>   // BF: bfloat16 operands / outputs (plain deep ring only)
+template <int BM, int BN, bool GENERIC, bool WIDE, bool ALL8 = false, bool GI = false, bool BF = false>   // BF: bfloat16 operands / outputs (gemm_common.h: mfma16 / e2f / f2e)
 __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
-  static_assert(!BF || (!WIDE && !ALL8 && !GI && BM != 256), "the bfloat16 instances use the plain deep ring");
   constexpr int TM = BM / 2, TN = BN / 2, MJ = TM / 16, NI = TN / 16;
   constexpr int NG = (BM + BN) / 8;                       // 8-row staging groups: activation rows first, then weight rows
   // weight pieces per CONSUMER wave per stage (the last 4 LPC groups); one more per wave measured 1-3 % slower on every shape
@@ -59,6 +58,18 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kt_begin = split * p.ktiles_per_split;
   const int kt_end = min(p.ktiles, kt_begin + p.ktiles_per_split);
+#if TF_IGEMM_STAMP
+  // diagnostic build: wave 0 (a consumer) and wave 4 (a loader) of every block keep four stamps of the constant 100 MHz clock each and store them when
+  // they leave: [0] entry [1] K loop done (behind barrier X) [2] epilogue stores issued [3] stores drained | [4] entry [5] K tile 0 landed
+  // [6] last stage issued [7] left.  The fences idle nothing the shipped kernel overlaps across these points (they sit at barriers).
+  unsigned long long stp0 = __builtin_amdgcn_s_memrealtime(), stp1 = 0, stp2 = 0, stp3 = 0;
+  auto stamp_out = [&](int base) {
+    if (p.stamp && lane == 0 && blockIdx.x < 8192) { unsigned long long* d = p.stamp + (size_t)blockIdx.x * 8 + base; d[0] = stp0; d[1] = stp1; d[2] = stp2; d[3] = stp3; }
+  };
+#define IG_STAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define IG_STAMP(v) do { } while (0)
+#endif
 
   if (loader) {
     // =============================== LOADER WAVES ===============================================
@@ -99,20 +110,13 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < LPS; ++i) { ls[i] = 0.f; lq[i] = 0.f; }
     auto ln_tile = [&](int slot) {
-      typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
-      const hh2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
       const char* base = smem + slot * STAGE;
 #pragma unroll
       for (int i = 0; i < LPS; ++i) {
         const int g = w4 + 4 * i;
         if (g * 8 < BM) {
           h8 x = *reinterpret_cast<const h8*>(base + g * 1024 + lane * 16);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            hh2 v = {x[2 * e], x[2 * e + 1]};
-            ls[i] = __builtin_amdgcn_fdot2(v, one2, ls[i], false);
-            lq[i] = __builtin_amdgcn_fdot2(v, v, lq[i], false);
-          }
+          dot2_stats<BF>(x, ls[i], lq[i]);
         }
       }
     };
@@ -129,7 +133,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
         const int g = w4 + 4 * i;
         if (g * 8 < BM) {
           h8 x = lds_read16(base + g * 1024);
-          lds_write16(base + g * 1024, gi_apply(x, ga, gb, p.gi_silu, true));
+          lds_write16(base + g * 1024, gi_apply<BF>(x, ga, gb, p.gi_silu, true));
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -225,6 +229,9 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
       if (gi_on) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }   // barriers A, B of gi_prologue (consumer waves)
       for (int it = 0; it < nt; ++it) {
         wait_vm<0>();
+#if TF_IGEMM_STAMP
+        if (it == 0) IG_STAMP(stp1);
+#endif
         if (gi_on) gi_tile(it & 1, kt_begin + it);
         __builtin_amdgcn_s_barrier();                     // barrier(it)
         asm volatile("" ::: "memory");
@@ -240,6 +247,9 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
         if (s_ < nt) stage(s_, kt_begin + s_);
       if (gi_on) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }   // barriers A, B of gi_prologue (consumer waves)
       wait_stages<LPS, NS - 1>(nt - 1);                    // tile 0 landed; up to NS-1 newer stages in flight
+#if TF_IGEMM_STAMP
+      IG_STAMP(stp1);
+#endif
       if (gi_on && nt > 0) gi_tile(0, kt_begin);
       __builtin_amdgcn_s_barrier();                       // barrier P
       if (ln_on && nt > 0) ln_tile(0);                    // slot 0 is refilled only after barrier(0)
@@ -267,6 +277,9 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
         lstat[i] = (f2){mean, rsqrtf(var + p.ln_eps)};
       }
     }
+#if TF_IGEMM_STAMP
+    IG_STAMP(stp2);
+#endif
     __builtin_amdgcn_s_barrier();                         // barrier X: matches the consumers' "ring is free" barrier
     asm volatile("" ::: "memory");
     if (TF_ABL(p.dbg & 1)) return;
@@ -286,11 +299,16 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
     asm volatile("" ::: "memory");
     igemm_epilogue<BM, BN, false, BF>(p, smem, m0, n0, split, w4, 1, lane);
     if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 1, lane);
+#if TF_IGEMM_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IG_STAMP(stp3);
+    if (wid == 4) stamp_out(4);
+#endif
     return;
   }
 
   // ================================= CONSUMER WAVES ===============================================
-  if constexpr (GI) gi_prologue(p, smem, m0 / p.HoWo, w4 * 64 + lane);   // first: its global loads must not wait behind this wave's own DMA (ALL8)
+  if constexpr (GI) gi_prologue<BF>(p, smem, m0 / p.HoWo, w4 * 64 + lane);   // first: its global loads must not wait behind this wave's own DMA (ALL8)
   const int wave_m = w4 & 1, wave_n = w4 >> 1;
   const int lr = lane & 15, lg = lane >> 4;
   f4 acc[NI][MJ];
@@ -362,7 +380,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < MJ; ++j) acc[i][j] = mfma16<BF>(wf[i], xf[j], acc[i][j]);
     };
     __builtin_amdgcn_s_barrier();                         // barrier P: tile 0 landed
     asm volatile("" ::: "memory");
@@ -402,7 +420,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
-          for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < MJ; ++j) acc[i][j] = mfma16<BF>(wf[i], xf[j], acc[i][j]);
 
       }
     }
@@ -437,10 +455,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < MJ; ++j) {
-          if constexpr (BF) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8v, wf[k2][i]), __builtin_bit_cast(b8v, xf[k2][j]), acc[i][j], 0, 0, 0);
-          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[k2][i], xf[k2][j], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < MJ; ++j) acc[i][j] = mfma16<BF>(wf[k2][i], xf[k2][j], acc[i][j]);
   };
   if constexpr (ALL8) {
 #pragma unroll
@@ -475,6 +490,9 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   }
   __builtin_amdgcn_s_barrier();                           // barrier X: every consumer is done with the ring
   asm volatile("" ::: "memory");
+#if TF_IGEMM_STAMP
+  IG_STAMP(stp1);
+#endif
   if (TF_ABL(p.dbg & 1)) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -493,4 +511,11 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   asm volatile("" ::: "memory");
   igemm_epilogue<BM, BN, false, BF>(p, smem, m0, n0, split, w4, 0, lane);
   if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 0, lane);
+#if TF_IGEMM_STAMP
+  IG_STAMP(stp2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  IG_STAMP(stp3);
+  if (wid == 0) stamp_out(0);
+#endif
 }
+#undef IG_STAMP

@@ -7,12 +7,12 @@ static int c4_num_cus() {
   return n;
 }
 static int g_c4_chunk = getenv("TF_C4_CHUNK") ? atoi(getenv("TF_C4_CHUNK")) : 0;   // A/B: tiles per chunk of k_gemm_c4's walk (0 = per-shape choice)
-int tfk_launch_c4(const GemmP& p, hipStream_t st) {
+int TFK(tfk_launch_c4)(const GemmP& p, hipStream_t st) {
   constexpr int smem = 2 * (128 + 128) * 128 + 4 * 64 * 8;   // the two-slot ring (the epilogue's patches live in slot 1) + the LayerNorm row-sum exchange
   static bool attr_set = false;
   if (!attr_set) {
-    TF_HIP(hipFuncSetAttribute((const void*)k_gemm_c4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    TF_HIP(hipFuncSetAttribute((const void*)k_gemm_c4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    TF_HIP(hipFuncSetAttribute((const void*)k_gemm_c4<false, kBF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    TF_HIP(hipFuncSetAttribute((const void*)k_gemm_c4<true, kBF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   const int tiles = p.ntm * p.ntn;
@@ -25,8 +25,8 @@ int tfk_launch_c4(const GemmP& p, hipStream_t st) {
   q.c4_chunk = g_c4_chunk > 0 ? g_c4_chunk : chunk;
   const int chunks = (tiles + q.c4_chunk - 1) / q.c4_chunk;
   const int grid = chunks < 2 * c4_num_cus() ? chunks : 2 * c4_num_cus();   // two resident blocks per CU walk the tile list
-  if (p.ln_colsum) hipLaunchKernelGGL(k_gemm_c4<true>, dim3(grid), dim3(256), smem, st, q);
-  else hipLaunchKernelGGL(k_gemm_c4<false>, dim3(grid), dim3(256), smem, st, q);
+  if (p.ln_colsum) hipLaunchKernelGGL((k_gemm_c4<true, kBF>), dim3(grid), dim3(256), smem, st, q);
+  else hipLaunchKernelGGL((k_gemm_c4<false, kBF>), dim3(grid), dim3(256), smem, st, q);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }

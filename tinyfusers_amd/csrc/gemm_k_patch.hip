@@ -8,16 +8,16 @@ static int launch_patch(const GemmP& p, hipStream_t st) {
   const int smem = ring > scratch + tail ? ring : scratch + tail;
   static bool attr_set = false;
   if (!attr_set) {
-    TF_HIP(hipFuncSetAttribute((const void*)k_igemm_patch<BM, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-    TF_HIP(hipFuncSetAttribute((const void*)k_igemm_patch<BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    TF_HIP(hipFuncSetAttribute((const void*)k_igemm_patch<BM, BN, false, kBF>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    TF_HIP(hipFuncSetAttribute((const void*)k_igemm_patch<BM, BN, true, kBF>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     attr_set = true;
   }
-  if (p.gi_part) hipLaunchKernelGGL((k_igemm_patch<BM, BN, true>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
-  else hipLaunchKernelGGL((k_igemm_patch<BM, BN, false>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
+  if (p.gi_part) hipLaunchKernelGGL((k_igemm_patch<BM, BN, true, kBF>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
+  else hipLaunchKernelGGL((k_igemm_patch<BM, BN, false, kBF>), dim3(p.ntm * p.ntn * p.splitk), dim3(512), smem, st, p);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
-int tfk_launch_patch(const GemmP& p, hipStream_t st, int bm, int bn) {
+int TFK(tfk_launch_patch)(const GemmP& p, hipStream_t st, int bm, int bn) {
   if (bm == 128 && bn == 160) return launch_patch<128, 160>(p, st);
   if (bm == 64 && bn == 160) return launch_patch<64, 160>(p, st);
   if (bm == 128 && bn == 128) return launch_patch<128, 128>(p, st);

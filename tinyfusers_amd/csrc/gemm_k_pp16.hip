@@ -15,7 +15,7 @@ static int launch_pp16(const GemmP& p, hipStream_t st, int np_force) {
   }
   else { tf_set_error("k_igemm_pp: the 192-row tile has the one-phase form only"); return TF_E_UNSUPPORTED; }
 }
-int tfk_launch_pp16(const GemmP& p, hipStream_t st, int bm, int bn, int np_force) {
+int TFK(tfk_launch_pp16)(const GemmP& p, hipStream_t st, int bm, int bn, int np_force) {
   if (bm == 192 && bn == 128) return launch_pp16<128, 192>(p, st, np_force);
   if (bm == 192 && bn == 160) return launch_pp16<160, 192>(p, st, np_force);
   if (bm == 256 && bn == 128) return launch_pp16<128, 256>(p, st, np_force);

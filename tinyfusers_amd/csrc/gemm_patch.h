@@ -18,7 +18,7 @@
 //   Stages carry different numbers of loads, so the counted vmcnt waits follow the schedule (W in the loader loop).
 // MEASURED (tools/patch_bench.py, MI355X): 1.02-1.13x k_igemm on the long-K 3x3 shapes of the step (0.95-1.0x on the shortest
 // ones: the prologue stages a whole patch before the first barrier); one candidate of the per-shape autotuner.
-template <int BM, int BN, bool GI = false>
+template <int BM, int BN, bool GI = false, bool BF = false>   // BF: bfloat16 operands / outputs (gemm_k_patch_bf16.hip)
 __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
   constexpr int TM = BM / 2, TN = BN / 2, MJ = TM / 16, NI = TN / 16;
   constexpr int BNP = BN / 32;                            // weight pieces per loader wave per K tile
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
     auto gi_piece = [&](int G, int v, int i) {            // piece w4 + 4 i of patch(G); v = pp[i]
       if (w4 + 4 * i >= PPC) return;
       const unsigned a = lds_off(smem + (G & 1) * PB) + (unsigned)(w4 + 4 * i) * 1024u + lane * 16;
-      lds_write16(a, gi_apply(lds_read16(a), na, nb, p.gi_silu, v >= 0));
+      lds_write16(a, gi_apply<BF>(lds_read16(a), na, nb, p.gi_silu, v >= 0));
     };
     auto gi_range = [&](int G, int lo, int hi) {          // pieces lo <= i < hi of patch(G) (static register indices)
       if (ab_group != G) { gi_load_ab(p, smem, (G << 6) + cs * 8, na, nb); ab_group = G; }
@@ -212,13 +212,13 @@ __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();                         // barrier Y: the consumers' tiles are in the LDS scratch
     asm volatile("" ::: "memory");
-    igemm_epilogue<BM, BN>(p, smem, m0, n0, split, w4, 1, lane);
+    igemm_epilogue<BM, BN, 0, BF>(p, smem, m0, n0, split, w4, 1, lane);
     if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 1, lane);
     return;
   }
 
   // ================================= CONSUMER WAVES ===============================================
-  if constexpr (GI) gi_prologue(p, smem, m0 / p.HoWo, w4 * 64 + lane);
+  if constexpr (GI) gi_prologue<BF>(p, smem, m0 / p.HoWo, w4 * 64 + lane);
   const int wave_m = w4 & 1, wave_n = w4 >> 1;
   const int lr = lane & 15, lg = lane >> 4;
   f4 acc[NI][MJ];
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[k2][i], xf[k2][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < MJ; ++j) acc[i][j] = mfma16<BF>(wf[k2][i], xf[k2][j], acc[i][j]);
   };
   __builtin_amdgcn_s_barrier();                           // barrier P: tile 0 (and its patch) landed
   asm volatile("" ::: "memory");
@@ -308,6 +308,6 @@ __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                           // barrier Y
   asm volatile("" ::: "memory");
-  igemm_epilogue<BM, BN>(p, smem, m0, n0, split, w4, 0, lane);
+  igemm_epilogue<BM, BN, 0, BF>(p, smem, m0, n0, split, w4, 0, lane);
   if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 0, lane);
 }

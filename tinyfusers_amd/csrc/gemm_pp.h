@@ -59,8 +59,9 @@
 #ifndef TF_PP_PRIO
 #define TF_PP_PRIO 0      // experiment switch of tools' tagged builds: 0 = s_setprio 1 around every MFMA block (shipped), 1 = static priority for waves 4-7, 2 = none
 #endif
-template <int BN, int NP, bool FASTA, bool DBG = false, bool F8 = false, bool H2 = false, int BM = 256, bool LNF = false>
+template <int BN, int NP, bool FASTA, bool DBG = false, bool F8 = false, bool H2 = false, int BM = 256, bool LNF = false, bool BF = false>   // BF: bfloat16 operands / outputs (gemm_k_pp16_bf16.hip)
 __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
+  static_assert(!(BF && F8), "the e4m3 form has fp16 bias / residual / outputs");
   static_assert(!LNF || !F8, "the LayerNorm fold is an fp16 path");
   constexpr int TN = BN / 2, MJ = BM / 64, NI = TN / 16;
   constexpr int APW = BM / 64;                            // activation pieces (8 rows x 128 B) per wave and stage: BM / 8 pieces in front of the weight pieces
@@ -371,18 +372,10 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
   auto mma = [&]() {                                       // the MFMAs of every k-step held in registers
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (LNF) {
-      typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
-      const hh2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
 #pragma unroll
       for (int f = 0; f < KF; ++f)
 #pragma unroll
-        for (int j = 0; j < MJ; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            hh2 v = {xf[f][j][2 * e], xf[f][j][2 * e + 1]};
-            ls[j] = __builtin_amdgcn_fdot2(v, one2, ls[j], false);
-            lq[j] = __builtin_amdgcn_fdot2(v, v, lq[j], false);
-          }
+        for (int j = 0; j < MJ; ++j) dot2_stats<BF>(xf[f][j], ls[j], lq[j]);
     }
     if constexpr (DBG) {
       if (p.dbg & 2) {
@@ -420,7 +413,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
-          for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[f][i], xf[f][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < MJ; ++j) acc[i][j] = mfma16<BF>(wf[f][i], xf[f][j], acc[i][j]);
     }
     if (TF_PP_PRIO == 0) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -444,20 +437,12 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
     } else {
       if constexpr (LNF) {
         if (i == 0) {
-          typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
-          const hh2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
 #pragma unroll
-          for (int j = 0; j < MJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              hh2 v = {xf[f][j][2 * e], xf[f][j][2 * e + 1]};
-              ls[j] = __builtin_amdgcn_fdot2(v, one2, ls[j], false);
-              lq[j] = __builtin_amdgcn_fdot2(v, v, lq[j], false);
-            }
+          for (int j = 0; j < MJ; ++j) dot2_stats<BF>(xf[f][j], ls[j], lq[j]);
         }
       }
 #pragma unroll
-      for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[f][i], xf[f][j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < MJ; ++j) acc[i][j] = mfma16<BF>(wf[f][i], xf[f][j], acc[i][j]);
     }
   };
   auto barrier = [&]() {
@@ -470,10 +455,10 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
   const int lb_img0 = m0 / p.HoWo;
   float lb_b = 0.f, lb_c0 = 0.f, lb_c1 = 0.f;
   if (tid < BN && n0 + tid < p.N && p.splitk <= 1) {
-    if (p.bias) lb_b = (float)p.bias[n0 + tid];
+    if (p.bias) lb_b = e2f<BF>(p.bias[n0 + tid]);
     if (p.bias_nc) {
-      lb_c0 = (float)p.bias_nc[(long long)lb_img0 * p.bias_nc_stride + n0 + tid];
-      if ((lb_img0 + 1) * p.HoWo < p.M) lb_c1 = (float)p.bias_nc[(long long)(lb_img0 + 1) * p.bias_nc_stride + n0 + tid];
+      lb_c0 = e2f<BF>(p.bias_nc[(long long)lb_img0 * p.bias_nc_stride + n0 + tid]);
+      if ((lb_img0 + 1) * p.HoWo < p.M) lb_c1 = e2f<BF>(p.bias_nc[(long long)(lb_img0 + 1) * p.bias_nc_stride + n0 + tid]);
     }
   }
   // ---- prologue: the first D tiles, whole
@@ -625,7 +610,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp(const GemmP p) {
     barrier();
     // (two items' loads in flight at a time: half of the accumulators is still live during the first pass)
     if (F8 && BN == 128 && p.out8) igemm_epilogue<BS, BN, (F8 && BN == 128) ? 2 : 0, false, 2, true>(p, smem, m0 + sm * BS, n0, split, wid & 3, wid >> 2, lane, lbt, n0, lb_m1);   // (block-scaled GEGLU output: the host admits it for act = 1 and 128-wide tiles only)
-    else igemm_epilogue<BS, BN, false, false, 2, true>(p, smem, m0 + sm * BS, n0, split, wid & 3, wid >> 2, lane, lbt, n0, lb_m1);
+    else igemm_epilogue<BS, BN, false, BF, 2, true>(p, smem, m0 + sm * BS, n0, split, wid & 3, wid >> 2, lane, lbt, n0, lb_m1);
     if (p.gn_part && m0 + sm * BS < p.M) igemm_gn_stats<BS, BN>(p, smem, m0 + sm * BS, n0, wid & 3, wid >> 2, lane);   // (block-uniform: the barrier inside is safe)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     barrier();

@@ -50,8 +50,9 @@
 //   (zero codes; the weight bytes they meet belong to the next tap or row, finite e4m3 values, and contribute nothing) -- and a patch row's four scale bytes sit at
 //   an offset that is only 2-byte aligned (C / 32 = 10 bytes per pixel), so they travel as two buffer_load_ushort ... lds into two tables (blocks 0-1 | blocks 2-3; the
 //   second one out of range for the half slab: E8M0 0 instead of a neighbour's byte, which could be the NaN code).
-template <int BN, int W, bool F8 = false, bool H2 = false>
+template <int BN, int W, bool F8 = false, bool H2 = false, bool BF = false>   // BF: bfloat16 operands / outputs (gemm_k_pp3_bf16.hip)
 __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
+  static_assert(!(BF && F8), "the e4m3 form has fp16 bias / residual / outputs");
   static_assert(F8 || !H2, "the half-slab form is the e4m3 kernel's");
   constexpr int BM = 192, TN = BN / 2, MJ = 3, NI = TN / 16, NS = 3, D = NS - 1;
   constexpr int ES = F8 ? 1 : 2, SLAB = 128 / ES;          // bytes per element; channels of a slab (128 bytes of a patch row)
@@ -280,7 +281,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
-          for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[f][i], xf[f][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < MJ; ++j) acc[i][j] = mfma16<BF>(wf[f][i], xf[f][j], acc[i][j]);
     }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -293,8 +294,8 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
   // bias and time-embedding values of this tile's columns (as in k_igemm_pp; a tile lies inside one image)
   float lb_b = 0.f, lb_c0 = 0.f;
   if (tid < BN && n0 + tid < p.N) {
-    if (p.bias) lb_b = (float)p.bias[n0 + tid];
-    if (p.bias_nc) lb_c0 = (float)p.bias_nc[(long long)img * p.bias_nc_stride + n0 + tid];
+    if (p.bias) lb_b = e2f<BF>(p.bias[n0 + tid]);
+    if (p.bias_nc) lb_c0 = e2f<BF>(p.bias_nc[(long long)img * p.bias_nc_stride + n0 + tid]);
   }
 
   // ---- prologue: patch(0) whole, weight tiles 0 .. D - 1; tile 0's loads landed, the others in flight
@@ -407,7 +408,7 @@ __global__ void __launch_bounds__(512, 2) k_igemm_pp3(const GemmP p) {
     if ((wm >> 1) == sm) igemm_scratch_write<BS, BN>(p, acc, csum, smem, (wm & 1) | (wn << 1), lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     barrier();
-    igemm_epilogue<BS, BN, 0, false, 2, true>(p, smem, m0 + sm * BS, n0, 0, wid & 3, wid >> 2, lane, lbt, n0, lb_m1);
+    igemm_epilogue<BS, BN, 0, BF, 2, true>(p, smem, m0 + sm * BS, n0, 0, wid & 3, wid >> 2, lane, lbt, n0, lb_m1);
     if (p.gn_part) igemm_gn_stats<BS, BN>(p, smem, m0 + sm * BS, n0, wid & 3, wid >> 2, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     barrier();

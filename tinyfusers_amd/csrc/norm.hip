@@ -437,6 +437,11 @@ int tf_group_norm_bf16(void* y, const void* x, const void* x2, const void* gamma
 
 int tf_group_norm_apply_f16(void* y, const void* x, const void* gamma, const void* beta, const void* partial, int chunks, int N, int HW, int C, int G,
                             float eps, int silu, tfStream_t s) {
+  return tf_group_norm_apply_16(TF_DTYPE_F16, y, x, gamma, beta, partial, chunks, N, HW, C, G, eps, silu, s);
+}
+int tf_group_norm_apply_16(int dtype, void* y, const void* x, const void* gamma, const void* beta, const void* partial, int chunks, int N, int HW, int C, int G,
+                           float eps, int silu, tfStream_t s) {
+  TF_REQUIRE(dtype == TF_DTYPE_F16 || dtype == TF_DTYPE_BF16, "tf_group_norm_apply_16: dtype=%d (0 = float16, 1 = bfloat16)", dtype);
   TF_REQUIRE(y && x && partial, "tf_group_norm_apply_f16: null tensor");
   TF_REQUIRE((gamma == nullptr) == (beta == nullptr), "tf_group_norm_apply_f16: gamma and beta must both be given or both NULL");
   TF_REQUIRE(N >= 0 && HW >= 0 && G >= 1 && C > 0 && C % G == 0, "tf_group_norm_apply_f16: C=%d not divisible by G=%d", C, G);
@@ -447,7 +452,9 @@ int tf_group_norm_apply_f16(void* y, const void* x, const void* gamma, const voi
   gn_geometry(HW, C, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
   int tl = (threads + 7) & ~7;
   TfProfScope prof_(TF_PROF_FAM_GROUP_NORM, (double)N * HW * C * 4.0, tf_hs(s));
-  hipLaunchKernelGGL(k_gn_apply<0>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)nullptr,
+  if (dtype == TF_DTYPE_BF16) hipLaunchKernelGGL((k_gn_apply<0, bf16_t>), dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (bf16_t*)y, (const bf16_t*)x, (const bf16_t*)nullptr,
+                     (const bf16_t*)gamma, (const bf16_t*)beta, (const float*)partial, HW, C, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
+  else hipLaunchKernelGGL(k_gn_apply<0>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)nullptr,
                      (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
   TF_LAUNCH_CHECK();
   return TF_OK;
@@ -460,6 +467,12 @@ int tf_group_norm_apply_cat_f16(void* y, const void* x, const void* x2, const vo
                                 int groups1, const void* partial2, int chunks2, int groups2, int N, int HW, int C1, int C2, int G, float eps, int silu,
                                 tfStream_t s) {
   return gn_apply_cat(y, x, x2, gamma, beta, partial, chunks, groups1, partial2, chunks2, groups2, N, HW, C1, C2, G, eps, silu, 0, s);
+}
+int tf_group_norm_apply_cat_16(int dtype, void* y, const void* x, const void* x2, const void* gamma, const void* beta, const void* partial, int chunks,
+                               int groups1, const void* partial2, int chunks2, int groups2, int N, int HW, int C1, int C2, int G, float eps, int silu,
+                               tfStream_t s) {
+  TF_REQUIRE(dtype == TF_DTYPE_F16 || dtype == TF_DTYPE_BF16, "tf_group_norm_apply_cat_16: dtype=%d (0 = float16, 1 = bfloat16)", dtype);
+  return gn_apply_cat(y, x, x2, gamma, beta, partial, chunks, groups1, partial2, chunks2, groups2, N, HW, C1, C2, G, eps, silu, dtype == TF_DTYPE_BF16 ? 16 : 0, s);   // (out8 = 16: a bfloat16 tensor in, a bfloat16 tensor out)
 }
 /* the same with an e4m3 (fp8) output -- the operand of an fp8 conv (config 5); x2 / partial2 may be NULL (single source: groups1 = G).
  * mode 1: e4m3 at scale 1 (tf_group_norm_apply_fp8); mode 2: block-scaled e4m3 (tf_group_norm_apply_mx8: codes, then the E8M0 bytes) */
@@ -513,8 +526,11 @@ static int gn_apply_cat(void* y, const void* x, const void* x2, const void* gamm
   int CV, RPB, threads, sc, ppc, ablocks, appb;
   gn_geometry(HW, C, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
   int tl = (threads + 7) & ~7;
-  TfProfScope prof_(TF_PROF_FAM_GROUP_NORM, (double)N * HW * C * (out8 ? 3.0 : 4.0), tf_hs(s));
-  if (out8 == 2) hipLaunchKernelGGL(k_gn_apply<2>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
+  TfProfScope prof_(TF_PROF_FAM_GROUP_NORM, (double)N * HW * C * ((out8 == 1 || out8 == 2) ? 3.0 : 4.0), tf_hs(s));
+  if (out8 == 16) hipLaunchKernelGGL((k_gn_apply<0, bf16_t>), dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (bf16_t*)y, (const bf16_t*)x, (const bf16_t*)x2,
+                               (const bf16_t*)gamma, (const bf16_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB,
+                               (const float*)partial2, chunks2, groups1, groups2, cpg / sub);
+  else if (out8 == 2) hipLaunchKernelGGL(k_gn_apply<2>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
                                (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB,
                                (const float*)partial2, chunks2, groups1, groups2, cpg / sub);
   else if (out8) hipLaunchKernelGGL(k_gn_apply<1>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,

@@ -60,7 +60,7 @@ __device__ __forceinline__ SdpaBlk sdpa_block(const SdpaP& p, const int QB = 128
   return o;
 }
 
-template <int DQK, int DV>
+template <int DQK, int DV, bool BF = false>   // BF: bfloat16 q / k / v / o (sdpa_bf16.hip)
 __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
   constexpr int KS = DQK + 8;                 // K row stride (halves); 16-B multiple
   constexpr int VS = DV + 8;                  // V row stride (halves); 16-B multiple
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
       int d0 = ks * 32 + lg * 8;
       h8 qv = (qi < p.Tq && d0 < p.HS) ? *reinterpret_cast<const h8*>(qb + qi * p.q_st + d0) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) qv[j] = (half_t)((float)qv[j] * p.scale_log2e);
+      for (int j = 0; j < 8; ++j) qv[j] = f2e<BF>(e2f<BF>(qv[j]) * p.scale_log2e);
       qf[qt][ks] = qv;
     }
   }
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
   load_tile(0);
   __syncthreads();           // zero-fill complete before the first tile lands on top of it
   store_tile(0);
-  if (tid < 128) smem[(tid >> 6) * STAGE_H + 64 * KS + (tid & 63) * VS + DV - 1] = (half_t)1.0f;   // ones column -> row sums
+  if (tid < 128) smem[(tid >> 6) * STAGE_H + 64 * KS + (tid & 63) * VS + DV - 1] = f2e<BF>(1.0f);   // ones column -> row sums
   __syncthreads();
 
   for (int t = 0; t < ntiles; ++t) {
@@ -170,8 +170,8 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         h8 kf = *reinterpret_cast<const h8*>(ks_ + krow * KS + ks * 32 + lg * 8);
-        st[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], ks == 0 ? init4[0] : st[kt][0], 0, 0, 0);
-        st[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], ks == 0 ? init4[1] : st[kt][1], 0, 0, 0);
+        st[kt][0] = mfma16<BF>(kf, qf[0][ks], ks == 0 ? init4[0] : st[kt][0]);
+        st[kt][1] = mfma16<BF>(kf, qf[1][ks], ks == 0 ? init4[1] : st[kt][1]);
       }
     }
     // ---- masks: this lane's keys are t*64 + 32 (kt>>1) + 8 lg + 4 (kt&1) + reg
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pf[kt >> 1][qt][(kt & 1) * 4 + e] = (half_t)__builtin_amdgcn_exp2f(st[kt][qt][e]);
+        for (int e = 0; e < 4; ++e) pf[kt >> 1][qt][(kt & 1) * 4 + e] = f2e<BF>(__builtin_amdgcn_exp2f(st[kt][qt][e]));
     // ---- O^T += V^T P^T
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
@@ -239,8 +239,8 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
         s4v v0 = lds_tr16(va), v1 = lds_tr16(va + 4 * VS);
         union { struct { s4v a, b; } s; h8 h; } u;
         u.s.a = v0; u.s.b = v1;
-        ot[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.h, pf[kc][0], ot[dt][0], 0, 0, 0);
-        ot[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.h, pf[kc][1], ot[dt][1], 0, 0, 0);
+        ot[dt][0] = mfma16<BF>(u.h, pf[kc][0], ot[dt][0]);
+        ot[dt][1] = mfma16<BF>(u.h, pf[kc][1], ot[dt][1]);
       }
     }
     if (t + 1 < ntiles) store_tile(buf ^ 1);
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256) k_sdpa(const SdpaP p) {
         if (d < p.HS) {
           h4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[dt][qt][e] * inv);
+          for (int e = 0; e < 4; ++e) o[e] = f2e<BF>(ot[dt][qt][e] * inv);
           *reinterpret_cast<h4*>(ob + qi * p.o_st + d) = o;
         }
       }
@@ -333,8 +333,9 @@ struct SdpaDma {
 
 // NW = waves per block (4, or 8 for long sequences: twice the queries per fetched K/V tile -- the tile fetch, not the barrier, is what the
 // ablation prices at 19 % of the d = 40 loop at 9216 tokens -- and four waves per SIMD instead of three at two blocks per CU)
-template <int HS, int QT, int DBG = 0, int NW = 4>        // DBG: compile-time ablation mask (tools/sdpa_dbg.py; bits as SdpaP::dbg)
+template <int HS, int QT, int DBG = 0, int NW = 4, bool BF = false>        // DBG: compile-time ablation mask (tools/sdpa_dbg.py; bits as SdpaP::dbg); BF: bfloat16 q / k / v / o (sdpa_bf16.hip)
 __global__ void __launch_bounds__(NW * 64) k_sdpa_dma(const SdpaP p) {
+  static_assert(!(BF && DBG), "the ablation instances are fp16");
   constexpr int QW = 16 * QT, QB = NW * QW, NT = NW * 64;   // queries per wave / per block, threads
   using C = SdpaDma<HS>;
   constexpr int NKS = C::NKS, NDT = C::NDT, CK = C::CK, KPC = C::KPC, VPC = C::VPC, KP = C::KP, VP = C::VP, VSK = C::VSK, VGC = C::VGC;
@@ -358,7 +359,7 @@ __global__ void __launch_bounds__(NW * 64) k_sdpa_dma(const SdpaP p) {
     __syncthreads();                     // ones column of V (column HS of every key row, every ring stage): written once
     for (int i = tid; i < S * 64; i += NT) {
       int st_ = i >> 6, R = i & 63;
-      reinterpret_cast<half_t*>(smem_raw + st_ * STAGE_B + C::K_BYTES)[(R >> 3) * VGC * 8 + (R & 7) * VP + HS] = (half_t)1.0f;
+      reinterpret_cast<half_t*>(smem_raw + st_ * STAGE_B + C::K_BYTES)[(R >> 3) * VGC * 8 + (R & 7) * VP + HS] = f2e<BF>(1.0f);
     }
   }
 
@@ -371,7 +372,7 @@ __global__ void __launch_bounds__(NW * 64) k_sdpa_dma(const SdpaP p) {
       int d0 = ks * 32 + lg * 8;
       h8 qv = (qi < p.Tq && d0 < HS) ? *reinterpret_cast<const h8*>(qb + qi * p.q_st + d0) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) qv[j] = (half_t)((float)qv[j] * p.scale_log2e);
+      for (int j = 0; j < 8; ++j) qv[j] = f2e<BF>(e2f<BF>(qv[j]) * p.scale_log2e);
       qf[qt][ks] = qv;
     }
   }
@@ -422,7 +423,8 @@ __global__ void __launch_bounds__(NW * 64) k_sdpa_dma(const SdpaP p) {
   for (int q_ = 0; q_ < QT; ++q_) lt[q_] = (f4){0, 0, 0, 0};
   float m_run[QT];
   for (int q_ = 0; q_ < QT; ++q_) m_run[q_] = 0.f;
-  const h8 ones = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
+  const half_t one1 = f2e<BF>(1.f);
+  const h8 ones = {one1, one1, one1, one1, one1, one1, one1, one1};
 
   __syncthreads();                       // zero fill done (and drained) before the first DMA lands
 #pragma unroll
@@ -458,7 +460,7 @@ __global__ void __launch_bounds__(NW * 64) k_sdpa_dma(const SdpaP p) {
 #pragma unroll
         for (int q_ = 0; q_ < QT; ++q_) {
           if (DBG & 4) { if (ks == 0) st[kt][q_] = init4[q_] + (f4){(float)kf[0], (float)kf[1], (float)kf[2], (float)kf[3]}; }
-          else st[kt][q_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[q_][ks], ks == 0 ? init4[q_] : st[kt][q_], 0, 0, 0);
+          else st[kt][q_] = mfma16<BF>(kf, qf[q_][ks], ks == 0 ? init4[q_] : st[kt][q_]);
         }
       }
     }
@@ -516,12 +518,12 @@ __global__ void __launch_bounds__(NW * 64) k_sdpa_dma(const SdpaP p) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pf[kt >> 1][qt][(kt & 1) * 4 + e] = (DBG & 1) ? (half_t)st[kt][qt][e] : (half_t)__builtin_amdgcn_exp2f(st[kt][qt][e]);
+        for (int e = 0; e < 4; ++e) pf[kt >> 1][qt][(kt & 1) * 4 + e] = (DBG & 1) ? (half_t)st[kt][qt][e] : f2e<BF>(__builtin_amdgcn_exp2f(st[kt][qt][e]));
     if constexpr (!HAS_PAD) {
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc) {
 #pragma unroll
-        for (int q_ = 0; q_ < QT; ++q_) lt[q_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[kc][q_], lt[q_], 0, 0, 0);
+        for (int q_ = 0; q_ < QT; ++q_) lt[q_] = mfma16<BF>(ones, pf[kc][q_], lt[q_]);
       }
     }
 #pragma unroll
@@ -535,7 +537,7 @@ __global__ void __launch_bounds__(NW * 64) k_sdpa_dma(const SdpaP p) {
 #pragma unroll
         for (int q_ = 0; q_ < QT; ++q_) {
           if (DBG & 2) ot[dt][q_] += (f4){(float)u.h[0] * (float)pf[kc][q_][0], (float)u.h[1], (float)u.h[2], (float)pf[kc][q_][7]};
-          else ot[dt][q_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.h, pf[kc][q_], ot[dt][q_], 0, 0, 0);
+          else ot[dt][q_] = mfma16<BF>(u.h, pf[kc][q_], ot[dt][q_]);
         }
       }
     }
@@ -556,7 +558,7 @@ __global__ void __launch_bounds__(NW * 64) k_sdpa_dma(const SdpaP p) {
         if (d < HS) {
           h4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[dt][qt][e] * inv);
+          for (int e = 0; e < 4; ++e) o[e] = f2e<BF>(ot[dt][qt][e] * inv);
           *reinterpret_cast<h4*>(ob + qi * p.o_st + d) = o;
         }
       }
@@ -570,10 +572,10 @@ static int launch_sdpa_dma(const SdpaP& p, hipStream_t st) {
   constexpr int QB = 16 * NW * QT;
   static bool attr_set = false;
   if (!attr_set) {
-    TF_HIP(hipFuncSetAttribute((const void*)k_sdpa_dma<HS, QT, 0, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    TF_HIP(hipFuncSetAttribute((const void*)k_sdpa_dma<HS, QT, 0, NW, kBF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-#ifdef TF_ABLATION   // the ablation library only (python -m tinyfusers_amd.build --ablation; tools/sdpa_dbg.py): wrong results by design
+#if defined(TF_ABLATION) && !TF_TU_BF   // the ablation library only (python -m tinyfusers_amd.build --ablation; tools/sdpa_dbg.py): wrong results by design
   if constexpr (HS == 40 && QT == 2 && NW == 4) {
     if (p.dbg) {
       const dim3 grid((unsigned)((p.Tq + QB - 1) / QB * p.NH * p.B));
@@ -589,7 +591,7 @@ static int launch_sdpa_dma(const SdpaP& p, hipStream_t st) {
     }
   }
 #endif
-  hipLaunchKernelGGL((k_sdpa_dma<HS, QT, 0, NW>), dim3((unsigned)((p.Tq + QB - 1) / QB * p.NH * p.B)), dim3(NW * 64), smem, st, p);
+  hipLaunchKernelGGL((k_sdpa_dma<HS, QT, 0, NW, kBF>), dim3((unsigned)((p.Tq + QB - 1) / QB * p.NH * p.B)), dim3(NW * 64), smem, st, p);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
@@ -599,10 +601,10 @@ static int launch_sdpa(const SdpaP& p, hipStream_t st) {
   constexpr int smem = 2 * (64 * (DQK + 8) + 64 * (DV + 8)) * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    TF_HIP(hipFuncSetAttribute((const void*)k_sdpa<DQK, DV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    TF_HIP(hipFuncSetAttribute((const void*)k_sdpa<DQK, DV, kBF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_sdpa<DQK, DV>), dim3((unsigned)((p.Tq + 127) / 128 * p.NH * p.B)), dim3(256), smem, st, p);
+  hipLaunchKernelGGL((k_sdpa<DQK, DV, kBF>), dim3((unsigned)((p.Tq + 127) / 128 * p.NH * p.B)), dim3(256), smem, st, p);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
@@ -616,7 +618,22 @@ static const int g_sdpa_dbg = 0;   // the shipped library ignores TF_SDPA_DBG: i
 static int g_sdpa_nw = getenv("TF_SDPA_NW") ? atoi(getenv("TF_SDPA_NW")) : 0;      // A/B: 4 / 8 waves per block where both exist (0 = per-shape choice)
 static int g_sdpa_qt = getenv("TF_SDPA_QT") ? atoi(getenv("TF_SDPA_QT")) : 0;   // debugging: force the register-staged kernel
 
-extern "C" int tf_sdpa_f16(void* o, const void* q, const void* k, const void* v, int B, int NH, int Tq, int Tk, int HS, long long q_sb,
+// one body for both element types: this unit's kernels (kBF) behind tf_sdpa_f16 here, behind tfk_sdpa_bf16 in sdpa_bf16.hip (#define TF_TU_BF 1 + #include of this file)
+int tfk_sdpa_bf16(void* o, const void* q, const void* k, const void* v, int B, int NH, int Tq, int Tk, int HS, long long q_sb, long long q_sh, long long q_st, long long k_sb,
+                  long long k_sh, long long k_st, long long v_sb, long long v_sh, long long v_st, long long o_sb, long long o_sh, long long o_st, int causal, tfStream_t s);
+#if TF_TU_BF
+int tfk_sdpa_bf16(
+#else
+extern "C" int tf_sdpa_16(int dtype, void* o, const void* q, const void* k, const void* v, int B, int NH, int Tq, int Tk, int HS, long long q_sb, long long q_sh, long long q_st,
+                          long long k_sb, long long k_sh, long long k_st, long long v_sb, long long v_sh, long long v_st, long long o_sb, long long o_sh, long long o_st, int causal,
+                          tfStream_t s) {
+  if (dtype == TF_DTYPE_F16) return tf_sdpa_f16(o, q, k, v, B, NH, Tq, Tk, HS, q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st, causal, s);
+  TF_REQUIRE(dtype == TF_DTYPE_BF16, "tf_sdpa_16: dtype=%d (0 = float16, 1 = bfloat16)", dtype);
+  return tfk_sdpa_bf16(o, q, k, v, B, NH, Tq, Tk, HS, q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st, causal, s);
+}
+extern "C" int tf_sdpa_f16(
+#endif
+                           void* o, const void* q, const void* k, const void* v, int B, int NH, int Tq, int Tk, int HS, long long q_sb,
                            long long q_sh, long long q_st, long long k_sb, long long k_sh, long long k_st, long long v_sb, long long v_sh,
                            long long v_st, long long o_sb, long long o_sh, long long o_st, int causal, tfStream_t s) {
   TF_REQUIRE(o && q && k && v, "tf_sdpa_f16: null tensor");
