@@ -12,7 +12,7 @@ import numpy as np
 from .. import config
 from ..ff.group_norm import GroupNorm
 from ..ff.layer_norm import LayerNorm
-from ..ff.linear import Linear, fold_layer_norm, linear_any, linear_f16, linear_ln_f16, to_bf16, to_f16
+from ..ff.linear import Linear, fold_layer_norm, linear_any, linear_f16, linear_ln_f16
 from ..ff.nn import FeedForward
 from ..native import hip
 from ..storage.tensor import DeviceArray, _sh, is_bfloat16
@@ -96,7 +96,7 @@ class CrossAttention:
 
     def project_kv(self, context):
         """(b, tk, 2C) fused K|V projection of the context (computed once per UNet call by the model)."""
-        return to_f16(linear_any(context, self._fused_weights(False)))     # (bfloat16 step: the attention core reads fp16)
+        return linear_any(context, self._fused_weights(False))
 
     def __call__(self, x, context=None, residual=None, kv=None, ln=None):
         """ln: a LayerNorm to apply to x first, folded into the q (or q|k|v) projection (x is then the RAW input)."""
@@ -118,7 +118,7 @@ class CrossAttention:
             elif ln is not None:
                 qkv = linear_ln_f16(x, self._folded(ln, True), ln.eps)
             else:
-                qkv = to_f16(linear_any(x, self._fused_weights(True)))        # (b, t, 3C): q | k | v  (bfloat16 step: converted once for the fp16 attention core)
+                qkv = linear_any(x, self._fused_weights(True))        # (b, t, 3C): q | k | v
             q, k, v = qkv, qkv.view((b, t, 3 * c), "row", c), qkv.view((b, t, 3 * c), "row", 2 * c)
             tk, qs, ks = t, (t * 3 * c, hs, 3 * c), (t * 3 * c, hs, 3 * c)
         else:
@@ -126,7 +126,7 @@ class CrossAttention:
                 w8, wsc = fp8.pack_weight(self.to_q.weight, self._cache8["q"])
                 q = fp8.linear_mx(x8, w8, wsc, None)
             else:
-                q = linear_ln_f16(x, self._folded(ln, False), ln.eps) if ln is not None else to_f16(linear_any(x, self.to_q.weight))
+                q = linear_ln_f16(x, self._folded(ln, False), ln.eps) if ln is not None else linear_any(x, self.to_q.weight)
             if kv is None:
                 kv = self.project_kv(context)
             if hasattr(kv, "ld"):                          # column slice of the UNet's step-level K|V GEMM
@@ -137,14 +137,12 @@ class CrossAttention:
                 tk, ld = kv.shape[1], 2 * c
                 k, v = kv, kv.view(kv.shape, "row", c)
             qs, ks = (t * c, hs, c), (tk * ld, hs, ld)
-        o = DeviceArray.empty((b, t, c), np.float16, "row")
+        o = DeviceArray.empty((b, t, c), x.dtype, "row")       # (attention in the step's own 16-bit type: bfloat16 q / k / v run the bf16 kernels, no fp16 hop)
         if config.head_merge == "reference_exact":
             os_ = (nh * t * hs, t * hs, hs)      # (b,h,t,d) contiguous, then read as (b, t, h*d): attention.py:38-39
         else:
             os_ = (t * c, hs, c)                 # LDM-intended merge
         sdpa_strided(o, q, k, v, b, nh, t, tk, hs, qs, ks, ks, os_)
-        if is_bfloat16(x.dtype):
-            o = to_bf16(o)
         lo = self.to_out[0]
         if fp8.ATTENTION and fp8.linear_ok(b * t, lo.weight.shape[0], c):
             if getattr(self, "_cache8", None) is None:
@@ -165,7 +163,7 @@ class BasicTransformerBlock:
 
     def __call__(self, x, context=None, kv=None, defer_ff2=False):
         """defer_ff2: stop after GEGLU and return (hidden (b, t, 4*dim), x): the caller folds ff.net[2] into what follows."""
-        if config.fuse_layer_norm and x.shape[-1] % 64 == 0 and not is_bfloat16(x.dtype):
+        if config.fuse_layer_norm and x.shape[-1] % 64 == 0:
             x = self.attn1(x, residual=x, ln=self.norm1)
             x = self.attn2(x, context=context, residual=x, kv=kv, ln=self.norm2)
             if defer_ff2:
@@ -202,7 +200,7 @@ class SpatialTransformer:
             wp, bp = po.weight.numpy().reshape(c, -1), po.bias.numpy()
             wf = np.concatenate((wp @ w2, wp), axis=1).astype(np.float32)
             bf = (wp @ b2 + bp).astype(np.float32)
-            self._fold = (key, DeviceArray.from_numpy(wf.reshape(c, -1, 1, 1)), DeviceArray.from_numpy(bf, layout="row"))
+            self._fold = (key, DeviceArray.from_numpy(wf.reshape(c, -1, 1, 1), po.weight.dtype), DeviceArray.from_numpy(bf, po.bias.dtype, layout="row"))
         return self._fold[1], self._fold[2]
 
     def __call__(self, x, context=None, kv=None, out_gn=0, out_norm=None):
@@ -210,7 +208,7 @@ class SpatialTransformer:
         x_in = x
         x = self.proj_in(x, gn_in=(self.norm, False))    # GroupNorm -> 1x1 conv (attention.py:66-68) as one launch where the statistics came with x
         x = x.tokens()                                   # (b, hw, c): free re-view of NHWC (attention.py:71)
-        if config.fold_proj_out and config.dtype not in ("fp8", "bf16") and c % 8 == 0 and self.proj_out.weight.shape[0] == c:   # (fp8: the FeedForward runs in e4m3, proj_out stays fp16)
+        if config.fold_proj_out and config.dtype != "fp8" and c % 8 == 0 and self.proj_out.weight.shape[0] == c:   # (fp8: the FeedForward runs in e4m3, proj_out stays fp16)
             for block in self.transformer_blocks[:-1]:
                 x = block(x, context=context, kv=kv)
             hid, x2 = self.transformer_blocks[-1](x, context=context, kv=kv, defer_ff2=True)

@@ -3,12 +3,13 @@ One fused flash-style launch (tf_sdpa_f16); the (B,NH,Tq,Tk) score matrix never 
 import numpy as np
 
 from ..native import hip
-from ..storage.tensor import DeviceArray, _sh
+from ..storage.tensor import DeviceArray, _sh, dtag
 
 
 def sdpa_strided(o, q, k, v, B, NH, Tq, Tk, HS, qs, ks, vs, os_, causal=False):
     """Raw launch: q/k/v/o are DeviceArrays (or views), *s = (batch, head, token) element strides."""
-    hip.tf_sdpa_f16(o.ptr, q.ptr, k.ptr, v.ptr, B, NH, Tq, Tk, HS, *qs, *ks, *vs, *os_, 1 if causal else 0, _sh())
+    assert dtag(q.dtype) == dtag(k.dtype) == dtag(v.dtype) == dtag(o.dtype), "sdpa: q / k / v / o must hold the same 16-bit type"
+    hip.tf_sdpa_16(dtag(q.dtype), o.ptr, q.ptr, k.ptr, v.ptr, B, NH, Tq, Tk, HS, *qs, *ks, *vs, *os_, 1 if causal else 0, _sh())
     return o
 
 

@@ -357,11 +357,42 @@ __device__ __forceinline__ void igemm_scratch_write(const GemmP& p, f4 (&acc)[BN
       *reinterpret_cast<f4*>(sc + (j * 16 + lr) * RS + i * 16 + lg * 4) = acc[i][j];
 }
 
+// The epilogue's first batch of global loads (bias, time embedding, residual of the common 16-byte path), issued EARLY by k_igemm: the phase
+// stamps (profiles/r05_small_gemm_stamps.txt) show 0.8-2.8 us between "K loop done" and "stores issued", most of it one global round trip that
+// started only behind barrier X + scratch write + barrier Y.  A wave requests them when its K loop is over (the loader waves well before the
+// consumers' last MFMAs) and igemm_epilogue consumes the registers instead of loading.  Same values, same arithmetic: results are bit-identical.
+template <int BM, int BN, int KBMAX = 4>
+struct EpiPre {
+  static constexpr int ROWS = BM / 4, CPR = BN / 16, ITEMS = ROWS * CPR, ITER = (ITEMS + 63) / 64, KB = ITER < KBMAX ? ITER : KBMAX;
+  h8 bv[KB], cv[KB], rv[KB];
+  bool on;
+};
+template <int BM, int BN, int KBMAX = 4>
+__device__ __forceinline__ void igemm_epilogue_prefetch(const GemmP& p, int m0, int n0, int w4, int half, int lane, EpiPre<BM, BN, KBMAX>& r) {
+  typedef EpiPre<BM, BN, KBMAX> P;
+  r.on = p.act != 1 && (p.N & 7) == 0 && p.splitk <= 1 && !p.out32;
+  if (!r.on) return;
+  constexpr int TM = BM / 2, TN = BN / 2;
+  const int mb = m0 + (w4 & 1) * TM + half * P::ROWS, nb = n0 + (w4 >> 1) * TN;
+#pragma unroll
+  for (int k = 0; k < P::KB; ++k) {
+    const int idx = lane + 64 * k;
+    const int row = idx / P::CPR, c8 = idx - row * P::CPR;
+    const int m = mb + row, n = nb + c8 * 8;
+    if (idx < P::ITEMS && m < p.M && n < p.N) {
+      if (p.bias) r.bv[k] = *reinterpret_cast<const h8*>(p.bias + n);
+      if (p.bias_nc) r.cv[k] = *reinterpret_cast<const h8*>(p.bias_nc + (long long)(m / p.HoWo) * p.bias_nc_stride + n);
+      if (p.residual) r.rv[k] = *reinterpret_cast<const h8*>(p.residual + (long long)m * p.N + n);
+    }
+  }
+}
+
 // all 8 waves: wave (w4, half) stores rows [half*TM/2, (half+1)*TM/2) of consumer w4's tile
 // LB: bias and the time embedding (bias_nc) come from an fp32 LDS table `lb` the kernel filled for its tile ([0][BN]: bias, [1 + i][BN]:
 //   bias_nc of image lb_img0 + i, i < 2) instead of per-item global loads -- the only loads left in the epilogue are the residual's.
-template <int BM, int BN, int OUT8 = 0, bool BF = false, int KBMAX = 4, bool LB = false>     // OUT8: the output is stored as e4m3 -- 1: at scale 1 (k_igemm8), 2: block scaled (k_igemm_pp, GEGLU only: codes, then the E8M0 bytes behind the M x N/2 codes) -- a template parameter keeps it out of the fp16 kernels; BF: bias / residual / output are bfloat16; KBMAX: items whose loads are in flight together
-__device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m0, int n0, int split, int w4, int half, int lane, const float* lb = nullptr, int lb_n0 = 0, int lb_m1 = 0) {
+template <int BM, int BN, int OUT8 = 0, bool BF = false, int KBMAX = 4, bool LB = false, bool PRE = false>     // PRE: the first batch of loads arrives in `pre` (igemm_epilogue_prefetch); OUT8: the output is stored as e4m3 -- 1: at scale 1 (k_igemm8), 2: block scaled (k_igemm_pp, GEGLU only: codes, then the E8M0 bytes behind the M x N/2 codes) -- a template parameter keeps it out of the fp16 kernels; BF: bias / residual / output are bfloat16; KBMAX: items whose loads are in flight together
+__device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m0, int n0, int split, int w4, int half, int lane, const float* lb = nullptr, int lb_n0 = 0, int lb_m1 = 0,
+                                               const EpiPre<BM, BN, KBMAX>& pre = EpiPre<BM, BN, KBMAX>()) {
   typedef typename std::conditional<BF, bf16_t, half_t>::type E;
   typedef E E8 __attribute__((ext_vector_type(8)));
   const E* const e_bias = reinterpret_cast<const E*>(p.bias);
@@ -467,7 +498,9 @@ __device__ __forceinline__ void igemm_epilogue(const GemmP& p, char* smem, int m
       const int row = idx / CPR, c8 = idx - row * CPR;
       const int m = mb + row, n = nb + c8 * 8;
       ok[k] = k0 + k < ITER && idx < ITEMS && m < p.M && n < p.N;
-      if (ok[k]) {
+      if (PRE && k0 == 0) {                               // (k_igemm: this batch was requested when the wave's K loop ended; pre.on is implied by this branch)
+        bv[k] = __builtin_bit_cast(E8, pre.bv[k]); cv[k] = __builtin_bit_cast(E8, pre.cv[k]); rv[k] = __builtin_bit_cast(E8, pre.rv[k]);
+      } else if (ok[k]) {
         const long long o = (long long)m * p.N + n;
         if constexpr (!LB) {
           if (p.bias) bv[k] = *reinterpret_cast<const E8*>(e_bias + n);

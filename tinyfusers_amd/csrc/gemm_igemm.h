@@ -22,6 +22,7 @@
 template <int BM, int BN, bool GENERIC, bool WIDE, bool ALL8 = false, bool GI = false, bool BF = false>   // BF: bfloat16 operands / outputs (gemm_common.h: mfma16 / e2f / f2e)
 __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   constexpr int TM = BM / 2, TN = BN / 2, MJ = TM / 16, NI = TN / 16;
+  constexpr bool EPRE = !WIDE;                            // epilogue loads requested when the K loop ends (igemm_epilogue_prefetch); not on the 128-VGPR two-blocks-per-CU form (up to 48 registers)
   constexpr int NG = (BM + BN) / 8;                       // 8-row staging groups: activation rows first, then weight rows
   // weight pieces per CONSUMER wave per stage (the last 4 LPC groups); one more per wave measured 1-3 % slower on every shape
   constexpr int LPC = ALL8 ? (BN >= 128 ? (BM + BN >= 256 ? 3 : 2) : 1) : 0;
@@ -242,16 +243,23 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
       // Ring protocol (NS slots, tile t lives in slot t % NS).  Barrier P hands tile 0 to the consumers; barrier(it)
       // guarantees tile it+1 has landed (the consumers prefetch its fragments while multiplying tile it) and hands
       // slot it % NS back (the consumers drained their reads of tile it before arriving).  NS-1 tiles stay in flight.
+      // (round 5: only PRE = 2 stages are issued in front of barrier P -- the stamps showed the consumers waiting 0.6-1.2 us for nothing but the
+      // ISSUE of ring slots 2 .. NS-1, at 60-100 cycles per 1-KiB piece; the rest of the ring follows right behind the barrier)
+      constexpr int PRE = NS < 2 ? NS : 2;
 #pragma unroll
-      for (int s_ = 0; s_ < NS; ++s_)
+      for (int s_ = 0; s_ < PRE; ++s_)
         if (s_ < nt) stage(s_, kt_begin + s_);
       if (gi_on) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }   // barriers A, B of gi_prologue (consumer waves)
-      wait_stages<LPS, NS - 1>(nt - 1);                    // tile 0 landed; up to NS-1 newer stages in flight
+      wait_stages<LPS, PRE - 1>(nt - 1);                   // tile 0 landed; up to PRE-1 newer stages in flight
 #if TF_IGEMM_STAMP
       IG_STAMP(stp1);
 #endif
       if (gi_on && nt > 0) gi_tile(0, kt_begin);
       __builtin_amdgcn_s_barrier();                       // barrier P
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int s_ = PRE; s_ < NS; ++s_)
+        if (s_ < nt) stage(s_, kt_begin + s_);
       if (ln_on && nt > 0) ln_tile(0);                    // slot 0 is refilled only after barrier(0)
       asm volatile("" ::: "memory");
       for (int it = 0; it < nt; ++it) {
@@ -263,6 +271,8 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
         if (ln_on && it + 1 < nt) ln_tile((it + 1) % NS);  // tile it+1 stays in its slot until barrier(it+1)
       }
     }
+    EpiPre<BM, BN> epre;
+    if constexpr (EPRE) igemm_epilogue_prefetch<BM, BN>(p, m0, n0, w4, 1, lane, epre);     // (no counted vmcnt wait follows in this wave)
     // LayerNorm fold: finish (mean, rstd) of the rows this wave staged while the consumers drain their last MFMAs
     f2 lstat[LPS];
     if (ln_on) {
@@ -297,7 +307,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
     }
     __builtin_amdgcn_s_barrier();                         // barrier Y: the consumers' tiles are in the LDS scratch
     asm volatile("" ::: "memory");
-    igemm_epilogue<BM, BN, false, BF>(p, smem, m0, n0, split, w4, 1, lane);
+    igemm_epilogue<BM, BN, false, BF, 4, false, EPRE>(p, smem, m0, n0, split, w4, 1, lane, nullptr, 0, 0, epre);
     if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 1, lane);
 #if TF_IGEMM_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -457,14 +467,20 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
 #pragma unroll
         for (int j = 0; j < MJ; ++j) acc[i][j] = mfma16<BF>(wf[k2][i], xf[k2][j], acc[i][j]);
   };
+  constexpr int PRE = NS < 2 ? NS : 2;                     // (as the loaders: two stages in front of barrier P, the rest of the ring behind it)
   if constexpr (ALL8) {
 #pragma unroll
-    for (int s_ = 0; s_ < NS; ++s_)
+    for (int s_ = 0; s_ < PRE; ++s_)
       if (s_ < nt) cstage(s_, kt_begin + s_);
-    wait_stages<LPC, NS - 1>(nt - 1);                      // this wave's pieces of tile 0 landed
+    wait_stages<LPC, PRE - 1>(nt - 1);                     // this wave's pieces of tile 0 landed
   }
   __builtin_amdgcn_s_barrier();                           // barrier P: tile 0 landed
   asm volatile("" ::: "memory");
+  if constexpr (ALL8) {
+#pragma unroll
+    for (int s_ = PRE; s_ < NS; ++s_)
+      if (s_ < nt) cstage(s_, kt_begin + s_);
+  }
   if (nt > 0) read_frags(0, wfA, xfA);
   for (int it = 0; it < nt; it += 2) {
     wait_lds_reads();    // fragments of tile it are in registers: its slot may be refilled
@@ -488,6 +504,8 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
     __builtin_amdgcn_sched_barrier(0);
   }
   }
+  EpiPre<BM, BN> epre;
+  if constexpr (EPRE) igemm_epilogue_prefetch<BM, BN>(p, m0, n0, w4, 0, lane, epre);       // the K loop is over (its fragments are dead): the epilogue's loads fly under barriers X / Y and the scratch write
   __builtin_amdgcn_s_barrier();                           // barrier X: every consumer is done with the ring
   asm volatile("" ::: "memory");
 #if TF_IGEMM_STAMP
@@ -509,7 +527,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                           // barrier Y
   asm volatile("" ::: "memory");
-  igemm_epilogue<BM, BN, false, BF>(p, smem, m0, n0, split, w4, 0, lane);
+  igemm_epilogue<BM, BN, false, BF, 4, false, EPRE>(p, smem, m0, n0, split, w4, 0, lane, nullptr, 0, 0, epre);
   if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 0, lane);
 #if TF_IGEMM_STAMP
   IG_STAMP(stp2);

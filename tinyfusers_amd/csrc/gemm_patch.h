@@ -181,17 +181,20 @@ __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
     auto advance = [&]() { if (ng >= G1) ++ng; else if (++ntap == 9) { ntap = 0; ++ng; } };
     advance();                                             // tile 1
     {
+      // (round 5, as in k_igemm: two stages in front of barrier P, the rest of the ring right behind it -- the consumers were waiting for the ISSUE of
+      // ring slots 2 .. NS-1, not for data: profiles/r05_small_gemm_stamps.txt)
       int s_ = 0;
-      for (; s_ < NS && s_ < nt; ++s_) { int n = stage(s_); if (s_ > 0) W += n; }
+      for (; s_ < 2 && s_ < NS && s_ < nt; ++s_) { int n = stage(s_); if (s_ > 0) W += n; }
       if (gi_on) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }   // barriers A, B of gi_prologue (consumer waves)
       wait_vm_dyn(W);                                      // tile 0 (and everything issued before it) landed
       if (gi_on && pro_g >= 0) {
         gi_range(pro_g, 0, TF_PATCH_PPW);
         if (pro_next > 0) gi_range(pro_g + 1, 0, pro_next);
       }
+      __builtin_amdgcn_s_barrier();                       // barrier P
+      asm volatile("" ::: "memory");
+      for (; s_ < NS && s_ < nt; ++s_) W += stage(s_);
     }
-    __builtin_amdgcn_s_barrier();                         // barrier P
-    asm volatile("" ::: "memory");
     int slot = 0;
     for (int it = 0; it < nt; ++it) {
       if (it + 1 < nt) {
@@ -208,11 +211,13 @@ __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
       if (it + NS < nt) W += stage(slot);
       if (++slot == NS) slot = 0;
     }
+    EpiPre<BM, BN> epre;
+    igemm_epilogue_prefetch<BM, BN>(p, m0, n0, w4, 1, lane, epre);     // the epilogue's first loads, requested now (no counted vmcnt wait follows in this wave)
     __builtin_amdgcn_s_barrier();                         // barrier X
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();                         // barrier Y: the consumers' tiles are in the LDS scratch
     asm volatile("" ::: "memory");
-    igemm_epilogue<BM, BN, 0, BF>(p, smem, m0, n0, split, w4, 1, lane);
+    igemm_epilogue<BM, BN, 0, BF, 4, false, true>(p, smem, m0, n0, split, w4, 1, lane, nullptr, 0, 0, epre);
     if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 1, lane);
     return;
   }
@@ -302,12 +307,14 @@ __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
     mma(wfB, xfB);
     __builtin_amdgcn_sched_barrier(0);
   }
+  EpiPre<BM, BN> epre;
+  igemm_epilogue_prefetch<BM, BN>(p, m0, n0, w4, 0, lane, epre);       // the K loop is over: the epilogue's loads fly under barriers X / Y and the scratch write
   __builtin_amdgcn_s_barrier();                           // barrier X: every consumer is done with the ring and the patches
   asm volatile("" ::: "memory");
   igemm_scratch_write<BM, BN>(p, acc, csum, smem, w4, lane);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                           // barrier Y
   asm volatile("" ::: "memory");
-  igemm_epilogue<BM, BN, 0, BF>(p, smem, m0, n0, split, w4, 0, lane);
+  igemm_epilogue<BM, BN, 0, BF, 4, false, true>(p, smem, m0, n0, split, w4, 0, lane, nullptr, 0, 0, epre);
   if (p.gn_part) igemm_gn_stats<BM, BN>(p, smem, m0, n0, w4, 0, lane);
 }

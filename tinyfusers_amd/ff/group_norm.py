@@ -5,7 +5,7 @@ import numpy as np
 
 from .. import config
 from ..native import hip
-from ..storage.tensor import DeviceArray, _sh, asarray, is_bfloat16
+from ..storage.tensor import DeviceArray, _sh, asarray, dtag, is_bfloat16
 from .linear import workspace
 
 
@@ -15,19 +15,12 @@ def _gn(x, num_groups, eps, gamma, beta, silu):
         x, x2 = x
     n, c1, h, w = x.shape
     c2 = x2.shape[1] if x2 is not None else 0
-    if is_bfloat16(x.dtype):                           # bfloat16 tensors (tests/group_norm.py:12-19): the stand-alone two-pass form
-        y = DeviceArray.empty((n, c1 + c2, h, w), x.dtype, "nhwc")
-        nb = hip.tf_group_norm_workspace(n, h * w, c1 + c2, num_groups)
-        ws = workspace(nb)
-        hip.tf_group_norm_bf16(y.ptr, x.ptr, x2.ptr if x2 is not None else None, gamma.ptr if gamma is not None else None,
-                               beta.ptr if beta is not None else None, n, h * w, c1, c2, num_groups, float(eps), 1 if silu else 0,
-                               ws.ptr, nb, _sh())
-        return y
-    y = DeviceArray.empty((n, c1 + c2, h, w), np.float16, "nhwc")
+    dt = dtag(x.dtype)
+    y = DeviceArray.empty((n, c1 + c2, h, w), x.dtype, "nhwc")
     if x2 is None and x.gn is not None and x.gn[2] == num_groups:
         part, chunks, _ = x.gn                         # statistics came with x from the conv that produced it
-        hip.tf_group_norm_apply_f16(y.ptr, x.ptr, gamma.ptr if gamma is not None else None, beta.ptr if beta is not None else None,
-                                    part.ptr, chunks, n, h * w, c1, num_groups, float(eps), 1 if silu else 0, _sh())
+        hip.tf_group_norm_apply_16(dt, y.ptr, x.ptr, gamma.ptr if gamma is not None else None, beta.ptr if beta is not None else None,
+                                   part.ptr, chunks, n, h * w, c1, num_groups, float(eps), 1 if silu else 0, _sh())
         return y
     if config.concat_stats and x2 is not None and x.gn is not None and x2.gn is not None:
         # concat whose statistics came with its two sources: their partials' sub-groups (equal width) tile the concat's groups --
@@ -35,15 +28,15 @@ def _gn(x, num_groups, eps, gamma, beta, silu):
         g1, g2 = x.gn[2], x2.gn[2]
         cpg = (c1 + c2) // num_groups
         if c1 % g1 == 0 and c2 % g2 == 0 and c1 // g1 == c2 // g2 and cpg % (c1 // g1) == 0 and cpg // (c1 // g1) <= 8:
-            hip.tf_group_norm_apply_cat_f16(y.ptr, x.ptr, x2.ptr, gamma.ptr if gamma is not None else None, beta.ptr if beta is not None else None,
-                                            x.gn[0].ptr, x.gn[1], g1, x2.gn[0].ptr, x2.gn[1], g2, n, h * w, c1, c2, num_groups, float(eps),
-                                            1 if silu else 0, _sh())
+            hip.tf_group_norm_apply_cat_16(dt, y.ptr, x.ptr, x2.ptr, gamma.ptr if gamma is not None else None, beta.ptr if beta is not None else None,
+                                           x.gn[0].ptr, x.gn[1], g1, x2.gn[0].ptr, x2.gn[1], g2, n, h * w, c1, c2, num_groups, float(eps),
+                                           1 if silu else 0, _sh())
             return y
     nb = hip.tf_group_norm_workspace(n, h * w, c1 + c2, num_groups)
     ws = workspace(nb)
-    hip.tf_group_norm_f16(y.ptr, x.ptr, x2.ptr if x2 is not None else None, gamma.ptr if gamma is not None else None,
-                          beta.ptr if beta is not None else None, n, h * w, c1, c2, num_groups, float(eps), 1 if silu else 0,
-                          ws.ptr, nb, _sh())
+    (hip.tf_group_norm_bf16 if dt else hip.tf_group_norm_f16)(y.ptr, x.ptr, x2.ptr if x2 is not None else None, gamma.ptr if gamma is not None else None,
+                                                              beta.ptr if beta is not None else None, n, h * w, c1, c2, num_groups, float(eps), 1 if silu else 0,
+                                                              ws.ptr, nb, _sh())
     return y
 
 

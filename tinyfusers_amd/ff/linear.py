@@ -4,7 +4,7 @@ GEMV (tf_gemv_f16) for <= 8 rows (time-embedding MLP, ResBlock emb_layers)."""
 import numpy as np
 
 from ..native import hip
-from ..storage.tensor import DeviceArray, _sh, asarray, is_bfloat16
+from ..storage.tensor import DeviceArray, _sh, asarray, dtag, is_bfloat16
 
 
 def workspace(nbytes):
@@ -12,15 +12,17 @@ def workspace(nbytes):
 
 
 def linear_f16(x, w, b=None, residual=None, act=0, out_features=None):
-    """y = act(x . w^T + b) + residual on raw DeviceArrays (x (..., K) row-major, w (N, K))."""
+    """y = act(x . w^T + b) + residual on raw DeviceArrays (x (..., K) row-major, w (N, K)); float16 or -- every tensor alike -- bfloat16
+    (tf_linear_16: the same tuned kernels, the element type is a tag)."""
     K = x.shape[-1]
     rows = x.size // K
     n_out = out_features if out_features is not None else w.shape[0]
-    y = DeviceArray.empty(x.shape[:-1] + (n_out,), np.float16, "row")
+    assert dtag(w.dtype) == dtag(x.dtype) and (b is None or dtag(b.dtype) == dtag(x.dtype)) and (residual is None or dtag(residual.dtype) == dtag(x.dtype)), "linear: mixed element types"
+    y = DeviceArray.empty(x.shape[:-1] + (n_out,), x.dtype, "row")
     nb = hip.tf_linear_workspace(rows, n_out, K, act)
     ws = workspace(nb)
-    hip.tf_linear_f16(y.ptr, x.ptr, w.ptr, b.ptr if b is not None else None, residual.ptr if residual is not None else None,
-                      rows, n_out, K, act, ws.ptr if ws else None, nb, _sh())
+    hip.tf_linear_16(dtag(x.dtype), y.ptr, x.ptr, w.ptr, b.ptr if b is not None else None, residual.ptr if residual is not None else None,
+                     rows, n_out, K, act, ws.ptr if ws else None, nb, _sh())
     return y
 
 
@@ -46,9 +48,7 @@ def linear_act_bf16(x, w, b=None, residual=None, act=0, out_features=None):
 
 
 def linear_any(x, w, b=None, residual=None, act=0, out_features=None):
-    """linear_f16 or its bfloat16 form, by the element type of x."""
-    if is_bfloat16(x.dtype):
-        return linear_act_bf16(x, w, b, residual, act, out_features)
+    """(round 4 name) linear_f16 takes either element type since round 5."""
     return linear_f16(x, w, b, residual, act, out_features)
 
 
@@ -73,18 +73,18 @@ def to_bf16(x):
 def gemv_f16(x, w, b=None, silu_input=False):
     K = x.shape[-1]
     rows = x.size // K
-    y = DeviceArray.empty(x.shape[:-1] + (w.shape[0],), np.float16, "row")
-    hip.tf_gemv_f16(y.ptr, x.ptr, w.ptr, b.ptr if b is not None else None, rows, w.shape[0], K, 1 if silu_input else 0, _sh())
+    y = DeviceArray.empty(x.shape[:-1] + (w.shape[0],), x.dtype, "row")
+    hip.tf_gemv_16(dtag(x.dtype), y.ptr, x.ptr, w.ptr, b.ptr if b is not None else None, rows, w.shape[0], K, 1 if silu_input else 0, _sh())
     return y
 
 
 def fold_layer_norm(w, b, ln):
     """(w', bias', colsum) of Linear(LayerNorm(.)) for tf_linear_ln_f16; w (N,K), b (N,) or None, ln a LayerNorm."""
     n, k = w.shape
-    wf = DeviceArray.empty((n, k), np.float16, "row")
-    bf = DeviceArray.empty((n,), np.float16, "row")
+    wf = DeviceArray.empty((n, k), w.dtype, "row")
+    bf = DeviceArray.empty((n,), w.dtype, "row")
     cs = DeviceArray.empty((n,), np.float32, "row")
-    hip.tf_ln_fold_weights_f16(wf.ptr, bf.ptr, cs.ptr, w.ptr, b.ptr if b is not None else None, ln.weight.ptr, ln.bias.ptr, n, k, _sh())
+    hip.tf_ln_fold_weights_16(dtag(w.dtype), wf.ptr, bf.ptr, cs.ptr, w.ptr, b.ptr if b is not None else None, ln.weight.ptr, ln.bias.ptr, n, k, _sh())
     return wf, bf, cs
 
 
@@ -94,9 +94,9 @@ def linear_ln_f16(x, folded, eps, residual=None, act=0, out_features=None):
     K = x.shape[-1]
     rows = x.size // K
     n_out = out_features if out_features is not None else wf.shape[0]
-    y = DeviceArray.empty(x.shape[:-1] + (n_out,), np.float16, "row")
-    hip.tf_linear_ln_f16(y.ptr, x.ptr, wf.ptr, bf.ptr, cs.ptr, residual.ptr if residual is not None else None, rows, n_out, K, act,
-                         float(np.asarray(eps).reshape(-1)[0]), _sh())
+    y = DeviceArray.empty(x.shape[:-1] + (n_out,), x.dtype, "row")
+    hip.tf_linear_ln_16(dtag(x.dtype), y.ptr, x.ptr, wf.ptr, bf.ptr, cs.ptr, residual.ptr if residual is not None else None, rows, n_out, K, act,
+                        float(np.asarray(eps).reshape(-1)[0]), _sh())
     return y
 
 
@@ -190,12 +190,6 @@ class Linear:
     def __call__(self, x, residual=None, silu_input=False):
         assert x.layout == "row" and x.shape[-1] == self.weight.shape[1], (x.shape, self.weight.shape)
         rows = x.size // x.shape[-1]
-        if is_bfloat16(x.dtype):
-            if silu_input:
-                xs = DeviceArray.empty(x.shape, x.dtype, x.layout)
-                hip.tf_silu_bf16(xs.ptr, x.ptr, x.size, _sh())
-                x = xs
-            return linear_bf16(x, self.weight, self.bias, residual)
         if rows <= 8 and residual is None:
             return gemv_f16(x, self.weight, self.bias, silu_input)
         assert not silu_input

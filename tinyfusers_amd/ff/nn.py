@@ -55,6 +55,7 @@ class GEGLU:
             wp, bp = self._pack()
             return linear_any(x, wp, bp, None, act=1, out_features=self.dim_out)
         h = self.proj(x)                                   # unfused fallback shape (still HIP): split + a*gelu(gate)
+        assert h.dtype == np.float16, "unfused GEGLU fallback: fp16 only"
         y = DeviceArray.empty(x.shape[:-1] + (self.dim_out,), np.float16, "row")
         hip.tf_geglu_f16(y.ptr, h.ptr, h.size // h.shape[-1], self.dim_out, _sh())
         return y

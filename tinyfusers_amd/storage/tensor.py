@@ -258,6 +258,11 @@ def is_bfloat16(dtype):
     return bool(md and md.get("bfloat16"))
 
 
+def dtag(dtype):
+    """TF_DTYPE_* tag of the C-ABI's dtype-tagged entries (tf_*_16): 0 = float16, 1 = bfloat16."""
+    return 1 if is_bfloat16(dtype) else 0
+
+
 def f32_to_bf16_bits(x):
     """float array -> uint16 bfloat16 bit patterns, round-to-nearest-even (what v_cvt_pk_bf16_f32 does); NaN stays NaN."""
     u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
@@ -401,9 +406,9 @@ class DeviceArray:
         return out
 
     def __add__(self, other):
-        assert isinstance(other, DeviceArray) and other.size == self.size and self.dtype == np.float16
+        assert isinstance(other, DeviceArray) and other.size == self.size and self.dtype.itemsize == 2 and dtag(other.dtype) == dtag(self.dtype)
         out = DeviceArray.empty(self.shape, self.dtype, self.layout)
-        hip.tf_add_f16(out.ptr, self.ptr, other.ptr, self.size, _sh())
+        hip.tf_add_16(dtag(self.dtype), out.ptr, self.ptr, other.ptr, self.size, _sh())
         return out
 
     def __repr__(self):

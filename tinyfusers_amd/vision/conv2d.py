@@ -10,7 +10,7 @@ import numpy as np
 
 from .. import config
 from ..native import hip, lib
-from ..storage.tensor import DeviceArray, _sh, asarray, is_bfloat16
+from ..storage.tensor import DeviceArray, _sh, asarray, dtag, is_bfloat16
 from ..ff.linear import workspace, linear_f16
 
 
@@ -92,7 +92,9 @@ def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, up
     up = 1 if upsample else 0
     ho = ((h << up) + 2 * padding[0] - r) // stride[0] + 1
     wo = ((wd << up) + 2 * padding[1] - s) // stride[1] + 1
-    y = out if out is not None else DeviceArray.empty((n, k, ho, wo), np.float16, "nhwc")
+    dt = dtag(x.dtype)
+    assert dtag(w.dtype) == dt, "conv: activations and weights must hold the same 16-bit type"
+    y = out if out is not None else DeviceArray.empty((n, k, ho, wo), x.dtype, "nhwc")
     assert y.shape == (n, k, ho, wo) and y.layout == "nhwc"
     nb = hip.tf_conv2d_fused_workspace(n, h, wd, c1, c2, k, r, s, stride[0], padding[0], up, c3, c4)
     ws = workspace(nb)
@@ -108,7 +110,7 @@ def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, up
         if gn:
             pb = hip.tf_conv2d_gn_partial_bytes(n, gn)
             part = workspace(pb)
-        hip.tf_conv2d_gn_f16(*args, *ex, part.ptr if part is not None else None, pb, gn, ctypes.byref(chunks), *gi, 1 if gn_in[1] else 0, _sh())
+        hip.tf_conv2d_gn_16(dt, *args, *ex, part.ptr if part is not None else None, pb, gn, ctypes.byref(chunks), *gi, 1 if gn_in[1] else 0, _sh())
         if chunks.value > 0:
             y.gn = (part, chunks.value, gn)
         y._base = (y._base, x.gn[0], x2.gn[0] if x2 is not None else None)   # the statistics stay referenced while the launch is queued
@@ -116,9 +118,9 @@ def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, up
         # ... and, behind a split-K shape, is applied by the reduce kernel as well: z rides along with y
         pb = hip.tf_conv2d_gn_partial_bytes(n, gn)
         part, chunks, zw = workspace(pb), ctypes.c_int(0), ctypes.c_int(0)
-        z = DeviceArray.empty((n, k, ho, wo), np.float16, "nhwc")
+        z = DeviceArray.empty((n, k, ho, wo), x.dtype, "nhwc")
         nm = out_norm[0]
-        hip.tf_conv2d_fused_norm_f16(*args, *ex, part.ptr, pb, gn, ctypes.byref(chunks), z.ptr, nm.weight.ptr if nm.weight is not None else None,
+        hip.tf_conv2d_fused_norm_16(dt, *args, *ex, part.ptr, pb, gn, ctypes.byref(chunks), z.ptr, nm.weight.ptr if nm.weight is not None else None,
                                      nm.bias.ptr if nm.bias is not None else None, float(nm.eps), 1 if out_norm[1] else 0, ctypes.byref(zw), _sh())
         if chunks.value > 0:
             y.gn = (part, chunks.value, gn)
@@ -128,13 +130,11 @@ def _conv(x, w, bias, padding, stride, dilation, bias_nc=None, residual=None, up
         # the GroupNorm(gn) that consumes y next gets its statistics from this conv's epilogue (when the shape allows)
         pb = hip.tf_conv2d_gn_partial_bytes(n, gn)
         part, chunks = workspace(pb), ctypes.c_int(0)
-        hip.tf_conv2d_fused_f16(*args, *ex, part.ptr, pb, gn, ctypes.byref(chunks), _sh())
+        hip.tf_conv2d_fused_16(dt, *args, *ex, part.ptr, pb, gn, ctypes.byref(chunks), _sh())
         if chunks.value > 0:
             y.gn = (part, chunks.value, gn)
-    elif extra is not None:
-        hip.tf_conv2d_fused_f16(*args, *ex, None, 0, 0, None, _sh())
     else:
-        hip.tf_conv2d_f16(*args, _sh())
+        hip.tf_conv2d_fused_16(dt, *args, *ex, None, 0, 0, None, _sh())
     return y
 
 
@@ -152,24 +152,24 @@ def _conv_small_c(x, w, bias, padding, stride, cache, gn=0):
     wo = (wd + 2 * padding[1] - s) // stride[1] + 1
     key = (w.wkey, kpad)
     if cache.get("key") != key:
-        wp = DeviceArray.zeros((k, kpad), np.float16, "row")
+        wp = DeviceArray.zeros((k, kpad), w.dtype, "row")
         hip.tf_memcpy_2d_async(wp.ptr, kpad * 2, w.ptr, kk * 2, kk * 2, k, _sh())
         cache["key"], cache["w"] = key, wp
     if n * ho * wo * kpad * 2 <= _BAND_BYTES:
-        col = DeviceArray.empty((n * ho * wo, kpad), np.float16, "row")
-        hip.tf_im2col_nhwc_f16(col.ptr, x.ptr, n, h, wd, c, r, s, stride[0], padding[0], kpad, _sh())
+        col = DeviceArray.empty((n * ho * wo, kpad), x.dtype, "row")
+        hip.tf_im2col_nhwc_f16(col.ptr, x.ptr, n, h, wd, c, r, s, stride[0], padding[0], kpad, _sh())     # (a 2-byte gather: either element type)
         return _conv(col.view((n, kpad, ho, wo), "nhwc"), cache["w"].view((k, kpad, 1, 1), "nhwc"), bias, [0, 0], [1, 1], [1, 1], gn=gn)
     # large images (the reference's own conv test is 10000 x 10000, tests/conv2d.py:13-33): bands of output rows, image by image,
     # each band's patch matrix and GEMM operands far below the 2 GiB one buffer descriptor spans
     assert gn == 0, "banded small-C conv: no GroupNorm statistics"
-    y = DeviceArray.empty((n, k, ho, wo), np.float16, "nhwc")
+    y = DeviceArray.empty((n, k, ho, wo), x.dtype, "nhwc")
     rows = max(1, _BAND_BYTES // (wo * kpad * 2))
     wv = cache["w"].view((k, kpad, 1, 1), "nhwc")
     for img in range(n):
         xi = x.view((1, c, h, wd), "nhwc", img * h * wd * c)
         for o0 in range(0, ho, rows):
             o1 = min(ho, o0 + rows)
-            col = DeviceArray.empty(((o1 - o0) * wo, kpad), np.float16, "row")
+            col = DeviceArray.empty(((o1 - o0) * wo, kpad), x.dtype, "row")
             hip.tf_im2col_rows_nhwc_f16(col.ptr, xi.ptr, 1, h, wd, c, r, s, stride[0], padding[0], kpad, o0, o1, _sh())
             _conv(col.view((1, kpad, o1 - o0, wo), "nhwc"), wv, bias, [0, 0], [1, 1], [1, 1],
                   out=y.view((1, k, o1 - o0, wo), "nhwc", (img * ho + o0) * wo * k))
@@ -178,8 +178,6 @@ def _conv_small_c(x, w, bias, padding, stride, cache, gn=0):
 
 def conv_2d(X_gpu, W_gpu, padding, stride, dilation):
     """vision/conv2d.py:9-28: NCHW cross-correlation, no bias.  X (N,C,H,W) and W (K,C,R,S) logical shapes."""
-    if is_bfloat16(X_gpu.dtype):
-        return conv2d_bf16(X_gpu, W_gpu, None, padding, stride, dilation)
     if X_gpu.shape[1] % 8 != 0:
         return _conv_small_c(X_gpu, W_gpu, None, padding, stride, {})
     return _conv(X_gpu, W_gpu, None, padding, stride, dilation)
@@ -232,9 +230,9 @@ def pad_image(x, left, right, top, bottom):
     """Zero padding of an NHWC image tensor on the device: the asymmetric [0, 1, 0, 1] (left, right, top, bottom) of the VAE encoder's
     stride-2 convolutions (vae/encoder.py:19 hands that list to the conv as its ``padding``; a symmetric conv cannot express it)."""
     n, c, h, w = x.shape
-    assert x.layout == "nhwc" and x.dtype == np.float16
+    assert x.layout == "nhwc" and x.dtype.itemsize == 2
     hp, wp = h + top + bottom, w + left + right
-    y = DeviceArray.empty((n, c, hp, wp), np.float16, "nhwc")
+    y = DeviceArray.empty((n, c, hp, wp), x.dtype, "nhwc")
     hip.tf_memset_async(y.ptr, 0, y.nbytes, _sh())
     for i in range(n):
         hip.tf_memcpy_2d_async(y.ptr + ((i * hp + top) * wp + left) * c * 2, wp * c * 2, x.ptr + i * h * w * c * 2, w * c * 2, w * c * 2, h, _sh())
@@ -267,11 +265,11 @@ class Conv2d:
             k, c, r, s = self.weight.shape
             kc, ce = r * s * c, proj.weight.shape[1]
             assert proj.weight.shape[0] == k and tuple(proj.weight.shape[2:]) == (1, 1)
-            wp = DeviceArray.empty((k, kc + ce), np.float16, "row")
+            wp = DeviceArray.empty((k, kc + ce), self.weight.dtype, "row")
             hip.tf_memcpy_2d_async(wp.ptr, (kc + ce) * 2, self.weight.ptr, kc * 2, kc * 2, k, _sh())
             hip.tf_memcpy_2d_async(wp.ptr + kc * 2, (kc + ce) * 2, proj.weight.ptr, ce * 2, ce * 2, k, _sh())
-            bp = DeviceArray.empty((k,), np.float16, "row")
-            hip.tf_add_f16(bp.ptr, self.bias.ptr, proj.bias.ptr, k, _sh())
+            bp = DeviceArray.empty((k,), self.bias.dtype, "row")
+            hip.tf_add_16(dtag(self.bias.dtype), bp.ptr, self.bias.ptr, proj.bias.ptr, k, _sh())
             self._cache["fold_key"], self._cache["fold"] = key, (wp, bp)
         return self._cache["fold"]
 
@@ -280,16 +278,6 @@ class Conv2d:
         extra = (proj, x3): add ``proj(x3)`` (a Conv2d 1x1; x3 a tensor or a concat pair) inside this conv's GEMM.
         gn_in = (GroupNorm, silu): this conv reads GroupNorm(x) [-> SiLU] (x is the RAW tensor): one launch where possible."""
         x0 = x[0] if isinstance(x, (tuple, list)) else x
-        if is_bfloat16(x0.dtype):
-            # the bfloat16 step: the plain per-op structure -- GroupNorm (+ SiLU) as its own launch, one bf16-MFMA conv with bias / time embedding /
-            # residual / up-sampling / concat folded in; no statistics ride along, nothing is split along K
-            assert extra is None and len(self.padding) == 2
-            if gn_in is not None:
-                x = gn_in[0](x, silu=gn_in[1])
-            if (x[0].shape[1] + x[1].shape[1] if isinstance(x, (tuple, list)) else x.shape[1]) % 8 != 0:
-                assert bias_nc is None and residual is None and not upsample and not isinstance(x, (tuple, list))
-                return _conv_small_c_bf16(x, self.weight, self.bias, self.padding, self.stride, self._cache)
-            return conv2d_bf16(x, self.weight, self.bias, self.padding, self.stride, self.dilation, residual, bias_nc, upsample)
         if len(self.padding) == 4:                         # [left, right, top, bottom]: pad explicitly, then an unpadded conv
             assert extra is None and gn_in is None and not upsample and not isinstance(x, (tuple, list))
             x = pad_image(x, *self.padding)

@@ -45,7 +45,7 @@ class ResBlock:
         n2 = (self.out_layers[0], True)
         if br is not None:
             br.join()
-        elif config.fold_skip_projection and config.dtype not in ("fp8", "bf16") and isinstance(self.skip_connection, Conv2d) and self.out_layers[3].weight.shape[0] % 8 == 0 \
+        elif config.fold_skip_projection and config.dtype != "fp8" and isinstance(self.skip_connection, Conv2d) and self.out_layers[3].weight.shape[0] % 8 == 0 \
                 and self.skip_connection.weight.shape[1] % 8 == 0:
             # skip_connection(x) + h in ONE GEMM: the 1x1 projection rides as extra K columns of the last conv
             return self.out_layers[3](h, gn=out_gn, extra=(self.skip_connection, x), gn_in=n2, out_norm=out_norm)

@@ -168,17 +168,13 @@ class UNetModel:
         bt = self._prepare()
         t_emb = timestep_embedding(timesteps, self.cfg.model_channels)
         emb = self.time_embed[2](self.time_embed[0](t_emb), silu_input=True)          # Linear -> SiLU -> Linear
-        if is_bfloat16(emb.dtype):                                                    # the bfloat16 step: SiLU launch + one bf16-MFMA GEMM with M = 1
-            se = DeviceArray.empty(emb.shape, emb.dtype, emb.layout)
-            hip.tf_silu_bf16(se.ptr, emb.ptr, emb.size, _sh())
-            return emb, linear_bf16(se, bt["emb_w"], bt["emb_b"])
         return emb, gemv_f16(emb, bt["emb_w"], bt["emb_b"], silu_input=True)          # every ResBlock's Linear(SiLU(emb))
 
     def context_kv(self, context):
         """Every cross-attention's K|V projection of the (stacked) context as ONE GEMM (attention/attention.py:35-36 for all 16 blocks):
         depends on the context alone, so a sampler computes it when the context changes, not once per step."""
         bt = self._prepare()
-        return to_f16(linear_any(context, bt["kv_w"])) if bt["kv_w"] is not None else None     # (bfloat16 step: the attention core reads fp16 K|V)
+        return linear_any(context, bt["kv_w"]) if bt["kv_w"] is not None else None
 
     def weights_key(self):
         """Identity of everything time_embedding_all / context_kv depend on: a cached row is stale once any of these weights is replaced."""
@@ -200,7 +196,7 @@ class UNetModel:
             if config.parallel_branches and bt["kv_w"] is not None:
                 br = Branch()                          # the context projection is independent of the time-embedding chain
                 with br:
-                    kv_all = linear_f16(context, bt["kv_w"])
+                    kv_all = linear_f16(context, bt["kv_w"])      # (either element type since round 5)
             emb, emb_all = self.time_embedding_all(timesteps)                            # Linear -> SiLU -> Linear, then every ResBlock's Linear(SiLU(emb))
             if br is None:
                 kv_all = self.context_kv(context)                                         # every attn2's K|V of the context
