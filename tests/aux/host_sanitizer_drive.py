@@ -67,12 +67,12 @@ ok(lib.tf_gemm_tune_count(ctypes.byref(n)) == 0 and n.value >= len(rows), "rows 
 for i in range(n.value):
     k, c = c_int10(), c_int5()
     lib.tf_gemm_tune_entry(i, k, c)
-    ok(c[0] in (64, 128, 192, 256) and c[1] in (64, 128, 160, 256) and 1 <= c[2] <= 32 and 0 <= c[3] <= 6 and c[4] in (0, 1), f"row {list(k)} -> {list(c)}")
+    ok(c[0] in (64, 128, 192, 256) and c[1] in (64, 128, 160, 256) and 1 <= c[2] <= 32 and 0 <= c[3] <= 7 and c[4] in (0, 1), f"row {list(k)} -> {list(c)}")
 # ---- switches
 ok(lib.tf_gemm_autotune(3) == 10001 and lib.tf_gemm_autotune(-1) == 10001 and lib.tf_gemm_autotune(2) == 0 and lib.tf_gemm_autotune(1) == 0, "autotune modes")
 ok(lib.tf_gemm_splitk_partials(8) == 10001 and lib.tf_gemm_splitk_partials(32) == 0 and lib.tf_gemm_splitk_partials(16) == 0, "slab types")
 ok(lib.tf_gemm_debug(1) == 10001 and lib.tf_gemm_debug(4096) == 10001, "ablation bits refused")
-for f in (8, 16, 32, 64, 128, 256, 512, 1024, 2048, 8192, 0):
+for f in (8, 16, 32, 64, 128, 256, 512, 1024, 2048, 8192, 16384, 0):
     ok(lib.tf_gemm_debug(f) == 0, f"debug {f}")
 ok(lib.tf_gemm_force_config(256, 160, 4) == 0 and lib.tf_gemm_force_config(0, 0, 0) == 0, "force config")
 # ---- shape predicates and sizes: pure host arithmetic over many shapes (incl. degenerate ones)

@@ -123,7 +123,7 @@ def _dev16(x, bf, layout=None):
 
 
 @pytest.mark.parametrize("cfg", [(64, 64, 1, 0), (64, 160, 1, 256), (128, 128, 1, 16), (128, 160, 4, 0), (64, 128, 8, 256), (256, 128, 1, 0), (128, 128, 1, 1024),
-                                 (256, 160, 1, 512), (192, 128, 2, 512), (256, 256, 1, 512)])
+                                 (256, 160, 1, 512), (192, 128, 2, 512), (256, 256, 1, 512), (256, 128, 1, 16384)])
 def test_bf16_linear_is_exact_on_small_integers_on_every_kernel(cfg):
     """Small-integer operands: every product and partial sum is exact in bf16 x bf16 -> fp32, so each kernel family's bf16 instance (deep / wide /
     ALL8 rings, split-K with fp32 slabs + the bf16 reducers, the 256-row tile, k_gemm_c4, k_igemm_pp incl. 256 x 256) must reproduce the integer
@@ -142,6 +142,8 @@ def test_bf16_linear_is_exact_on_small_integers_on_every_kernel(cfg):
         y = linear_f16(_dev16(x, True, "row"), _dev16(w, True, "row"), _dev16(b, True, "row"), _dev16(r, True, "row")).numpy()
     finally:
         lib.tf_gemm_force_config(0, 0, 0); lib.tf_gemm_debug(0)
+    if flag & (1024 | 16384):          # the persistent kernels round the tile to 16 bits in front of their row-side residual add (two roundings, as in float16)
+        want = OB.round_bf16(x @ w.T + b) + r
     np.testing.assert_array_equal(y, OB.round_bf16(want))
 
 

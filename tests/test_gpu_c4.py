@@ -19,23 +19,32 @@ def tf():
     return T
 
 
+KERNELS = {"c4": (128, 128, 1024), "c8": (256, 128, 16384)}      # k_gemm_c4 (two 4-wave blocks per CU, 128 x 128 tiles) / k_gemm_c8 (round 5: one 8-wave block, 256 x 128 tiles, three-slot ring across tiles)
+
+
+@pytest.fixture(params=["c4", "c8"])
+def kern(request):
+    return request.param
+
+
 class forced:
-    def __init__(self, flags=1024):
-        self.flags = flags
+    def __init__(self, kern="c4", extra=0):
+        self.bm, self.bn, flag = KERNELS[kern]
+        self.flags = flag | extra
 
     def __enter__(self):
         from tinyfusers_amd.native import lib
-        lib.tf_gemm_force_config(128, 128, 1); lib.tf_gemm_debug(self.flags)
+        lib.tf_gemm_force_config(self.bm, self.bn, 1); lib.tf_gemm_debug(self.flags)
 
     def __exit__(self, *a):
         from tinyfusers_amd.native import lib
         lib.tf_gemm_force_config(0, 0, 0); lib.tf_gemm_debug(0)
 
 
-@pytest.mark.parametrize("flags", [1024, 1024 | 64])       # 64: m-fastest tile order
+@pytest.mark.parametrize("flags", [0, 64])       # 64: m-fastest tile order
 @pytest.mark.parametrize("m,n,k", [(1000, 400, 64), (1000, 400, 128), (1000, 400, 256), (257, 160, 192), (5000, 320, 320), (8192, 2560, 320), (70000, 128, 128), (129, 8, 1280),
-                                   (66000, 136, 192), (140000, 64, 128)])
-def test_c4_linear_exact_integers(tf, flags, m, n, k):
+                                   (66000, 136, 192), (140000, 64, 128), (73728, 320, 448), (4608, 1280, 6400)])
+def test_c4_linear_exact_integers(tf, kern, flags, m, n, k):
     """1 ... 20 K tiles, 1 ... 1280 output tiles (fewer and more than the 512 resident blocks, up to five tiles per block: the cross-tile
     prefetch, the counted wait that leaves the previous tile's stores in flight), ragged M / N edges, bias + residual, then neither."""
     from tinyfusers_amd.native import hip
@@ -44,38 +53,38 @@ def test_c4_linear_exact_integers(tf, flags, m, n, k):
     b = rs.randint(-4, 5, (n,)).astype(np.float32); r = rs.randint(-8, 9, (m, n)).astype(np.float32)
     y = tf.DeviceArray.empty((m, n))
     xd, wd, bd, rd = dev(tf, x), dev(tf, w), dev(tf, b), dev(tf, r)
-    with forced(flags):
+    with forced(kern, flags):
         hip.tf_linear_f16(y.ptr, xd.ptr, wd.ptr, bd.ptr, rd.ptr, m, n, k, 0, None, 0, None)
     np.testing.assert_array_equal(y.numpy(), (x @ w.T + b + r).astype(np.float16).astype(np.float32))
     y2 = tf.DeviceArray.empty((m, n))
-    with forced(flags):
+    with forced(kern, flags):
         hip.tf_linear_f16(y2.ptr, xd.ptr, wd.ptr, None, None, m, n, k, 0, None, 0, None)
     np.testing.assert_array_equal(y2.numpy(), (x @ w.T).astype(np.float16).astype(np.float32))
 
 
-def test_c4_refuses_what_it_cannot_run(tf):
+def test_c4_refuses_what_it_cannot_run(tf, kern):
     from tinyfusers_amd.native import hip
     for m, n, k in ((512, 256, 200), (512, 250, 128)):     # K off the 64 grid; N off the 8 grid
         y = tf.DeviceArray.empty((m, n))
         x, w = dev(tf, rnd("c4r.x", (m, k))), dev(tf, rnd("c4r.w", (n, k)))
-        with forced():
+        with forced(kern):
             with pytest.raises(RuntimeError):
                 hip.tf_linear_f16(y.ptr, x.ptr, w.ptr, None, None, m, n, k, 0, None, 0, None)
 
 
 @pytest.mark.parametrize("m,c", [(1000, 128), (4608, 320), (9216, 320)])
-def test_c4_geglu(tf, m, c):
+def test_c4_geglu(tf, kern, m, c):
     from oracle import ops as O
     from tinyfusers_amd.ff.nn import GEGLU
     x = rnd("c4g.x", (m, c)); w = rnd("c4g.w", (8 * c, c), c ** -0.5); b = rnd("c4g.b", (8 * c,), 0.1)
     g = GEGLU(c, 4 * c, init=False); g.proj.weight = dev(tf, w); g.proj.bias = dev(tf, b)
-    with forced():
+    with forced(kern):
         got = g(dev(tf, x)).numpy()
     close(got, O.geglu(x, w, b).numpy())
 
 
 @pytest.mark.parametrize("m,n,k,act", [(4608, 960, 320, 0), (2000, 640, 640, 0), (1100, 1280, 1280, 0), (4608, 1280, 320, 1), (1000, 2560, 640, 1), (300, 128, 128, 0)])
-def test_c4_linear_with_folded_layer_norm(tf, m, n, k, act):
+def test_c4_linear_with_folded_layer_norm(tf, kern, m, n, k, act):
     """Linear(LayerNorm(x)) as one GEMM on the raw x (tf_linear_ln_f16): the row statistics come from the fragments the waves multiply,
     the fold rstd (acc - mean colsum) + bias' happens on the accumulators."""
     from oracle import ops as O
@@ -86,7 +95,7 @@ def test_c4_linear_with_folded_layer_norm(tf, m, n, k, act):
     g, b = 1 + rnd("cln.g", (k,), 0.1), rnd("cln.b", (k,), 0.1)
     ln = LayerNorm(k); ln.weight = dev(tf, g); ln.bias = dev(tf, b)
     xn = O.layer_norm(x, g, b)
-    with forced():
+    with forced(kern):
         if act == 0:
             w, bias = rnd("cln.w", (n, k), k ** -0.5), rnd("cln.bias", (n,), 0.1)
             r = rnd("cln.r", (m, n))
@@ -101,7 +110,7 @@ def test_c4_linear_with_folded_layer_norm(tf, m, n, k, act):
 
 
 @pytest.mark.parametrize("n,c1,c2,hw,cout", [(2, 128, 64, 32, 320), (2, 320, 0, 32, 320), (3, 128, 0, 24, 128), (2, 64, 64, 32, 192)])
-def test_c4_conv1x1(tf, n, c1, c2, hw, cout):
+def test_c4_conv1x1(tf, kern, n, c1, c2, hw, cout):
     """A 1x1 / stride 1 convolution is the same GEMM; the concat input is a second K segment with its own row pitch."""
     from oracle import ops as O
     from tinyfusers_amd.vision.conv2d import Conv2d
@@ -112,12 +121,12 @@ def test_c4_conv1x1(tf, n, c1, c2, hw, cout):
     x = (dev(tf, xa), dev(tf, xb)) if c2 else dev(tf, xa)
     xin = torch.from_numpy(np.concatenate((xa, xb), 1) if c2 else xa)
     want = O.conv2d_bias(xin, wt, b, (0, 0)) + torch.from_numpy(r)
-    with forced():
+    with forced(kern):
         got = m(x, residual=dev(tf, r)).numpy()
     close(got, want.numpy())
 
 
-def test_c4_agrees_with_the_deep_ring_kernel_at_config5_size(tf):
+def test_c4_agrees_with_the_deep_ring_kernel_at_config5_size(tf, kern):
     """The GEGLU projection of config 5's first level (73728 x 2560 x 320: 11520 tiles, 22-23 per resident block) is too large for the CPU
     oracle inside a test: the persistent kernel against the round-1 two-blocks-per-CU kernel on the same inputs (same products, another
     summation order inside a K tile only), plus the linearity property f(2 x) = 2 f(x) of the plain linear (exact in floating point)."""
@@ -127,7 +136,7 @@ def test_c4_agrees_with_the_deep_ring_kernel_at_config5_size(tf):
     xd, x2d, wd, bd = dev(tf, x), dev(tf, 2.0 * x), dev(tf, w), dev(tf, b)
     y_c4, y_c42, y_ref = tf.DeviceArray.empty((m, n // 2)), tf.DeviceArray.empty((m, n)), tf.DeviceArray.empty((m, n // 2))
     y_lin = tf.DeviceArray.empty((m, n))
-    with forced():
+    with forced(kern):
         hip.tf_linear_f16(y_c4.ptr, xd.ptr, wd.ptr, bd.ptr, None, m, n // 2, k, 1, None, 0, None)          # GEGLU
         hip.tf_linear_f16(y_lin.ptr, xd.ptr, wd.ptr, None, None, m, n, k, 0, None, 0, None)
         hip.tf_linear_f16(y_c42.ptr, x2d.ptr, wd.ptr, None, None, m, n, k, 0, None, 0, None)

@@ -541,6 +541,10 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
     if (!c4_ok(p) || c.bm != 128 || c.bn != 128 || p.splitk != 1) { tf_set_error("run_gemm: the persistent short-K kernel cannot run this launch (tile %dx%d, split %d)", c.bm, c.bn, p.splitk); return TF_E_UNSUPPORTED; }
     rc = bf ? tfk_launch_c4_bf16(p, st) : tfk_launch_c4(p, st);
   }
+  else if (variant == 7) {
+    if (!c4_ok(p) || c.bm != 256 || c.bn != 128 || p.splitk != 1) { tf_set_error("run_gemm: the 256-row persistent short-K kernel cannot run this launch (tile %dx%d, split %d)", c.bm, c.bn, p.splitk); return TF_E_UNSUPPORTED; }
+    rc = bf ? tfk_launch_c8_bf16(p, st) : tfk_launch_c8(p, st);
+  }
   else if (variant == 6) {
     if (p.splitk != 1 || !pp3_setup(p, c.bm, c.bn)) { tf_set_error("run_gemm: the patch form of the ping-pong kernel cannot run this launch (tile %dx%d, split %d)", c.bm, c.bn, p.splitk); return TF_E_UNSUPPORTED; }
     rc = bf ? tfk_launch_pp3_bf16(p, st, c.bn) : tfk_launch_pp3(p, st, c.bn);
@@ -783,6 +787,26 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
       if (tv[2] < best) { best = tv[2]; bc = {c, 5, order}; }
     }
   }
+  // the 256-row persistent short-K kernel (variant 7): one 8-wave block per CU walks 256 x 128 tiles -- a candidate once those tiles give most CUs one
+  if (c4_ok(p) && (long long)((p.M + 255) / 256) * ((p.N + 127) / 128) >= 192) {
+    TileCfg c = {256, 128, 1};
+    for (int order = 0; order < 2; ++order) {
+      int rc = launch_one(p, c, 7, order, workspace, st);   // warm-up
+      if (rc) return rc;
+      float tv[5];
+      for (int r = 0; r < 5; ++r) {
+        TF_HIP(hipMemsetAsync(g_flush, r, TF_FLUSH_BYTES, st));
+        TF_HIP(hipEventRecord(a, st));
+        rc = launch_one(p, c, 7, order, workspace, st);
+        if (rc) return rc;
+        TF_HIP(hipEventRecord(b, st));
+        TF_HIP(hipEventSynchronize(b));
+        TF_HIP(hipEventElapsedTime(&tv[r], a, b));
+      }
+      for (int i = 0; i < 5; ++i) for (int j = i + 1; j < 5; ++j) if (tv[j] < tv[i]) { float t = tv[i]; tv[i] = tv[j]; tv[j] = t; }
+      if (tv[2] < best) { best = tv[2]; bc = {c, 7, order}; }
+    }
+  }
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
   *out = bc;
   return TF_OK;
@@ -893,6 +917,13 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     else if (g_force_wide == 6) { tf_set_error("run_gemm: the patch form of the ping-pong kernel cannot run this launch"); return TF_E_UNSUPPORTED; }
     else { wide = 0; if (t.c.bm >= 192) t.c = choose_tiles(p.M, p.N, p.K, p.act, workspace != nullptr); }
   }
+  if (wide == 7) {
+    GemmP q = p;
+    if (!gn_chunks) q.gn_part = nullptr;
+    if (c4_ok(q) && (!force_bm || (t.c.bm == 256 && t.c.bn == 128 && t.c.splitk == 1))) t.c = {256, 128, 1};
+    else if (g_force_wide == 7) { tf_set_error("run_gemm: the 256-row persistent short-K kernel cannot run this launch"); return TF_E_UNSUPPORTED; }
+    else { wide = 0; t.c = choose_tiles(p.M, p.N, p.K, p.act, workspace != nullptr); }
+  }
   if (wide == 5) {
     GemmP q = p;
     if (!gn_chunks) q.gn_part = nullptr;                  // (statistics the caller did not ask to hear about are never requested)
@@ -957,7 +988,7 @@ int tf_gemm_debug(int flags) {
   TF_REQUIRE(!(flags & (7 | 4096)), "tf_gemm_debug: the ablation bits (1, 2, 4, 4096) exist only in the library built with -DTF_ABLATION (python -m tinyfusers_amd.build --ablation)");
 #endif
   g_pp_np = (flags & 8192) ? 2 : 0;                       // 8192: k_igemm_pp with one phase per k-step even where the 3-slot ring allows one per K tile
-  g_force_wide = (flags & 2048) ? 6 : (flags & 1024) ? 5 : (flags & 512) ? 4 : (flags & 256) ? 3 : (flags & 128) ? 2 : (flags & 16) ? 1 : (flags & 8) ? 0 : -1;   // 128 / 256 / 512 / 1024 / 2048: the PATCH / ALL8 / ping-pong / persistent short-K / ping-pong PATCH variants where eligible
+  g_force_wide = (flags & 16384) ? 7 : (flags & 2048) ? 6 : (flags & 1024) ? 5 : (flags & 512) ? 4 : (flags & 256) ? 3 : (flags & 128) ? 2 : (flags & 16) ? 1 : (flags & 8) ? 0 : -1;   // 128 / 256 / 512 / 1024 / 2048: the PATCH / ALL8 / ping-pong / persistent short-K / ping-pong PATCH variants where eligible
   g_force_order = (flags & 64) ? 1 : (flags & 32) ? 0 : -1;
   return TF_OK;
 }
@@ -1026,7 +1057,7 @@ int tf_gemm_tune_load(const char* path) {
     const bool f8 = (k[9] & 64) != 0;
     bool ok = (bm == 64 || bm == 128 || (f8 && bm == 256 && bn == 64) || (!f8 && bm == 256 && bn == 128) || wide == 4) && (bn == 64 || bn == 128 || (!f8 && bn == 160) || wide == 4) &&
               sk >= 1 && sk <= 32;
-    if (((f8 && wide != 4) || (bm == 256 && wide != 4)) && wide != 0) ok = false;
+    if (((f8 && wide != 4) || (bm == 256 && wide != 4 && wide != 7)) && wide != 0) ok = false;
     if (wide == 4) ok = ((bm == 256 && (bn == 128 || bn == 160 || (!f8 && bn == 256))) || (bm == 192 && (bn == 128 || bn == 160))) && sk >= 1 && sk <= 32;
     // rows the tuner itself never emits: GEGLU (act = 1) pairs 16-row value|gate blocks inside a wave tile (bn % 64 == 0), and
     // neither GEGLU nor the LayerNorm fold (flag bit 8) can be split along K
@@ -1034,8 +1065,9 @@ int tf_gemm_tune_load(const char* path) {
     if (act == 1 && (bn % 64) != 0) ok = false;
     if ((act == 1 || ln || (k[9] & 256)) && sk > 1) ok = false;
     if (wide == 5) ok = bm == 128 && bn == 128 && sk == 1 && !f8;
+    if (wide == 7) ok = bm == 256 && bn == 128 && sk == 1 && !f8;
     if (wide == 6) ok = bm == 192 && (bn == 128 || bn == 160) && sk == 1 && k[5] == 3 && k[6] == 1 && act == 0 && !ln && (!f8 || (k[9] & 512));   // the patch form: 3x3 / stride 1; e4m3 only block-scaled
-    if (ok) g_tuned[k] = {{bm, bn, sk}, wide < 0 || wide > 6 ? 0 : wide, order != 0 ? 1 : 0};
+    if (ok) g_tuned[k] = {{bm, bn, sk}, wide < 0 || wide > 7 ? 0 : wide, order != 0 ? 1 : 0};
   }
   fclose(f);
   return TF_OK;
@@ -1129,7 +1161,7 @@ int tf_prof_dump(const char* path) {
   if (rc) return rc;
   FILE* f = fopen(path, "w");
   TF_REQUIRE(f, "tf_prof_dump: cannot open %s", path);
-  fprintf(f, "M,N,K,taps,bm,bn,splitk,variant,launches,total_ms,avg_us,tflops\n");   // variant: 0 deep ring, 1 wide, 2 patch, 3 all8, 4 ping-pong, 5 persistent short-K, 6 ping-pong patch; times include the split-K reduce
+  fprintf(f, "M,N,K,taps,bm,bn,splitk,variant,launches,total_ms,avg_us,tflops\n");   // variant: 0 deep ring, 1 wide, 2 patch, 3 all8, 4 ping-pong, 5 persistent short-K, 6 ping-pong patch, 7 persistent short-K 256-row; times include the split-K reduce
   for (auto& kv : g_prof_shapes) {
     const auto& k = kv.first;
     double ms = kv.second.second; long long n = kv.second.first;

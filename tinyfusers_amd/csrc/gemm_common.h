@@ -695,6 +695,9 @@ int tfk_launch_pp8(const GemmP& p, hipStream_t st, int bm, int bn);
 //   k_gemm_c4 (gemm_k_c4.hip)
 int tfk_launch_c4(const GemmP& p, hipStream_t st);
 int tfk_launch_pp3(const GemmP& p, hipStream_t st, int bn);
+//   k_gemm_c8 (gemm_k_c8.hip)
+int tfk_launch_c8(const GemmP& p, hipStream_t st);
+int tfk_launch_c8_bf16(const GemmP& p, hipStream_t st);
 //   the bfloat16 instances of the same kernels (gemm_k_*_bf16.hip)
 int tfk_launch_igemm_160_bf16(const GemmP& p, hipStream_t st, int bm, bool wide, bool all8);
 int tfk_launch_igemm_128_bf16(const GemmP& p, hipStream_t st, int bm, bool wide, bool all8);

@@ -77,7 +77,10 @@ template <int OUT8, typename T = half_t>     // OUT8: 0 = 16-bit output, 1 = e4m
 __global__ void k_gn_apply(T* __restrict__ y, const T* __restrict__ x, const T* __restrict__ x2, const T* __restrict__ gamma,
                            const T* __restrict__ beta, const float* __restrict__ partial, int HW, int C1, int C2, int G, float eps,
                            int do_silu, int chunks, int pix_per_block, int CV, int RPB, const float* __restrict__ partial2, int chunks2,
-                           int G1, int G2, int mr) {
+                           int G1, int G2, int mr, int nbatch) {
+  // nbatch (round 5): a block streams nbatch batches of GN_APPLY_PPT * RPB pixels, the loads of batch b + 1 in flight while batch b is normalised and
+  // stored -- the statistics fold below (every block re-reads the image's chunks x G partials from L2: 49 KB at config 5's first level) is then paid
+  // once per nbatch * 15 KB of tensor instead of once per 15 KB; the host keeps >= 3 blocks per CU (gn_batches)
   typedef typename vec8<T>::type V8;
   extern __shared__ float st[];  // [G][2] : mean, rstd
   int n = blockIdx.y;
@@ -95,7 +98,7 @@ __global__ void k_gn_apply(T* __restrict__ y, const T* __restrict__ x, const T* 
     else { base = x2 + (long long)n * HW * C2 + (c - C1); ld = C2; }
   }
   const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
-  V8 gm, bt, v[GN_APPLY_PPT];                            // pix_per_block == GN_APPLY_PPT * RPB (gn_geometry)
+  V8 gm, bt, v[GN_APPLY_PPT];                            // pix_per_block == nbatch * GN_APPLY_PPT * RPB (gn_geometry, gn_batches)
   if (active) {
     if (gamma) { gm = *reinterpret_cast<const V8*>(gamma + c); bt = *reinterpret_cast<const V8*>(beta + c); }
 #pragma unroll
@@ -165,9 +168,21 @@ __global__ void k_gn_apply(T* __restrict__ y, const T* __restrict__ x, const T* 
     }
   }
   T* yo = y + (long long)n * HW * C + c;
+  const int bstride = GN_APPLY_PPT * RPB;
+  for (int bi = 0; bi < nbatch; ++bi) {
+  const int pb = p0 + bi * bstride;
+  if (pb >= p1) break;                                    // (block-uniform)
+  V8 vn[GN_APPLY_PPT];
+  if (bi + 1 < nbatch && active) {                        // the next batch's loads fly while this one is normalised and stored
+#pragma unroll
+    for (int i = 0; i < GN_APPLY_PPT; ++i) {
+      int p = pb + bstride + rr + i * RPB;
+      if (p < p1) vn[i] = *reinterpret_cast<const V8*>(base + (long long)p * ld);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < GN_APPLY_PPT; ++i) {
-    int p = p0 + rr + i * RPB;
+    int p = pb + rr + i * RPB;
     const bool live = active && p < p1;
     if (OUT8 == 2 || live) {
       V8 o;
@@ -194,6 +209,11 @@ __global__ void k_gn_apply(T* __restrict__ y, const T* __restrict__ x, const T* 
       else if constexpr (OUT8 == 1) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(y) + (long long)n * HW * C + c + (long long)p * C) = pack8_fp8(q0, q1);   // e4m3 operand of an fp8 conv
       else *reinterpret_cast<V8*>(yo + (long long)p * C) = o;
     }
+  }
+  if (bi + 1 < nbatch) {
+#pragma unroll
+    for (int i = 0; i < GN_APPLY_PPT; ++i) v[i] = vn[i];
+  }
   }
 }
 
@@ -359,6 +379,13 @@ static void gn_geometry(int HW, int C, int N, int* CV, int* RPB, int* threads, i
   *appb = q; *ablocks = (HW + q - 1) / q;
 }
 
+// batches per block of k_gn_apply: as many as keep >= 3 blocks per CU (768) in the launch, at most 8 (small tensors: 1 = the round-1 geometry)
+static int gn_batches(int ablocks, int N) {
+  int nb = 1;
+  while (nb < 8 && (long long)((ablocks + 2 * nb - 1) / (2 * nb)) * N >= 768) nb *= 2;
+  return nb;
+}
+
 template <typename T>
 static int layer_norm_impl(void* y, const void* x, const void* gamma, const void* beta, int rows, int C, float eps, int out8, tfStream_t s) {
   TF_REQUIRE(y && x && rows >= 0, "tf_layer_norm_f16: null tensor");
@@ -408,12 +435,13 @@ static int group_norm_impl(void* y, const void* x, const void* x2, const void* g
   gn_geometry(HW, C, N, &CV, &RPB, &threads, &chunks, &ppc, &ablocks, &appb);
   float* partial = (float*)workspace;
   int tl = (threads + 7) & ~7;                         // the folds work in groups of 8 lanes
+  const int gnb = gn_batches(ablocks, N);
   TfProfScope prof_(TF_PROF_FAM_GROUP_NORM, (double)N * HW * C * 6.0, tf_hs(s));     // statistics pass (1 read) + apply (1 read + 1 write), 16-bit
   hipLaunchKernelGGL(k_gn_stats<T>, dim3(chunks, N), dim3(tl), (size_t)threads * 16 * sizeof(float), tf_hs(s), partial, (const T*)x,
                      (const T*)x2, HW, C1, C2, G, chunks, ppc, CV, RPB);
   TF_LAUNCH_CHECK();
-  hipLaunchKernelGGL((k_gn_apply<0, T>), dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (T*)y, (const T*)x, (const T*)x2,
-                     (const T*)gamma, (const T*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
+  hipLaunchKernelGGL((k_gn_apply<0, T>), dim3((ablocks + gnb - 1) / gnb, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (T*)y, (const T*)x, (const T*)x2,
+                     (const T*)gamma, (const T*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb * gnb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1, gnb);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
@@ -451,11 +479,12 @@ int tf_group_norm_apply_16(int dtype, void* y, const void* x, const void* gamma,
   int CV, RPB, threads, sc, ppc, ablocks, appb;
   gn_geometry(HW, C, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
   int tl = (threads + 7) & ~7;
+  const int gnb = gn_batches(ablocks, N);
   TfProfScope prof_(TF_PROF_FAM_GROUP_NORM, (double)N * HW * C * 4.0, tf_hs(s));
-  if (dtype == TF_DTYPE_BF16) hipLaunchKernelGGL((k_gn_apply<0, bf16_t>), dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (bf16_t*)y, (const bf16_t*)x, (const bf16_t*)nullptr,
-                     (const bf16_t*)gamma, (const bf16_t*)beta, (const float*)partial, HW, C, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
-  else hipLaunchKernelGGL(k_gn_apply<0>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)nullptr,
-                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
+  if (dtype == TF_DTYPE_BF16) hipLaunchKernelGGL((k_gn_apply<0, bf16_t>), dim3((ablocks + gnb - 1) / gnb, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (bf16_t*)y, (const bf16_t*)x, (const bf16_t*)nullptr,
+                     (const bf16_t*)gamma, (const bf16_t*)beta, (const float*)partial, HW, C, 0, G, eps, silu, chunks, appb * gnb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1, gnb);
+  else hipLaunchKernelGGL(k_gn_apply<0>, dim3((ablocks + gnb - 1) / gnb, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)nullptr,
+                     (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C, 0, G, eps, silu, chunks, appb * gnb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1, gnb);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }
@@ -489,11 +518,12 @@ static int gn_apply_8(void* y8, const void* x, const void* x2, const void* gamma
     int CV, RPB, threads, sc, ppc, ablocks, appb;
     gn_geometry(HW, C1, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
     int tl = (threads + 7) & ~7;
+    const int gnb = gn_batches(ablocks, N);
     TfProfScope prof_(TF_PROF_FAM_GROUP_NORM, (double)N * HW * C1 * 3.0, tf_hs(s));         // fp16 in, e4m3 out
-    if (mode == 2) hipLaunchKernelGGL(k_gn_apply<2>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y8, (const half_t*)x, (const half_t*)nullptr,
-                       (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
-    else hipLaunchKernelGGL(k_gn_apply<1>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y8, (const half_t*)x, (const half_t*)nullptr,
-                       (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, 0, G, eps, silu, chunks, appb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1);
+    if (mode == 2) hipLaunchKernelGGL(k_gn_apply<2>, dim3((ablocks + gnb - 1) / gnb, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y8, (const half_t*)x, (const half_t*)nullptr,
+                       (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, 0, G, eps, silu, chunks, appb * gnb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1, gnb);
+    else hipLaunchKernelGGL(k_gn_apply<1>, dim3((ablocks + gnb - 1) / gnb, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y8, (const half_t*)x, (const half_t*)nullptr,
+                       (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, 0, G, eps, silu, chunks, appb * gnb, CV, RPB, (const float*)nullptr, 0, 0, 0, 1, gnb);
     TF_LAUNCH_CHECK();
     return TF_OK;
   }
@@ -526,19 +556,20 @@ static int gn_apply_cat(void* y, const void* x, const void* x2, const void* gamm
   int CV, RPB, threads, sc, ppc, ablocks, appb;
   gn_geometry(HW, C, N, &CV, &RPB, &threads, &sc, &ppc, &ablocks, &appb);
   int tl = (threads + 7) & ~7;
+  const int gnb = gn_batches(ablocks, N);
   TfProfScope prof_(TF_PROF_FAM_GROUP_NORM, (double)N * HW * C * ((out8 == 1 || out8 == 2) ? 3.0 : 4.0), tf_hs(s));
-  if (out8 == 16) hipLaunchKernelGGL((k_gn_apply<0, bf16_t>), dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (bf16_t*)y, (const bf16_t*)x, (const bf16_t*)x2,
-                               (const bf16_t*)gamma, (const bf16_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB,
-                               (const float*)partial2, chunks2, groups1, groups2, cpg / sub);
-  else if (out8 == 2) hipLaunchKernelGGL(k_gn_apply<2>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
-                               (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB,
-                               (const float*)partial2, chunks2, groups1, groups2, cpg / sub);
-  else if (out8) hipLaunchKernelGGL(k_gn_apply<1>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
-                               (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB,
-                               (const float*)partial2, chunks2, groups1, groups2, cpg / sub);
-  else hipLaunchKernelGGL(k_gn_apply<0>, dim3(ablocks, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
-                          (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb, CV, RPB,
-                          (const float*)partial2, chunks2, groups1, groups2, cpg / sub);
+  if (out8 == 16) hipLaunchKernelGGL((k_gn_apply<0, bf16_t>), dim3((ablocks + gnb - 1) / gnb, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (bf16_t*)y, (const bf16_t*)x, (const bf16_t*)x2,
+                               (const bf16_t*)gamma, (const bf16_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb * gnb, CV, RPB,
+                               (const float*)partial2, chunks2, groups1, groups2, cpg / sub, gnb);
+  else if (out8 == 2) hipLaunchKernelGGL(k_gn_apply<2>, dim3((ablocks + gnb - 1) / gnb, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
+                               (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb * gnb, CV, RPB,
+                               (const float*)partial2, chunks2, groups1, groups2, cpg / sub, gnb);
+  else if (out8) hipLaunchKernelGGL(k_gn_apply<1>, dim3((ablocks + gnb - 1) / gnb, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
+                               (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb * gnb, CV, RPB,
+                               (const float*)partial2, chunks2, groups1, groups2, cpg / sub, gnb);
+  else hipLaunchKernelGGL(k_gn_apply<0>, dim3((ablocks + gnb - 1) / gnb, N), dim3(tl), 2 * G * sizeof(float), tf_hs(s), (half_t*)y, (const half_t*)x, (const half_t*)x2,
+                          (const half_t*)gamma, (const half_t*)beta, (const float*)partial, HW, C1, C2, G, eps, silu, chunks, appb * gnb, CV, RPB,
+                          (const float*)partial2, chunks2, groups1, groups2, cpg / sub, gnb);
   TF_LAUNCH_CHECK();
   return TF_OK;
 }

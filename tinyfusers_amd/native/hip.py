@@ -74,6 +74,15 @@ class _Hip:
     (the reference checks the status at every call site; here it is done once)."""
 
     def __getattr__(self, name):
+        if name.endswith("_16") and not hasattr(lib, name) and os.environ.get("TF_LIB_PATH") and os.environ.get("TF_LIB_ALLOW_MISSING") == "1":
+            # same-box A/B against an earlier round's library (tools/ab_lib.sh): it has no dtype-tagged entries -- their float16 namesakes take the call
+            f16 = getattr(self, {"tf_conv2d_fused_16": "tf_conv2d_fused_f16", "tf_conv2d_fused_norm_16": "tf_conv2d_fused_norm_f16", "tf_conv2d_gn_16": "tf_conv2d_gn_f16"}.get(name, name[:-3] + "_f16"))
+
+            def call16(dtype, *args):
+                assert dtype == 0, f"{name}: the library at TF_LIB_PATH has float16 entries only"
+                return f16(*args)
+            setattr(self, name, call16)
+            return call16
         fn = getattr(lib, name)
         if fn.restype is not ctypes.c_int:
             return fn

@@ -32,16 +32,17 @@ def bench_linear(m, n, k, act, label, cfgs):
             res.append((float("inf"), bm, bn, sk, flags))
         finally:
             lib.tf_gemm_force_config(0, 0, 0); lib.tf_gemm_debug(0)
-    name = {8: "deep", 16: "wide", 512: "PP", 1024: "C4", 1024 | 64: "C4m"}
-    base = min(r for r in res if not (r[4] & 1024))
+    name = {8: "deep", 16: "wide", 512: "PP", 1024: "C4", 1024 | 64: "C4m", 16384: "C8", 16384 | 64: "C8m"}
+    base = min(r for r in res if not (r[4] & (1024 | 16384)))
     c4 = min(r for r in res if r[4] & 1024)
+    c8 = min(r for r in res if r[4] & 16384)
     byt = 2.0 * (m * k + n * k + m * no)
     print(f"{label:26s} M={m:6d} N={n:5d} K={k:5d} | best other {base[0]:7.1f} us {flops/base[0]/1e6:5.0f} TF {base[1]}x{base[2]} {name[base[4]]:5s} | C4 {c4[0]:7.1f} us {flops/c4[0]/1e6:5.0f} TF "
-          f"{byt/c4[0]/1e3:5.0f} GB/s | " + " ".join(f"{name[f]}{bm}x{bn}:{us:.1f}" for us, bm, bn, sk, f in sorted(res)), flush=True)
+          f"{byt/c4[0]/1e3:5.0f} GB/s | C8 {c8[0]:7.1f} us {flops/c8[0]/1e6:5.0f} TF | " + " ".join(f"{name[f]}{bm}x{bn}:{us:.1f}" for us, bm, bn, sk, f in sorted(res)), flush=True)
 
 
 if __name__ == "__main__":
-    C = [(128, 128, 1, 16), (128, 128, 1, 8), (64, 128, 1, 16), (128, 64, 1, 16), (256, 128, 1, 512), (256, 160, 1, 512), (192, 128, 1, 512), (128, 128, 1, 1024), (128, 128, 1, 1024 | 64)]
+    C = [(128, 128, 1, 16), (128, 128, 1, 8), (64, 128, 1, 16), (128, 64, 1, 16), (256, 128, 1, 512), (256, 160, 1, 512), (192, 128, 1, 512), (128, 128, 1, 1024), (128, 128, 1, 1024 | 64), (256, 128, 1, 16384), (256, 128, 1, 16384 | 64)]
     for tag, s in (("c2", 1), ("c5", 9)):
         m0 = 8192 * s
         bench_linear(m0, 2560, 320, 1, f"{tag} geglu 320", C)
@@ -54,3 +55,8 @@ if __name__ == "__main__":
         bench_linear(m0 // 16, 10240, 1280, 1, f"{tag} geglu 1280", C)
         bench_linear(m0 // 16, 1280, 5120, 0, f"{tag} ff2 5120->1280", C)
         bench_linear(m0 // 16, 3840, 1280, 0, f"{tag} qkv 1280", C)
+        bench_linear(m0 // 4, 640, 640, 0, f"{tag} out 640", C)
+        bench_linear(m0 // 16, 1280, 1280, 0, f"{tag} out 1280", C)
+        bench_linear(m0, 320, 1600, 0, f"{tag} ff2.proj_out 320", C)
+        bench_linear(m0 // 4, 640, 3200, 0, f"{tag} ff2.proj_out 640", C)
+        bench_linear(m0 // 16, 1280, 6400, 0, f"{tag} ff2.proj_out 1280", C)
