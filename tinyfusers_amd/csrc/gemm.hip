@@ -3,6 +3,7 @@
 // gemm_{igemm,patch,igemm8,pp,c4}.h and are instantiated in gemm_k_*.hip, one translation unit per family so that they compile in
 // parallel; gemm_common.h holds GemmP, the shared epilogue and the launcher declarations (its head comment describes the computation).
 #include "gemm_common.h"
+#include <stdlib.h>
 
 // Split-K partial slabs are fp32 or -- round 4, GemmP::part16 -- fp16 (half the bytes of the seam: a slab is written once and read once, both
 // through HBM / L2; the reducer accumulates in fp32 in split order either way).  PT = the slab's element type.
@@ -787,8 +788,11 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
       if (tv[2] < best) { best = tv[2]; bc = {c, 5, order}; }
     }
   }
-  // the 256-row persistent short-K kernel (variant 7): one 8-wave block per CU walks 256 x 128 tiles -- a candidate once those tiles give most CUs one
-  if (c4_ok(p) && (long long)((p.M + 255) / 256) * ((p.N + 127) / 128) >= 192) {
+  // the 256-row persistent short-K kernel (variant 7): one 8-wave block per CU walks 256 x 128 tiles.  MEASURED SLOWER than k_gemm_c4 on every shape it was
+  // built for (profiles/r05_c8_bench.txt: 5-20 %: eight waves in lockstep idle the matrix pipe during every epilogue, where k_gemm_c4's two independent blocks
+  // overlap one's epilogue with the other's K loop), so the tuner tries it only when asked (TF_TUNE_C8=1); table rows and tf_gemm_debug(16384) still select it
+  static const bool tune_c8 = getenv("TF_TUNE_C8") != nullptr;
+  if (tune_c8 && c4_ok(p) && (long long)((p.M + 255) / 256) * ((p.N + 127) / 128) >= 192) {
     TileCfg c = {256, 128, 1};
     for (int order = 0; order < 2; ++order) {
       int rc = launch_one(p, c, 7, order, workspace, st);   // warm-up
