@@ -20,6 +20,11 @@
 //   * the two blocks of a CU are independent programs: one's epilogue and first-tile latency overlap the other's MFMAs.
 // S = 1 / stride 1 / no padding (rows are contiguous K vectors; the concat pair of the FF2 . proj_out fold is two sources), channel
 // counts on the 64 grid, fp16, no split-K / statistics / time embedding (those launches keep the kernels above).
+#ifndef TF_C4_TWO
+#define TF_C4_TWO 0      // 1 (tagged build -DTF_C4_TWO=1): two K tiles in flight on the two-slot ring through a second barrier behind the fragment reads.  MEASURED: no change
+                         // on any shape (profiles/r05_c4_two.txt: 182.0 vs 181.4 us on 73728 x 2560 x 320 ...) -- the K step is not waiting for ONE tile's latency but for the
+                         // wave's own LDS-DMA issue stream (8 pieces per wave and K tile at 100-185 cycles each); off
+#endif
 template <bool LNF, bool BF = false>   // BF: bfloat16 operands / outputs (gemm_k_c4_bf16.hip)
 __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
   constexpr int BM = 128, BN = 128, MJ = 4, NI = 4;
@@ -122,18 +127,30 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
       if constexpr (LNF) cq[i] = *reinterpret_cast<const f4*>(p.ln_colsum + n);
     }
     const int young = pend > 0 ? pend + (p.bias ? NI : 0) + (LNF ? NI : 0) : 0;
-    // ---- K loop: tile t in slot t & 1; the wait + barrier at the top make tile t visible and slot (t + 1) & 1 free
+    // ---- K loop: tile t in slot t & 1.  Round-5 experiment (TF_C4_TWO = 1, off): TWO K tiles in flight on the two-slot ring -- a wave holds a whole K tile's
+    // fragments in registers while it multiplies, so slot t & 1 is free as soon as EVERY wave has read tile t; a second barrier behind the fragment reads says
+    // so and tile t + 2 is issued there, in front of tile t's MFMAs, instead of one step later.  Parity-green, and no faster (see TF_C4_TWO above).
     for (int t = 0; t < nt; ++t) {
       // K tile t has landed.  For t = 0 it was issued in front of the previous tile's epilogue: where that epilogue's vector-memory
       // instructions are known to be `pend` stores, followed by this tile's bias / column-sum loads and nothing else, those `young`
       // ones stay in flight (the counter retires in issue order)
-      if (t == 0 && young == 4) wait_vm<4>();
-      else if (t == 0 && young == 8) wait_vm<8>();
-      else if (t == 0 && young == 12) wait_vm<12>();
-      else if (t == 0 && young == 16) wait_vm<16>();
+      if (t == 0) {
+        if (young == 4) wait_vm<4>();
+        else if (young == 8) wait_vm<8>();
+        else if (young == 12) wait_vm<12>();
+        else if (young == 16) wait_vm<16>();
+        else wait_vm<0>();
+      }
+#if TF_C4_TWO
+      else if (t + 1 < nt) wait_vm<8>();                   // tile t landed; tile t + 1 (issued one step ago, 8 pieces per wave) stays in flight
+#endif
       else wait_vm<0>();
       barrier();
+#if TF_C4_TWO
+      if (t == 0 && nt > 1) stage(1, 1);                   // (slot 1 held the previous epilogue's patches: free behind this barrier)
+#else
       if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+#endif
       const char* sb = smem + (t & 1) * STAGE;
       h8 wf[2][NI], xf[2][MJ];
 #pragma unroll
@@ -144,6 +161,12 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
         for (int i = 0; i < NI; ++i) wf[f][i] = *reinterpret_cast<const h8*>(sb + ((wo_ + i * 2048) ^ (f * 64)));
       }
       wait_lds_reads();
+#if TF_C4_TWO
+      if (t + 2 < nt) {
+        barrier();                                         // every wave holds tile t in registers: its slot takes tile t + 2 now
+        stage(t & 1, t + 2);
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       if (LNF && need_stats) {
         // row statistics from the fragments: the two waves that share these 64 rows (wn = 0, 1) take one 32-deep k-step each
@@ -239,14 +262,29 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       // read back as rows: 32 rows x (ocols / 8) 16-byte chunks
       const int cpr = ocols >> 3;                          // 8 or 4 chunks per row
-      for (int idx = lane; idx < 32 * cpr; idx += 64) {
+      // (round 5) the residual rows of this half are requested up front -- as one loop the residual load of every iteration sat behind the previous
+      // iteration's store and in front of its own use: four serial global round trips per half
+      h8 rres[4];
+      if (!LNF && p.residual) {                            // (no LayerNorm-folded launch of the step carries a residual: that instance keeps its registers)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int idx = lane + 64 * it;
+          const int row = idx / cpr, c8 = idx - row * cpr;
+          const int m = cm0 + wm * 64 + h * 32 + row, no = ocol0 + c8 * 8;
+          if (idx < 32 * cpr && m < M_ && no < No) rres[it] = *reinterpret_cast<const h8*>(p.residual + (long long)m * No + no);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = lane + 64 * it;
+        if (idx >= 32 * cpr) break;                        // (GEGLU: two iterations)
         const int row = idx / cpr, c8 = idx - row * cpr;
         const int m = cm0 + wm * 64 + h * 32 + row, no = ocol0 + c8 * 8;
         h8 v;
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pa + (unsigned)row * 144u + (unsigned)c8 * 16u) : "memory");
         if (m < M_ && no < No) {
           const long long o = (long long)m * No + no;
-          if (p.residual) { h8 r = *reinterpret_cast<const h8*>(p.residual + o); for (int e = 0; e < 8; ++e) v[e] = f2e<BF>(e2f<BF>(v[e]) + e2f<BF>(r[e])); }
+          if (p.residual) { const h8 r = LNF ? *reinterpret_cast<const h8*>(p.residual + o) : rres[it]; for (int e = 0; e < 8; ++e) v[e] = f2e<BF>(e2f<BF>(v[e]) + e2f<BF>(r[e])); }
           *reinterpret_cast<h8*>(p.y + o) = v;
         }
       }

@@ -255,14 +255,29 @@ __global__ void __launch_bounds__(512, 2) k_gemm_c8(const GemmP p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       // read back as rows: 32 rows x (ocols / 8) 16-byte chunks
       const int cpr = ocols >> 3;                          // 8 or 4 chunks per row
-      for (int idx = lane; idx < 32 * cpr; idx += 64) {
+      // (round 5) the residual rows of this half are requested up front -- as one loop the residual load of every iteration sat behind the previous
+      // iteration's store and in front of its own use: four serial global round trips per half
+      h8 rres[4];
+      if (!LNF && p.residual) {                            // (no LayerNorm-folded launch of the step carries a residual: that instance keeps its registers)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int idx = lane + 64 * it;
+          const int row = idx / cpr, c8 = idx - row * cpr;
+          const int m = cm0 + wm * 64 + h * 32 + row, no = ocol0 + c8 * 8;
+          if (idx < 32 * cpr && m < M_ && no < No) rres[it] = *reinterpret_cast<const h8*>(p.residual + (long long)m * No + no);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = lane + 64 * it;
+        if (idx >= 32 * cpr) break;                        // (GEGLU: two iterations)
         const int row = idx / cpr, c8 = idx - row * cpr;
         const int m = cm0 + wm * 64 + h * 32 + row, no = ocol0 + c8 * 8;
         h8 v;
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pa + (unsigned)row * 144u + (unsigned)c8 * 16u) : "memory");
         if (m < M_ && no < No) {
           const long long o = (long long)m * No + no;
-          if (p.residual) { h8 r = *reinterpret_cast<const h8*>(p.residual + o); for (int e = 0; e < 8; ++e) v[e] = f2e<BF>(e2f<BF>(v[e]) + e2f<BF>(r[e])); }
+          if (p.residual) { const h8 r = LNF ? *reinterpret_cast<const h8*>(p.residual + o) : rres[it]; for (int e = 0; e < 8; ++e) v[e] = f2e<BF>(e2f<BF>(v[e]) + e2f<BF>(r[e])); }
           *reinterpret_cast<h8*>(p.y + o) = v;
         }
       }

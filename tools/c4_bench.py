@@ -44,6 +44,8 @@ def bench_linear(m, n, k, act, label, cfgs):
 if __name__ == "__main__":
     C = [(128, 128, 1, 16), (128, 128, 1, 8), (64, 128, 1, 16), (128, 64, 1, 16), (256, 128, 1, 512), (256, 160, 1, 512), (192, 128, 1, 512), (128, 128, 1, 1024), (128, 128, 1, 1024 | 64), (256, 128, 1, 16384), (256, 128, 1, 16384 | 64)]
     for tag, s in (("c2", 1), ("c5", 9)):
+        if os.environ.get("C4_ONLY") and os.environ["C4_ONLY"] != tag:
+            continue
         m0 = 8192 * s
         bench_linear(m0, 2560, 320, 1, f"{tag} geglu 320", C)
         bench_linear(m0, 320, 1280, 0, f"{tag} ff2 1280->320", C)
