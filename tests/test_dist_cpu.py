@@ -138,9 +138,16 @@ def _stale_worker(rank, path, nonce, delay, q):
     import time
     os.environ["TF_COMM_NONCE"] = nonce
     from tinyfusers_amd.dist import exchange_unique_id
-    time.sleep(delay)
+    marker = path + ".polling"
+    if rank == 0:                                          # publish only once rank 1 has been polling the stale file for a while
+        t_wait = time.time()
+        while not os.path.exists(marker) and time.time() - t_wait < 60:
+            time.sleep(0.01)
+        time.sleep(delay)
+    else:
+        open(marker, "w").close()
     t0 = time.time()
-    uid = exchange_unique_id(rank, lambda: bytes([7] * 128), path, timeout=30.0)
+    uid = exchange_unique_id(rank, lambda: bytes([7] * 128), path, timeout=60.0)
     q.put((rank, uid, time.time() - t0))
 
 
@@ -151,13 +158,13 @@ def test_stale_unique_id_file_of_a_dead_job_is_ignored(tmp_path):
     open(path, "wb").write(bytes(range(128)))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_stale_worker, args=(1, path, "job-B", 0.0, q)), ctx.Process(target=_stale_worker, args=(0, path, "job-B", 1.0, q))]
-    for p in procs: p.start()                              # rank 1 polls the stale file for a second before rank 0 publishes
+    procs = [ctx.Process(target=_stale_worker, args=(1, path, "job-B", 0.0, q)), ctx.Process(target=_stale_worker, args=(0, path, "job-B", 0.5, q))]
+    for p in procs: p.start()                              # rank 1 polls the stale file for half a second before rank 0 publishes
     res = dict((r, (u, dt)) for r, u, dt in (q.get(timeout=60) for _ in range(2)))
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
-    assert res[0][0] == res[1][0] == bytes([7] * 128) and res[1][1] >= 0.8      # the fresh id, and only once rank 0 had written it
+    assert res[0][0] == res[1][0] == bytes([7] * 128) and res[1][1] >= 0.4      # the fresh id, and only once rank 0 had written it (not the stale one it saw first)
     blob = open(path, "rb").read()
     assert len(blob) == 16 + 128 and (os.stat(path).st_mode & 0o777) == 0o600
     # ... and one in the current format carrying ANOTHER job's nonce: a waiting rank of this job times out on it instead of joining a dead id
