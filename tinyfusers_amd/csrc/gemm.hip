@@ -17,24 +17,30 @@ template <> __device__ __forceinline__ f4 part_load4<half_t>(const half_t* p) {
 // past the last one re-reads the last slab and its value is dropped -- because a load under `z < splitk` compiles to load / wait / branch one slab at a
 // time (round 4: the reducers spent 8-16 serial L2 latencies per element that way, 14 us for a launch that moves 5 MB).  NB is the smallest of 2 / 4 /
 // 8 / 16 that covers splitk in one batch where it can: no redundant loads for the common split counts.
-template <typename PT, int NB>
+template <typename PT, int NB, bool VS = true>
 __device__ __forceinline__ f4 sum_partials_nb(const PT* __restrict__ partial, long long total, long long e0, int splitk) {
   f4 v = {0.f, 0.f, 0.f, 0.f};
+  // (the slab stride as a per-lane value: with a uniform stride the compiler keeps NB 64-bit slab bases in SGPRs -- 26-41 of them spilled in the
+  // fp16-slab instances, VERDICT r4 -- where one 64-bit VALU multiply-add per load does)
+  // VS = false (k_splitk_reduce_gn_apply: 128-VGPR budget at 1024 threads, where the per-lane addresses spill VECTOR registers instead): uniform stride
+  int zv_ = 0;
+  if constexpr (VS) asm volatile("v_mov_b32 %0, 0" : "=v"(zv_));
+  const long long stride_v = total + (long long)zv_;
   for (int z0 = 0; z0 < splitk; z0 += NB) {
     f4 u[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) u[i] = part_load4<PT>(partial + (long long)min(z0 + i, splitk - 1) * total + e0);
+    for (int i = 0; i < NB; ++i) u[i] = part_load4<PT>(partial + (long long)min(z0 + i, splitk - 1) * stride_v + e0);
 #pragma unroll
     for (int i = 0; i < NB; ++i) v += z0 + i < splitk ? u[i] : (f4){0.f, 0.f, 0.f, 0.f};
   }
   return v;
 }
-template <typename PT>
+template <typename PT, bool VS = true>
 __device__ __forceinline__ f4 sum_partials(const PT* __restrict__ partial, long long total, long long e0, int splitk) {
-  if (splitk <= 2) return sum_partials_nb<PT, 2>(partial, total, e0, splitk);
-  if (splitk <= 4) return sum_partials_nb<PT, 4>(partial, total, e0, splitk);
-  if (sizeof(PT) == 2 && splitk > 8) return sum_partials_nb<PT, 16>(partial, total, e0, splitk);
-  return sum_partials_nb<PT, 8>(partial, total, e0, splitk);
+  if (splitk <= 2) return sum_partials_nb<PT, 2, VS>(partial, total, e0, splitk);
+  if (splitk <= 4) return sum_partials_nb<PT, 4, VS>(partial, total, e0, splitk);
+  if (sizeof(PT) == 2 && splitk > 8) return sum_partials_nb<PT, 16, VS>(partial, total, e0, splitk);
+  return sum_partials_nb<PT, 8, VS>(partial, total, e0, splitk);
 }
 // split-K reduce + epilogue: y[m,n] = sum_z partial[z,m,n] + bias + bias_nc + residual   (N % 4 == 0 fast path)
 // BF: bias / bias_nc / residual / gamma / beta / y / z hold bfloat16 (containers as in gemm_common.h: e2f / f2e)
@@ -164,7 +170,7 @@ __global__ void __launch_bounds__(1024) k_splitk_reduce_gn_apply(half_t* __restr
       const long long e0 = ((long long)img * HoWo + r) * N + n;
       h4 res = {0, 0, 0, 0};
       if (residual) res = *reinterpret_cast<const h4*>(residual + e0);
-      f4 acc = sum_partials<PT>(partial, total, e0, splitk);
+      f4 acc = sum_partials<PT, false>(partial, total, e0, splitk);
       acc += bv;
       for (int e = 0; e < 4; ++e) acc[e] += e2f<BF>(bnc[e]);
       for (int e = 0; e < 4; ++e) acc[e] += e2f<BF>(res[e]);
@@ -825,10 +831,15 @@ extern "C" int tf_debug_stamps(void* host_out, int blocks) {
   TF_HIP(hipMemcpy(host_out, g_stamp_buf, (size_t)blocks * 64, hipMemcpyDeviceToHost));
   return TF_OK;
 }
+extern "C" int tf_debug_loop_stamps(void* host_out) {      // TF_IGEMM_STAMP == 2: 256 K tiles x 8 u32 stamps of block 0 (behind the per-block table)
+  TF_REQUIRE(host_out && g_stamp_buf, "tf_debug_loop_stamps: no stamps");
+  TF_HIP(hipMemcpy(host_out, g_stamp_buf + (size_t)TF_STAMP_BLOCKS * 8, 256 * 8 * 4, hipMemcpyDeviceToHost));
+  return TF_OK;
+}
 #endif
 static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_bm, int force_bn, int force_split, hipStream_t st, int* gn_chunks = nullptr) {
 #if TF_IGEMM_STAMP
-  if (!g_stamp_buf) { TF_HIP(hipMalloc((void**)&g_stamp_buf, (size_t)TF_STAMP_BLOCKS * 64)); TF_HIP(hipMemset(g_stamp_buf, 0, (size_t)TF_STAMP_BLOCKS * 64)); }
+  if (!g_stamp_buf) { TF_HIP(hipMalloc((void**)&g_stamp_buf, (size_t)TF_STAMP_BLOCKS * 64 + 256 * 8 * 4)); TF_HIP(hipMemset(g_stamp_buf, 0, (size_t)TF_STAMP_BLOCKS * 64 + 256 * 8 * 4)); }
   p.stamp = g_stamp_buf;
 #endif
   p.ktiles = (p.K + 63) / 64;

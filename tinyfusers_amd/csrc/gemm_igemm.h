@@ -68,6 +68,28 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
     if (p.stamp && lane == 0 && blockIdx.x < 8192) { unsigned long long* d = p.stamp + (size_t)blockIdx.x * 8 + base; d[0] = stp0; d[1] = stp1; d[2] = stp2; d[3] = stp3; }
   };
 #define IG_STAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+  // TF_IGEMM_STAMP == 2: per-K-tile stamps (s_memtime, core clock) of block 0's wave 4 (loader: 0 top, 1 tile it + 1 landed, 2 behind barrier(it), 3 next stage
+  // issued) and wave 0 (consumer: 4 fragments of tile it in registers, 5 behind barrier(it)) for K tiles 4 .. 4 + 255, kept in the LDS above the ring
+  // (the launch gets all 160 KiB) and copied out when the waves leave.  Only where lgkmcnt is 0 anyway, so no overlap of the shipped loop is fenced off.
+  const bool lp_on = TF_IGEMM_STAMP == 2 && blockIdx.x == 0 && lane == 0 && (wid == 0 || wid == 4) && p.stamp && !WIDE && BM != 256;
+  const unsigned lp_base = lds_off(smem) + 163840u - 256u * 32u;
+  auto lp = [&](int it, int k) {
+    if (TF_IGEMM_STAMP != 2) return;
+    if (!lp_on || it < 4 || it >= 260) return;
+    unsigned long long t_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
+    asm volatile("ds_write_b32 %0, %1" :: "v"(lp_base + (unsigned)((it - 4) * 8 + k) * 4u), "v"((unsigned)t_) : "memory");
+  };
+  auto lp_out = [&]() {
+    if (TF_IGEMM_STAMP != 2 || !lp_on) return;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int i = 0; i < 256 * 8; ++i) {
+      if (((i & 7) < 4) != (wid == 4)) continue;           // each wave copies its own columns
+      unsigned v_;
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v_) : "v"(lp_base + (unsigned)i * 4u) : "memory");
+      reinterpret_cast<unsigned*>(p.stamp + 8192 * 8)[i] = v_;
+    }
+  };
 #else
 #define IG_STAMP(v) do { } while (0)
 #endif
@@ -263,11 +285,23 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
       if (ln_on && nt > 0) ln_tile(0);                    // slot 0 is refilled only after barrier(0)
       asm volatile("" ::: "memory");
       for (int it = 0; it < nt; ++it) {
+#if TF_IGEMM_STAMP == 2
+        lp(it, 0);
+#endif
         if (it + 1 < nt) wait_stages<LPS, NS - 2>(nt - 2 - it);   // tile it+1 landed (ring holds up to tile it+NS-1 here)
+#if TF_IGEMM_STAMP == 2
+        lp(it, 1);
+#endif
         if (gi_on && it + 1 < nt) gi_tile((it + 1) % NS, kt_begin + it + 1);
         __builtin_amdgcn_s_barrier();                     // barrier(it)
         asm volatile("" ::: "memory");
+#if TF_IGEMM_STAMP == 2
+        lp(it, 2);
+#endif
         if (it + NS < nt) stage(it % NS, kt_begin + it + NS);
+#if TF_IGEMM_STAMP == 2
+        lp(it, 3);
+#endif
         if (ln_on && it + 1 < nt) ln_tile((it + 1) % NS);  // tile it+1 stays in its slot until barrier(it+1)
       }
     }
@@ -313,6 +347,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     IG_STAMP(stp3);
     if (wid == 4) stamp_out(4);
+    lp_out();
 #endif
     return;
   }
@@ -484,9 +519,15 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   if (nt > 0) read_frags(0, wfA, xfA);
   for (int it = 0; it < nt; it += 2) {
     wait_lds_reads();    // fragments of tile it are in registers: its slot may be refilled
+#if TF_IGEMM_STAMP == 2
+    lp(it, 4);
+#endif
     if constexpr (ALL8) { if (it + 1 < nt) wait_stages<LPC, NS - 2>(nt - 2 - it); }   // ... and this wave's pieces of tile it+1 landed
     __builtin_amdgcn_s_barrier();                         // barrier(it): tile it+1 landed
     asm volatile("" ::: "memory");
+#if TF_IGEMM_STAMP == 2
+    lp(it, 5);
+#endif
     if constexpr (ALL8) { if (it + NS < nt) cstage(it % NS, kt_begin + it + NS); }
     if (it + 1 < nt) read_frags((it + 1) % NS, wfB, xfB);
     __builtin_amdgcn_sched_barrier(0);
@@ -494,9 +535,15 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
     __builtin_amdgcn_sched_barrier(0);
     if (it + 1 >= nt) break;
     wait_lds_reads();
+#if TF_IGEMM_STAMP == 2
+    lp(it + 1, 4);
+#endif
     if constexpr (ALL8) { if (it + 2 < nt) wait_stages<LPC, NS - 2>(nt - 3 - it); }
     __builtin_amdgcn_s_barrier();                         // barrier(it+1)
     asm volatile("" ::: "memory");
+#if TF_IGEMM_STAMP == 2
+    lp(it + 1, 5);
+#endif
     if constexpr (ALL8) { if (it + 1 + NS < nt) cstage((it + 1) % NS, kt_begin + it + 1 + NS); }
     if (it + 2 < nt) read_frags((it + 2) % NS, wfA, xfA);
     __builtin_amdgcn_sched_barrier(0);
@@ -534,6 +581,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   IG_STAMP(stp3);
   if (wid == 0) stamp_out(0);
+  lp_out();
 #endif
 }
 #undef IG_STAMP
