@@ -188,7 +188,7 @@ int tf_gemm_tune_trace_dump(const char* path);
  * tf_gemm_force_config(256, BN, split), BN in {128, 160, 256}: fails where it cannot take the launch), 10 (1024) the persistent short-K
  * kernel k_gemm_c4, 11 (2048) the patch form of the ping-pong kernel k_igemm_pp3 (3x3 / stride 1 convolutions on 96 / 48 / 24-pixel output rows, with
  * tf_gemm_force_config(192, BN, 1): the tile width is the instance's own; fails where it cannot take the launch), 13 (8192) the ping-pong kernel's
- * one-phase-per-k-step form on the three-slot ring, 14 (16384) the 256-row persistent short-K kernel k_gemm_c8 (with tf_gemm_force_config(256, 128, 1)).  The ABLATION bits -- 0 no stores,
+ * one-phase-per-k-step form on the three-slot ring, 14 (16384) the 256-row persistent short-K kernel k_gemm_c8 (with tf_gemm_force_config(256, 128, 1)), 15 (32768) the activation-resident short-K kernel k_gemm_ar (K = 256 / 320; with tf_gemm_force_config(128, 128, 1)).  The ABLATION bits -- 0 no stores,
  * 1 no MFMA, 2 no staging, 12 (4096) no fragment reads: wrong results by design -- exist only in the second library built with
  * -DTF_ABLATION (python -m tinyfusers_amd.build --ablation, loaded by the tools/ ablation scripts); the shipped library refuses them (10001) */
 int tf_gemm_debug(int flags);

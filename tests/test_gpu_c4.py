@@ -20,9 +20,10 @@ def tf():
 
 
 KERNELS = {"c4": (128, 128, 1024), "c8": (256, 128, 16384)}      # k_gemm_c4 (two 4-wave blocks per CU, 128 x 128 tiles) / k_gemm_c8 (round 5: one 8-wave block, 256 x 128 tiles, three-slot ring across tiles)
+KERNELS["ar"] = (128, 128, 32768)                                # k_gemm_ar (round 5): the 128-row activation panel resident in LDS, K = 256 / 320 only (tests below: test_ar_*)
 
 
-@pytest.fixture(params=["c4", "c8"])
+@pytest.fixture(params=["c4", "c8"])      # ("ar" has tests of its own below: it takes K = 256 / 320 only)
 def kern(request):
     return request.param
 
@@ -149,3 +150,111 @@ def test_c4_agrees_with_the_deep_ring_kernel_at_config5_size(tf, kern):
     assert np.isfinite(a).all()
     np.testing.assert_allclose(a, r, atol=2e-3, rtol=2e-3)
     np.testing.assert_allclose(y_c42.numpy(), 2.0 * y_lin.numpy(), rtol=0, atol=1.2e-7)
+
+
+# ---- k_gemm_ar: the activation-resident kernel (K = 256 / 320).  Block runs of the tile list that start and end inside a panel, cross one or several panel seams
+# (the resident images are replaced K tile by K tile behind the last step that read them), ragged M / N edges, one tile per block, fewer tiles than CUs.
+@pytest.mark.parametrize("m,n,k", [(1000, 400, 256), (1000, 400, 320), (257, 160, 320), (5000, 320, 320), (8192, 2560, 320), (8192, 960, 320), (8192, 320, 256), (70000, 128, 256),
+                                   (129, 8, 320), (66000, 136, 320), (73728, 320, 320), (36864, 2560, 320), (40000, 1000, 256), (128, 128, 320), (33000, 392, 320)])
+def test_ar_linear_exact_integers(tf, m, n, k):
+    from tinyfusers_amd.native import hip
+    rs = np.random.RandomState(m + n + k)
+    x = rs.randint(-3, 4, (m, k)).astype(np.float32); w = rs.randint(-2, 3, (n, k)).astype(np.float32)
+    b = rs.randint(-4, 5, (n,)).astype(np.float32)
+    y = tf.DeviceArray.empty((m, n))
+    xd, wd, bd = dev(tf, x), dev(tf, w), dev(tf, b)
+    with forced("ar"):
+        hip.tf_linear_f16(y.ptr, xd.ptr, wd.ptr, bd.ptr, None, m, n, k, 0, None, 0, None)
+    np.testing.assert_array_equal(y.numpy(), (x @ w.T + b).astype(np.float16).astype(np.float32))
+    y2 = tf.DeviceArray.empty((m, n))
+    with forced("ar"):
+        hip.tf_linear_f16(y2.ptr, xd.ptr, wd.ptr, None, None, m, n, k, 0, None, 0, None)
+    np.testing.assert_array_equal(y2.numpy(), (x @ w.T).astype(np.float16).astype(np.float32))
+
+
+def test_ar_refuses_other_k_and_residuals(tf):
+    from tinyfusers_amd.native import hip
+    for m, n, k, res in ((512, 256, 128, 0), (512, 256, 640, 0), (512, 250, 320, 0), (512, 256, 320, 1)):     # K of 2 / 10 tiles; N off the 8 grid; a residual (k_gemm_c4's)
+        y = tf.DeviceArray.empty((m, n))
+        x, w = dev(tf, rnd("arr.x", (m, k))), dev(tf, rnd("arr.w", (n, k)))
+        r = dev(tf, rnd("arr.r", (m, n)))
+        with forced("ar"):
+            with pytest.raises(RuntimeError):
+                hip.tf_linear_f16(y.ptr, x.ptr, w.ptr, None, r.ptr if res else None, m, n, k, 0, None, 0, None)
+
+
+@pytest.mark.parametrize("m,c", [(4608, 320), (9216, 320), (1000, 256)])
+def test_ar_geglu(tf, m, c):
+    from oracle import ops as O
+    from tinyfusers_amd.ff.nn import GEGLU
+    x = rnd("arg.x", (m, c)); w = rnd("arg.w", (8 * c, c), c ** -0.5); b = rnd("arg.b", (8 * c,), 0.1)
+    g = GEGLU(c, 4 * c, init=False); g.proj.weight = dev(tf, w); g.proj.bias = dev(tf, b)
+    with forced("ar"):
+        got = g(dev(tf, x)).numpy()
+    close(got, O.geglu(x, w, b).numpy())
+
+
+@pytest.mark.parametrize("m,n,k,act", [(4608, 960, 320, 0), (40000, 320, 320, 0), (4608, 1280, 320, 1), (1000, 2560, 256, 1), (300, 128, 256, 0)])
+def test_ar_linear_with_folded_layer_norm(tf, m, n, k, act):
+    """Linear(LayerNorm(x)) on the raw x: the row statistics come from the resident panel's fragments during the panel's first tile of a block's run (a run that
+    starts inside a panel recomputes them)."""
+    from oracle import ops as O
+    from tinyfusers_amd.ff.layer_norm import LayerNorm
+    from tinyfusers_amd.ff.linear import fold_layer_norm, linear_ln_f16
+    from tinyfusers_amd.ff.nn import GEGLU
+    x = rnd("aln.x", (m, k), 1.5) + 0.7
+    g, b = 1 + rnd("aln.g", (k,), 0.1), rnd("aln.b", (k,), 0.1)
+    ln = LayerNorm(k); ln.weight = dev(tf, g); ln.bias = dev(tf, b)
+    xn = O.layer_norm(x, g, b)
+    with forced("ar"):
+        if act == 0:
+            w, bias = rnd("aln.w", (n, k), k ** -0.5), rnd("aln.bias", (n,), 0.1)
+            got = linear_ln_f16(dev(tf, x), fold_layer_norm(dev(tf, w), dev(tf, bias), ln), ln.eps).numpy()
+            want = O.linear(xn, w, bias).numpy()
+        else:
+            w, bias = rnd("aln.w", (2 * n, k), k ** -0.5), rnd("aln.bias", (2 * n,), 0.1)
+            ge = GEGLU(k, n, init=False); ge.proj.weight = dev(tf, w); ge.proj.bias = dev(tf, bias)
+            got = ge(dev(tf, x), ln=ln).numpy()
+            want = O.geglu(xn, w, bias).numpy()
+    close(got, want)
+
+
+@pytest.mark.parametrize("n,c1,c2,hw,cout", [(2, 320, 0, 32, 320), (2, 192, 128, 32, 192), (3, 256, 0, 24, 128), (2, 64, 192, 32, 320)])
+def test_ar_conv1x1(tf, n, c1, c2, hw, cout):
+    """A 1x1 / stride 1 convolution is the same GEMM; the concat input is a second K segment with its own row pitch (the panel's K tiles come from two sources)."""
+    from oracle import ops as O
+    from tinyfusers_amd.vision.conv2d import Conv2d
+    xa = rnd("arc.xa", (n, c1, hw, hw)); xb = rnd("arc.xb", (n, c2, hw, hw)) if c2 else None
+    cin = c1 + c2
+    wt = rnd("arc.w", (cout, cin, 1, 1), cin ** -0.5); b = rnd("arc.b", (cout,), 0.1)
+    m = Conv2d(cin, cout, [1, 1], init=False); m.weight = dev(tf, wt); m.bias = dev(tf, b)
+    x = (dev(tf, xa), dev(tf, xb)) if c2 else dev(tf, xa)
+    xin = torch.from_numpy(np.concatenate((xa, xb), 1) if c2 else xa)
+    want = O.conv2d_bias(xin, wt, b, (0, 0))
+    with forced("ar"):
+        got = m(x).numpy()
+    close(got, want.numpy())
+
+
+def test_ar_agrees_with_the_deep_ring_kernel_at_config5_size(tf):
+    """73728 x 2560 x 320 (config 5's GEGLU projection: 576 panels, 45 tiles per block, two or three seams per run): against the round-1 kernel on the same inputs,
+    and the linearity property f(2 x) = 2 f(x) of the plain linear (exact in floating point)."""
+    from tinyfusers_amd.native import hip, lib
+    m, n, k = 73728, 2560, 320
+    x = rnd("a45.x", (m, k), 0.5); w = rnd("a45.w", (n, k), k ** -0.5); b = rnd("a45.b", (n,), 0.1)
+    xd, x2d, wd, bd = dev(tf, x), dev(tf, 2.0 * x), dev(tf, w), dev(tf, b)
+    y_ar, y_ar2, y_ref = tf.DeviceArray.empty((m, n // 2)), tf.DeviceArray.empty((m, n)), tf.DeviceArray.empty((m, n // 2))
+    y_lin = tf.DeviceArray.empty((m, n))
+    with forced("ar"):
+        hip.tf_linear_f16(y_ar.ptr, xd.ptr, wd.ptr, bd.ptr, None, m, n // 2, k, 1, None, 0, None)          # GEGLU
+        hip.tf_linear_f16(y_lin.ptr, xd.ptr, wd.ptr, None, None, m, n, k, 0, None, 0, None)
+        hip.tf_linear_f16(y_ar2.ptr, x2d.ptr, wd.ptr, None, None, m, n, k, 0, None, 0, None)
+    lib.tf_gemm_force_config(128, 128, 1); lib.tf_gemm_debug(16)
+    try:
+        hip.tf_linear_f16(y_ref.ptr, xd.ptr, wd.ptr, bd.ptr, None, m, n // 2, k, 1, None, 0, None)
+    finally:
+        lib.tf_gemm_force_config(0, 0, 0); lib.tf_gemm_debug(0)
+    a, r = y_ar.numpy(), y_ref.numpy()
+    assert np.isfinite(a).all()
+    np.testing.assert_allclose(a, r, atol=2e-3, rtol=2e-3)
+    np.testing.assert_allclose(y_ar2.numpy(), 2.0 * y_lin.numpy(), rtol=0, atol=1.2e-7)

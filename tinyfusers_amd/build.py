@@ -23,7 +23,7 @@ ASAN_FLAGS = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-omit-fr
 # the GEMM family is one translation unit per kernel family (gemm_k_*.hip) so that its instances compile in parallel; the largest first
 SOURCES = ["gemm_k_pp16.hip", "gemm_k_pp16_bf16.hip", "gemm_k_pp8.hip", "gemm_k_igemm_128.hip", "gemm_k_igemm_128_bf16.hip", "gemm_k_igemm_64.hip", "gemm_k_igemm_64_bf16.hip",
            "gemm_k_igemm_160.hip", "gemm_k_igemm_160_bf16.hip", "gemm_k_patch.hip", "gemm_k_patch_bf16.hip", "sdpa.hip", "sdpa_bf16.hip",
-           "gemm_k_igemm8.hip", "gemm_k_c4.hip", "gemm_k_c4_bf16.hip", "gemm_k_c8.hip", "gemm_k_c8_bf16.hip", "gemm_k_pp3.hip", "gemm_k_pp3_bf16.hip", "gemm.hip", "norm.hip", "elementwise.hip", "runtime.hip", "sgemm.hip",
+           "gemm_k_igemm8.hip", "gemm_k_c4.hip", "gemm_k_c4_bf16.hip", "gemm_k_c8.hip", "gemm_k_c8_bf16.hip", "gemm_k_ar.hip", "gemm_k_ar_bf16.hip", "gemm_k_pp3.hip", "gemm_k_pp3_bf16.hip", "gemm.hip", "norm.hip", "elementwise.hip", "runtime.hip", "sgemm.hip",
            "comm.hip", "rtc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-ffp-contract=fast"]
 # sdpa.hip: keep the MFMA accumulators in VGPRs (the softmax reads every score: no v_accvgpr_read traffic) and drop

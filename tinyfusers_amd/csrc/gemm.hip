@@ -481,6 +481,8 @@ static bool c4_ok(const GemmP& p) {
   if ((p.C1 % 64) || (p.C2 % 64) || (p.N % 8) || p.M < 1) return false;
   return p.act == 0 || (p.act == 1 && p.N % 64 == 0);
 }
+// k_gemm_ar (variant 8): the activation-resident short-K kernel -- k_gemm_c4's launches whose K is 4 or 5 whole K tiles (256 / 320: the 128-row panel stays in LDS), no residual
+static bool ar_ok(const GemmP& p) { return c4_ok(p) && (p.K == 256 || p.K == 320) && !p.residual; }   // (its loader waves store the outputs: a residual would be a second load stream in their instruction budget -- those launches stay on k_gemm_c4)
 static const int kTiles8[][2] = {{128, 128}, {64, 128}, {128, 64}, {256, 64}, {64, 64}};
 static const int kNumTiles8 = 5;
 
@@ -551,6 +553,10 @@ static int launch_one(GemmP p, TileCfg c, int variant, int order, void* workspac
   else if (variant == 7) {
     if (!c4_ok(p) || c.bm != 256 || c.bn != 128 || p.splitk != 1) { tf_set_error("run_gemm: the 256-row persistent short-K kernel cannot run this launch (tile %dx%d, split %d)", c.bm, c.bn, p.splitk); return TF_E_UNSUPPORTED; }
     rc = bf ? tfk_launch_c8_bf16(p, st) : tfk_launch_c8(p, st);
+  }
+  else if (variant == 8) {
+    if (!ar_ok(p) || c.bm != 128 || c.bn != 128 || p.splitk != 1) { tf_set_error("run_gemm: the activation-resident short-K kernel cannot run this launch (tile %dx%d, split %d, K %d)", c.bm, c.bn, p.splitk, p.K); return TF_E_UNSUPPORTED; }
+    rc = bf ? tfk_launch_ar_bf16(p, st) : tfk_launch_ar(p, st);
   }
   else if (variant == 6) {
     if (p.splitk != 1 || !pp3_setup(p, c.bm, c.bn)) { tf_set_error("run_gemm: the patch form of the ping-pong kernel cannot run this launch (tile %dx%d, split %d)", c.bm, c.bn, p.splitk); return TF_E_UNSUPPORTED; }
@@ -794,6 +800,24 @@ static int autotune(const GemmP& p, void* workspace, size_t workspace_bytes, hip
       if (tv[2] < best) { best = tv[2]; bc = {c, 5, order}; }
     }
   }
+  // the activation-resident short-K kernel (variant 8; K = 256 / 320): the tile order is its own (n fastest inside a block's run)
+  if (ar_ok(p) && (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) >= 96) {
+    TileCfg c = {128, 128, 1};
+    int rc = launch_one(p, c, 8, 0, workspace, st);   // warm-up
+    if (rc) return rc;
+    float tv[5];
+    for (int r = 0; r < 5; ++r) {
+      TF_HIP(hipMemsetAsync(g_flush, r, TF_FLUSH_BYTES, st));
+      TF_HIP(hipEventRecord(a, st));
+      rc = launch_one(p, c, 8, 0, workspace, st);
+      if (rc) return rc;
+      TF_HIP(hipEventRecord(b, st));
+      TF_HIP(hipEventSynchronize(b));
+      TF_HIP(hipEventElapsedTime(&tv[r], a, b));
+    }
+    for (int i = 0; i < 5; ++i) for (int j = i + 1; j < 5; ++j) if (tv[j] < tv[i]) { float t = tv[i]; tv[i] = tv[j]; tv[j] = t; }
+    if (tv[2] < best) { best = tv[2]; bc = {c, 8, 0}; }
+  }
   // the 256-row persistent short-K kernel (variant 7): one 8-wave block per CU walks 256 x 128 tiles.  MEASURED SLOWER than k_gemm_c4 on every shape it was
   // built for (profiles/r05_c8_bench.txt: 5-20 %: eight waves in lockstep idle the matrix pipe during every epilogue, where k_gemm_c4's two independent blocks
   // overlap one's epilogue with the other's K loop), so the tuner tries it only when asked (TF_TUNE_C8=1); table rows and tf_gemm_debug(16384) still select it
@@ -939,6 +963,13 @@ static int run_gemm(GemmP p, void* workspace, size_t workspace_bytes, int force_
     else if (g_force_wide == 7) { tf_set_error("run_gemm: the 256-row persistent short-K kernel cannot run this launch"); return TF_E_UNSUPPORTED; }
     else { wide = 0; t.c = choose_tiles(p.M, p.N, p.K, p.act, workspace != nullptr); }
   }
+  if (wide == 8) {
+    GemmP q = p;
+    if (!gn_chunks) q.gn_part = nullptr;
+    if (ar_ok(q) && (!force_bm || (t.c.bm == 128 && t.c.bn == 128 && t.c.splitk == 1))) t.c = {128, 128, 1};
+    else if (g_force_wide == 8) { tf_set_error("run_gemm: the activation-resident short-K kernel cannot run this launch"); return TF_E_UNSUPPORTED; }
+    else wide = c4_ok(q) ? 5 : 0;                         // (a table row of another K: the persistent kernel it grew out of)
+  }
   if (wide == 5) {
     GemmP q = p;
     if (!gn_chunks) q.gn_part = nullptr;                  // (statistics the caller did not ask to hear about are never requested)
@@ -1003,7 +1034,7 @@ int tf_gemm_debug(int flags) {
   TF_REQUIRE(!(flags & (7 | 4096)), "tf_gemm_debug: the ablation bits (1, 2, 4, 4096) exist only in the library built with -DTF_ABLATION (python -m tinyfusers_amd.build --ablation)");
 #endif
   g_pp_np = (flags & 8192) ? 2 : 0;                       // 8192: k_igemm_pp with one phase per k-step even where the 3-slot ring allows one per K tile
-  g_force_wide = (flags & 16384) ? 7 : (flags & 2048) ? 6 : (flags & 1024) ? 5 : (flags & 512) ? 4 : (flags & 256) ? 3 : (flags & 128) ? 2 : (flags & 16) ? 1 : (flags & 8) ? 0 : -1;   // 128 / 256 / 512 / 1024 / 2048: the PATCH / ALL8 / ping-pong / persistent short-K / ping-pong PATCH variants where eligible
+  g_force_wide = (flags & 32768) ? 8 : (flags & 16384) ? 7 : (flags & 2048) ? 6 : (flags & 1024) ? 5 : (flags & 512) ? 4 : (flags & 256) ? 3 : (flags & 128) ? 2 : (flags & 16) ? 1 : (flags & 8) ? 0 : -1;   // 128 / 256 / 512 / 1024 / 2048: the PATCH / ALL8 / ping-pong / persistent short-K / ping-pong PATCH variants where eligible
   g_force_order = (flags & 64) ? 1 : (flags & 32) ? 0 : -1;
   return TF_OK;
 }
@@ -1081,8 +1112,9 @@ int tf_gemm_tune_load(const char* path) {
     if ((act == 1 || ln || (k[9] & 256)) && sk > 1) ok = false;
     if (wide == 5) ok = bm == 128 && bn == 128 && sk == 1 && !f8;
     if (wide == 7) ok = bm == 256 && bn == 128 && sk == 1 && !f8;
+    if (wide == 8) ok = bm == 128 && bn == 128 && sk == 1 && !f8;
     if (wide == 6) ok = bm == 192 && (bn == 128 || bn == 160) && sk == 1 && k[5] == 3 && k[6] == 1 && act == 0 && !ln && (!f8 || (k[9] & 512));   // the patch form: 3x3 / stride 1; e4m3 only block-scaled
-    if (ok) g_tuned[k] = {{bm, bn, sk}, wide < 0 || wide > 7 ? 0 : wide, order != 0 ? 1 : 0};
+    if (ok) g_tuned[k] = {{bm, bn, sk}, wide < 0 || wide > 8 ? 0 : wide, order != 0 ? 1 : 0};
   }
   fclose(f);
   return TF_OK;
@@ -1176,7 +1208,7 @@ int tf_prof_dump(const char* path) {
   if (rc) return rc;
   FILE* f = fopen(path, "w");
   TF_REQUIRE(f, "tf_prof_dump: cannot open %s", path);
-  fprintf(f, "M,N,K,taps,bm,bn,splitk,variant,launches,total_ms,avg_us,tflops\n");   // variant: 0 deep ring, 1 wide, 2 patch, 3 all8, 4 ping-pong, 5 persistent short-K, 6 ping-pong patch, 7 persistent short-K 256-row; times include the split-K reduce
+  fprintf(f, "M,N,K,taps,bm,bn,splitk,variant,launches,total_ms,avg_us,tflops\n");   // variant: 0 deep ring, 1 wide, 2 patch, 3 all8, 4 ping-pong, 5 persistent short-K, 6 ping-pong patch, 7 persistent short-K 256-row, 8 activation-resident short-K; times include the split-K reduce
   for (auto& kv : g_prof_shapes) {
     const auto& k = kv.first;
     double ms = kv.second.second; long long n = kv.second.first;

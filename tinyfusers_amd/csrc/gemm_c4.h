@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       // read back as rows: 32 rows x (ocols / 8) 16-byte chunks
-      const int cpr = ocols >> 3;                          // 8 or 4 chunks per row
+      const int csh = geglu ? 2 : 3, cpr = 1 << csh;       // 8 or 4 chunks per row (a shift, not a divide: the runtime quotient cost ~40 VALU instructions per use)
       // (round 5) the residual rows of this half are requested up front -- as one loop the residual load of every iteration sat behind the previous
       // iteration's store and in front of its own use: four serial global round trips per half
       h8 rres[4];
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int idx = lane + 64 * it;
-          const int row = idx / cpr, c8 = idx - row * cpr;
+          const int row = idx >> csh, c8 = idx & (cpr - 1);
           const int m = cm0 + wm * 64 + h * 32 + row, no = ocol0 + c8 * 8;
           if (idx < 32 * cpr && m < M_ && no < No) rres[it] = *reinterpret_cast<const h8*>(p.residual + (long long)m * No + no);
         }
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_c4(const GemmP p) {
       for (int it = 0; it < 4; ++it) {
         const int idx = lane + 64 * it;
         if (idx >= 32 * cpr) break;                        // (GEGLU: two iterations)
-        const int row = idx / cpr, c8 = idx - row * cpr;
+        const int row = idx >> csh, c8 = idx & (cpr - 1);
         const int m = cm0 + wm * 64 + h * 32 + row, no = ocol0 + c8 * 8;
         h8 v;
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pa + (unsigned)row * 144u + (unsigned)c8 * 16u) : "memory");

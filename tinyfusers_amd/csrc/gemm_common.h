@@ -698,6 +698,9 @@ int tfk_launch_pp3(const GemmP& p, hipStream_t st, int bn);
 //   k_gemm_c8 (gemm_k_c8.hip)
 int tfk_launch_c8(const GemmP& p, hipStream_t st);
 int tfk_launch_c8_bf16(const GemmP& p, hipStream_t st);
+//   k_gemm_ar (gemm_k_ar.hip)
+int tfk_launch_ar(const GemmP& p, hipStream_t st);
+int tfk_launch_ar_bf16(const GemmP& p, hipStream_t st);
 //   the bfloat16 instances of the same kernels (gemm_k_*_bf16.hip)
 int tfk_launch_igemm_160_bf16(const GemmP& p, hipStream_t st, int bm, bool wide, bool all8);
 int tfk_launch_igemm_128_bf16(const GemmP& p, hipStream_t st, int bm, bool wide, bool all8);
