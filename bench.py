@@ -450,7 +450,7 @@ def roofline_leg(sd, run, n_inst, peak, default_workload):
         pass
     return {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": traffic, "traffic_unit": tnote,
-            "kernel": "k_igemm* / k_gemm_c4 (implicit-GEMM conv2d + linear) together with the split-K reduce launches that finish them",
+            "kernel": "k_igemm* / k_gemm_c4 / k_gemm_ar (implicit-GEMM conv2d + linear) together with the split-K reduce launches that finish them",
             "launches_per_step": gl.value / n_inst, "avg_launch_us": round(gfull.value * 1e3 / max(1, gl.value), 2),
             "gemm_ms_per_step": round(gfull.value / n_inst, 4), "gemm_flop_per_step": gfl.value / n_inst,
             "gemm_kernel_only": {"achieved": round(ach_k, 1), "frac": round(ach_k / peak, 4), "ms_per_step": round(gms.value / n_inst, 4),

@@ -147,6 +147,22 @@ def test_bf16_linear_is_exact_on_small_integers_on_every_kernel(cfg):
     np.testing.assert_array_equal(y, OB.round_bf16(want))
 
 
+@pytest.mark.parametrize("m,n,k", [(4608, 960, 320), (33000, 392, 320), (1000, 400, 256)])
+def test_bf16_linear_is_exact_on_small_integers_on_the_activation_resident_kernel(m, n, k):
+    """k_gemm_ar<..., BF> (K = 256 / 320, no residual): the same exact-integer argument; runs that cross panel seams and ragged edges."""
+    from tinyfusers_amd.ff.linear import linear_f16
+    from tinyfusers_amd.native import lib
+    rng = np.random.default_rng(m + n + k)
+    x, w = rng.integers(-3, 4, (m, k)).astype(np.float32), rng.integers(-3, 4, (n, k)).astype(np.float32)
+    b = rng.integers(-8, 9, n).astype(np.float32)
+    try:
+        lib.tf_gemm_force_config(128, 128, 1); lib.tf_gemm_debug(32768)
+        y = linear_f16(_dev16(x, True, "row"), _dev16(w, True, "row"), _dev16(b, True, "row")).numpy()
+    finally:
+        lib.tf_gemm_force_config(0, 0, 0); lib.tf_gemm_debug(0)
+    np.testing.assert_array_equal(y, OB.round_bf16(x @ w.T + b))
+
+
 @pytest.mark.parametrize("shape", [(2, 320, 64, 64, 320), (2, 1280, 8, 8, 1280), (8, 640, 48, 48, 640)])
 def test_bf16_conv3x3_all_fusions_against_the_oracle(shape):
     """conv 3x3 with bias + time embedding + residual + the statistics of the next GroupNorm, then that GroupNorm (+ SiLU): the fused entries in bfloat16

@@ -4,7 +4,7 @@ usage: pmc_sq_summary.py <dir> [out.json]"""
 import csv, glob, json, sys
 d = sys.argv[1]
 f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
-fam_of = lambda k: ("k_igemm" if ("k_igemm" in k or "k_gemm_c" in k) else "k_sdpa" if "k_sdpa" in k else "k_gn_apply" if "gn_apply" in k else "k_gn_stats" if "gn_stats" in k
+fam_of = lambda k: ("k_igemm" if ("k_igemm" in k or "k_gemm_" in k) else "k_sdpa" if "k_sdpa" in k else "k_gn_apply" if "gn_apply" in k else "k_gn_stats" if "gn_stats" in k
                     else "k_splitk_reduce" if "splitk" in k else "other")
 # kernel durations of the same run (q_kernel_trace.csv) -> SIMD-cycles available per family at the nominal 2.4 GHz, 1024 SIMDs
 CLK, SIMDS = 2.4e9, 256 * 4

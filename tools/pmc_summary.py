@@ -11,7 +11,7 @@ def load(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter: continue
         k = r["Kernel_Name"]
-        fam = "k_igemm" if ("k_igemm" in k or "k_gemm_c" in k) else "k_sdpa" if "k_sdpa" in k else "k_gn" if "k_gn" in k else "k_layer_norm" if "layer_norm" in k else "k_splitk_reduce" if "splitk" in k else "other"
+        fam = "k_igemm" if ("k_igemm" in k or "k_gemm_" in k) else "k_sdpa" if "k_sdpa" in k else "k_gn" if "k_gn" in k else "k_layer_norm" if "layer_norm" in k else "k_splitk_reduce" if "splitk" in k else "other"
         tot[fam] = tot.get(fam, 0.0) + float(r["Counter_Value"]); n[fam] = n.get(fam, 0) + 1
     return tot, n
 

@@ -19,7 +19,7 @@ print("sum of kernel durations: %.3f ms/step over %d kernel launches/step" % (to
 if len(sys.argv) > 3:
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from bench import csrc_hash
-    fam = [r for r in rows if "k_igemm" in r["Name"] or "k_gemm_c" in r["Name"]]      # (k_gemm_c4 / k_gemm_c8: the family's persistent short-K kernels)
+    fam = [r for r in rows if "k_igemm" in r["Name"] or "k_gemm_" in r["Name"]]      # (k_gemm_c4 / k_gemm_c8 / k_gemm_ar: the family's persistent short-K kernels)
     red = [r for r in rows if "k_splitk_reduce" in r["Name"]]
     calls = sum(int(r["Calls"]) for r in fam)
     ns = sum(float(r["TotalDurationNs"]) for r in fam)
