@@ -67,7 +67,7 @@ ok(lib.tf_gemm_tune_count(ctypes.byref(n)) == 0 and n.value >= len(rows), "rows 
 for i in range(n.value):
     k, c = c_int10(), c_int5()
     lib.tf_gemm_tune_entry(i, k, c)
-    ok(c[0] in (64, 128, 192, 256) and c[1] in (64, 128, 160, 256) and 1 <= c[2] <= 32 and 0 <= c[3] <= 7 and c[4] in (0, 1), f"row {list(k)} -> {list(c)}")
+    ok(c[0] in (64, 128, 192, 256) and c[1] in (64, 128, 160, 256) and 1 <= c[2] <= 32 and 0 <= c[3] <= 8 and c[4] in (0, 1), f"row {list(k)} -> {list(c)}")
 # ---- switches
 ok(lib.tf_gemm_autotune(3) == 10001 and lib.tf_gemm_autotune(-1) == 10001 and lib.tf_gemm_autotune(2) == 0 and lib.tf_gemm_autotune(1) == 0, "autotune modes")
 ok(lib.tf_gemm_splitk_partials(8) == 10001 and lib.tf_gemm_splitk_partials(32) == 0 and lib.tf_gemm_splitk_partials(16) == 0, "slab types")
