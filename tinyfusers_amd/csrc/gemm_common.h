@@ -24,6 +24,17 @@
 #ifndef TF_IGEMM_STAMP
 #define TF_IGEMM_STAMP 0
 #endif
+// The launch seam of k_igemm / k_igemm_patch (round 5; A/B in profiles/r05_ab.txt, tagged builds -DTF_IGEMM_PRE=2 / -DTF_IGEMM_EPRE=0):
+//   TF_IGEMM_PRE  = ring stages issued in FRONT of barrier P.  99 = the whole ring (shipped; the round-4 behaviour).  2 was tried on the strength of the phase stamps -- the consumers reach K tile 0
+//                   0.6-1.2 us earlier -- and shipped for part of the round: in the STEP it is 0.2 % SLOWER, four rounds of four on one box (the stages pushed behind the barrier land later, and the
+//                   loaders' issue stream is the K loop's critical path): reverted.
+//   TF_IGEMM_EPRE = epilogue loads (bias / residual / time embedding) requested when the K loop ends, under barriers X / Y (1, shipped; 0 = inside the epilogue): neutral within noise in the step.
+#ifndef TF_IGEMM_PRE
+#define TF_IGEMM_PRE 99
+#endif
+#ifndef TF_IGEMM_EPRE
+#define TF_IGEMM_EPRE 1
+#endif
 struct GemmP {
   const half_t* x; const half_t* x2; const half_t* w; half_t* y;
   // extra K segment after the R*S taps (tf_conv2d_fused_f16): a 1x1 projection of a second activation (pair) x3 | x4 read

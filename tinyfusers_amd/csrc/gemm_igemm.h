@@ -22,7 +22,7 @@
 template <int BM, int BN, bool GENERIC, bool WIDE, bool ALL8 = false, bool GI = false, bool BF = false>   // BF: bfloat16 operands / outputs (gemm_common.h: mfma16 / e2f / f2e)
 __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
   constexpr int TM = BM / 2, TN = BN / 2, MJ = TM / 16, NI = TN / 16;
-  constexpr bool EPRE = !WIDE;                            // epilogue loads requested when the K loop ends (igemm_epilogue_prefetch); not on the 128-VGPR two-blocks-per-CU form (up to 48 registers)
+  constexpr bool EPRE = !WIDE && TF_IGEMM_EPRE;                            // epilogue loads requested when the K loop ends (igemm_epilogue_prefetch); not on the 128-VGPR two-blocks-per-CU form (up to 48 registers)
   constexpr int NG = (BM + BN) / 8;                       // 8-row staging groups: activation rows first, then weight rows
   // weight pieces per CONSUMER wave per stage (the last 4 LPC groups); one more per wave measured 1-3 % slower on every shape
   constexpr int LPC = ALL8 ? (BN >= 128 ? (BM + BN >= 256 ? 3 : 2) : 1) : 0;
@@ -265,9 +265,9 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
       // Ring protocol (NS slots, tile t lives in slot t % NS).  Barrier P hands tile 0 to the consumers; barrier(it)
       // guarantees tile it+1 has landed (the consumers prefetch its fragments while multiplying tile it) and hands
       // slot it % NS back (the consumers drained their reads of tile it before arriving).  NS-1 tiles stay in flight.
-      // (round 5: only PRE = 2 stages are issued in front of barrier P -- the stamps showed the consumers waiting 0.6-1.2 us for nothing but the
+      // (TF_IGEMM_PRE stages are issued in front of barrier P -- gemm_common.h; with 2, tried in round 5, the stamps showed the consumers no longer waiting 0.6-1.2 us for nothing but the
       // ISSUE of ring slots 2 .. NS-1, at 60-100 cycles per 1-KiB piece; the rest of the ring follows right behind the barrier)
-      constexpr int PRE = NS < 2 ? NS : 2;
+      constexpr int PRE = NS < TF_IGEMM_PRE ? NS : TF_IGEMM_PRE;
 #pragma unroll
       for (int s_ = 0; s_ < PRE; ++s_)
         if (s_ < nt) stage(s_, kt_begin + s_);
@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(512, WIDE ? 4 : 2) k_igemm(const GemmP p) {
 #pragma unroll
         for (int j = 0; j < MJ; ++j) acc[i][j] = mfma16<BF>(wf[k2][i], xf[k2][j], acc[i][j]);
   };
-  constexpr int PRE = NS < 2 ? NS : 2;                     // (as the loaders: two stages in front of barrier P, the rest of the ring behind it)
+  constexpr int PRE = NS < TF_IGEMM_PRE ? NS : TF_IGEMM_PRE;   // (as the loaders: two stages in front of barrier P, the rest of the ring behind it)
   if constexpr (ALL8) {
 #pragma unroll
     for (int s_ = 0; s_ < PRE; ++s_)

@@ -181,10 +181,9 @@ __global__ void __launch_bounds__(512, 2) k_igemm_patch(const GemmP p) {
     auto advance = [&]() { if (ng >= G1) ++ng; else if (++ntap == 9) { ntap = 0; ++ng; } };
     advance();                                             // tile 1
     {
-      // (round 5, as in k_igemm: two stages in front of barrier P, the rest of the ring right behind it -- the consumers were waiting for the ISSUE of
-      // ring slots 2 .. NS-1, not for data: profiles/r05_small_gemm_stamps.txt)
+      // TF_IGEMM_PRE stages in front of barrier P, the rest of the ring right behind it (gemm_common.h: 99 = the whole ring, shipped; 2 was measured slower in the step)
       int s_ = 0;
-      for (; s_ < 2 && s_ < NS && s_ < nt; ++s_) { int n = stage(s_); if (s_ > 0) W += n; }
+      for (; s_ < TF_IGEMM_PRE && s_ < NS && s_ < nt; ++s_) { int n = stage(s_); if (s_ > 0) W += n; }
       if (gi_on) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }   // barriers A, B of gi_prologue (consumer waves)
       wait_vm_dyn(W);                                      // tile 0 (and everything issued before it) landed
       if (gi_on && pro_g >= 0) {
