@@ -1,6 +1,10 @@
 #!/bin/bash
 # tools/ab_lib.sh ROUNDS OLD_LIB [bench args...]: same-box A/B of the built library against an earlier one (e.g. _r03lib/libtinyfusers_hip.so),
 # alternating, one bench process per measurement (200 graph-replayed steps each); prints ms per step per round.
+# BOTH arms run with TF_HOIST_STEP_INVARIANTS=0: a library from before round 4 has no tf_set_step_params_copy, and switching the hoisting off for the OLD arm only
+# (as this script did until round 5) handicaps it by about 1 % -- that is how round 5 first read a -0.65 % "gain" that a fair comparison showed to be +0.16 %
+# (profiles/r05_ab.txt blocks 1-2).  Both arms also read the CURRENT tuning table: an old library drops rows of kernel variants it does not know and runs those shapes
+# on a fallback tile.  For a library that has its own table and the hoisting entry (round 4 on), use tools/ab_round.sh instead.
 R=$1; OLD=$2; shift 2
 mkdir -p gpurun_out
 one() {   # label, env assignment
@@ -15,5 +19,5 @@ PY
 }
 for i in $(seq 1 $R); do
   one "old[$i]" "TF_LIB_PATH=$OLD TF_HOIST_STEP_INVARIANTS=0" "$@"     # (an earlier round's library has no tf_set_step_params_copy)
-  one "new[$i]" "TF_AB_DUMMY=1" "$@"
+  one "new[$i]" "TF_HOIST_STEP_INVARIANTS=0" "$@"
 done
