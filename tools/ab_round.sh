@@ -2,6 +2,10 @@
 # tools/ab_round.sh ROUNDS OLD_LIB OLD_TABLE [bench args...]: same-box A/B of this round's library + shipped table against an earlier round's library WITH ITS OWN TABLE
 # (an old library drops table rows of kernel variants it does not know and would run those shapes on a fallback tile), both arms with identical settings otherwise;
 # alternating, one bench process per measurement.  GPU box only.  e.g. tools/ab_round.sh 3 _r04lib/libtinyfusers_hip.so _r04lib/gemm_tune_r04.txt --images 4 --latent 96
+# The old library and its table are not in the history (_rNNlib/ is git-ignored: binaries).  To recreate round 4's (commit d7b0887, "round 4: VERDICT + ADVICE + BENCH"):
+#   git worktree add /tmp/r04 d7b0887 && (cd /tmp/r04 && python -m tinyfusers_amd.build) && mkdir -p _r04lib && cp /tmp/r04/tinyfusers_amd/lib/libtinyfusers_hip.so _r04lib/
+#   git show d7b0887:tinyfusers_amd/gemm_tune_gfx950.txt > _r04lib/gemm_tune_r04.txt
+# (the directory travels to the GPU box with gpurun: it is not in .gpurunignore)
 R=$1; OLD=$2; OLDT=$3; shift 3
 mkdir -p gpurun_out
 one() {   # label, env assignments (space separated)
